@@ -1,0 +1,179 @@
+/* rvcx.h -- C ABI of librvcx.so: the MI355X-native RVC v2 inference hot path.
+ *
+ * The reference (Bebra777228/PolGen-RVC) is pure Python; it has no FFI of its own.  Each
+ * entry point below names the reference interface (file:line under /root/reference) whose
+ * work it replaces; the Python mirror in polgen-rvc_amd/infer/{infer,pipeline}.py binds
+ * them with ctypes behind the reference's own call signatures.
+ *
+ * Conventions: return 0 on success, negative on error (message via rvcx_last_error);
+ * nothing throws across the ABI.  One context per GPU; calls on one context are
+ * serialised by the caller, different contexts are fully concurrent.  "hd" pointers may
+ * be host or device memory (copied with hipMemcpyDefault); everything else is host.
+ * All tensors are dense row-major float32 unless stated.
+ */
+#ifndef RVCX_H
+#define RVCX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rvcx_ctx rvcx_ctx;
+
+/* one checkpoint tensor, borrowed for the duration of the load call only */
+typedef struct {
+  const char* name;
+  const void* data;
+  int32_t dtype; /* 0 = float32, 1 = float16, 2 = int64 */
+  int32_t ndim;
+  int64_t shape[4];
+} rvcx_tensor;
+
+/* Synthesizer(*cpt["config"]) hyper-parameters -- rvc/infer/infer.py:86-97,
+ * rvc/lib/algorithm/synthesizers.py:14-36 */
+typedef struct {
+  int32_t inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size;
+  int32_t n_resblocks;          /* len(resblock_kernel_sizes) (<= 4) */
+  int32_t res_kernels[4];
+  int32_t res_dilations[4][3];
+  int32_t n_ups;                /* len(upsample_rates) (<= 6) */
+  int32_t up_rates[6], up_kernels[6];
+  int32_t up_initial_channel, spk_embed_dim, gin_channels, sr, input_dim;
+} rvcx_synth_cfg;
+
+/* E2E(n_blocks, n_gru, kernel_size=(2,2), en_de_layers, inter_layers, in_channels,
+ * en_out_channels) -- rvc/lib/predictors/RMVPE.py:340-352,452 */
+typedef struct {
+  int32_t n_blocks, en_de_layers, inter_layers, en_out_channels;
+} rvcx_rmvpe_cfg;
+
+/* fairseq HubertModel (hubert_base) geometry -- loaded at rvc/infer/infer.py:67-74 */
+typedef struct {
+  int32_t conv_dim, n_conv;
+  int32_t conv_kernels[8], conv_strides[8];
+  int32_t embed_dim, ffn_dim, heads, layers, pos_kernel, pos_groups;
+} rvcx_hubert_cfg;
+
+/* per-call conversion parameters -- the keyword set of VC.pipeline / rvc_infer
+ * (rvc/infer/pipeline.py:289-311, rvc/infer/infer.py:109-128) plus Config's chunk geometry
+ * (rvc/infer/infer.py:36-43) */
+typedef struct {
+  float pitch;            /* semitones */
+  float f0_min, f0_max;
+  float index_rate;
+  float protect;
+  float volume_envelope;
+  int32_t sid;
+  int32_t x_pad, x_query, x_center, x_max; /* seconds */
+  uint64_t seed;          /* Philox seed for the two Gaussian draws when noise == NULL */
+} rvcx_params;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+int rvcx_create(int device, rvcx_ctx** out);
+void rvcx_destroy(rvcx_ctx* ctx);
+const char* rvcx_last_error(rvcx_ctx* ctx); /* ctx may be NULL: last error of this thread */
+const char* rvcx_version(void);
+
+/* ---- model loading (host tensors in checkpoint layout; folded + packed + uploaded) ---- */
+/* replaces load_hubert -- rvc/infer/infer.py:67-74 */
+int rvcx_load_hubert(rvcx_ctx*, const rvcx_hubert_cfg*, const rvcx_tensor* tbl, int n);
+/* replaces RMVPE0Predictor.__init__ -- rvc/lib/predictors/RMVPE.py:442-459 */
+int rvcx_load_rmvpe(rvcx_ctx*, const rvcx_rmvpe_cfg*, const rvcx_tensor* tbl, int n);
+/* replaces get_vc's Synthesizer construction -- rvc/infer/infer.py:78-105 */
+int rvcx_load_synth(rvcx_ctx*, const rvcx_synth_cfg*, const rvcx_tensor* tbl, int n, int* model_id);
+int rvcx_unload_synth(rvcx_ctx*, int model_id);
+/* replaces faiss.read_index + reconstruct_n -- rvc/infer/pipeline.py:322-323.
+ * big_npy is the (n, dim) float32 matrix of stored vectors; NULL/0 drops the index. */
+int rvcx_load_index(rvcx_ctx*, const float* big_npy, int64_t n, int dim);
+
+/* folded-weight blob of everything loaded so far (contiguous device memory) -- used to
+ * broadcast weights to other ranks with RCCL instead of re-loading from host */
+int rvcx_weights_blob(rvcx_ctx*, void** dev_ptr, int64_t* nbytes);
+
+/* ---- stage-level entry points (parity tests bind these) ------------------------------- */
+/* RMVPE0Predictor.infer_from_audio_with_pitch -- rvc/lib/predictors/RMVPE.py:487-496.
+ * audio (B, n) -> f0 (B, 1 + n/160) Hz; hidden (B, frames, 360) optional. */
+int rvcx_rmvpe_f0(rvcx_ctx*, int B, const float* audio_hd, int64_t n, float thred, float f0_min,
+                  float f0_max, float* f0_hd, float* hidden_hd);
+int rvcx_rmvpe_frames(int64_t n);
+/* HubertModel.extract_features(source, padding_mask=False, output_layer=L)[0] --
+ * call site rvc/infer/pipeline.py:228-236.  wav (B, n) -> feats (B, T', embed_dim). */
+int rvcx_hubert_features(rvcx_ctx*, int B, const float* wav_hd, int64_t n, int output_layer,
+                         float* feats_hd);
+int rvcx_hubert_frames(rvcx_ctx*, int64_t n);
+/* Synthesizer.infer -- rvc/lib/algorithm/synthesizers.py:163-188.
+ * phone (B,T,input_dim), pitch (B,T) int32 coarse, pitchf (B,T) Hz, lens (B) valid frames,
+ * sid (B).  z_noise (B,inter,T) / src_noise (B,T*upp) replace the two randn_like draws when
+ * non-NULL (parity mode), otherwise Philox(seed).  out (B, T*upp). */
+int rvcx_synth_infer(rvcx_ctx*, int model_id, int B, int T, const int32_t* lens,
+                     const float* phone_hd, const int32_t* pitch_hd, const float* pitchf_hd,
+                     const int32_t* sid, const float* z_noise_hd, const float* src_noise_hd,
+                     uint64_t seed, float* out_hd);
+int rvcx_synth_upp(rvcx_ctx*, int model_id);
+/* index.search(k=8) + weighted blend -- rvc/infer/pipeline.py:239-250.
+ * feats (T, dim) in/out; ids (T,8) int64 and dist (T,8) optional. */
+int rvcx_index_blend(rvcx_ctx*, float* feats_hd, int T, float index_rate, int64_t* ids_hd,
+                     float* dist_hd);
+
+/* ---- whole path ------------------------------------------------------------------------ */
+/* number of int16 samples VC.pipeline returns for an n-sample 16 kHz input */
+int64_t rvcx_out_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
+/* VC.pipeline for a batch of utterances -- rvc/infer/pipeline.py:289-467 with
+ * f0_method="rmvpe+", pitch_guidance=1, resample_sr=0, f0_file=None.
+ * wav16k[i] (n[i] samples, 16 kHz mono f32, host or device); out[i] caller-allocated int16
+ * buffers of rvcx_out_len samples (host or device); out_f32[i] optional pre-quantisation
+ * float waveform; noise[i] optional packed parity noise (see rvcx_noise_len). */
+int rvcx_convert_batch(rvcx_ctx*, int model_id, int B, const float* const* wav16k_hd,
+                       const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
+                       int16_t* const* out_hd, float* const* out_f32_hd);
+/* floats of parity noise rvcx_convert_batch consumes for one n-sample utterance: for each
+ * chunk in order, z_noise (inter*T) then src_noise (T*upp) -- the draw order of the reference */
+int64_t rvcx_noise_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
+/* VC.get_f0 -- rvc/infer/pipeline.py:132-201 on the reflect-padded, high-passed signal:
+ * returns coarse (int32) and f0 (Hz) of p_len frames for one utterance */
+int rvcx_get_f0(rvcx_ctx*, const float* wav16k_hd, int64_t n, const rvcx_params* p,
+                int32_t* coarse, float* f0, int64_t* p_len);
+
+/* ---- instrumentation ------------------------------------------------------------------- */
+/* per-stage GPU milliseconds (HIP events on the library's stream) of the last
+ * rvcx_convert_batch: {highpass, rmvpe, hubert, index, enc_p, flow, decoder, post, total} */
+int rvcx_last_timing(rvcx_ctx*, float* ms9);
+/* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */
+double rvcx_flop_counter(rvcx_ctx*, int reset);
+void* rvcx_stream(rvcx_ctx*); /* hipStream_t the library launches on */
+
+/* ---- kernel-level entry points (unit parity tests of the HIP kernels) ------------------ */
+/* y = act(conv1d(pre(x), w) + bias) + res ; x (B,Cin,Tin) w (Cout,Cin/groups,K) host f32 */
+int rvcx_op_conv1d(rvcx_ctx*, const float* x, const float* w, const float* bias, const float* res,
+                   float* y, int B, int Cin, int Tin, int Cout, int K, int stride, int dil,
+                   int pad_left, int Tout, int groups, int pre_lrelu, float pre_slope, int act,
+                   float act_slope, const int32_t* lens_in, const int32_t* lens_out);
+/* ConvTranspose1d: w (Cin,Cout,K), padding p; Tout = (Tin-1)*s - 2p + K */
+int rvcx_op_convtranspose1d(rvcx_ctx*, const float* x, const float* w, const float* bias, float* y,
+                            int B, int Cin, int Tin, int Cout, int K, int stride, int pad,
+                            int pre_lrelu, float pre_slope);
+/* Conv2d 3x3 pad 1 (+bias, act, res) on (B,Cin,H,W) */
+int rvcx_op_conv2d3x3(rvcx_ctx*, const float* x, const float* w, const float* bias, const float* res,
+                      float* y, int B, int Cin, int H, int W, int Cout, int act);
+/* ConvTranspose2d 3x3 stride 2 pad 1 output_padding 1: (B,Cin,H,W) -> (B,Cout,2H,2W), w (Cin,Cout,3,3) */
+int rvcx_op_convtranspose2d(rvcx_ctx*, const float* x, const float* w, const float* bias, float* y,
+                            int B, int Cin, int H, int W, int Cout, int act);
+/* softmax(q k^T [+ rel-pos bias]) v on (B, H*D, T) channel-first tensors; emb_rel_k/v (2w+1, D) or NULL */
+int rvcx_op_attention(rvcx_ctx*, const float* q, const float* k, const float* v, float* out, int B,
+                      int H, int D, int T, float scale, const float* emb_rel_k,
+                      const float* emb_rel_v, int window, const int32_t* lens);
+/* LayerNorm over channels of (B,C,T) */
+int rvcx_op_layernorm_c(rvcx_ctx*, const float* x, const float* gamma, const float* beta, float* y,
+                        int B, int C, int T, float eps);
+/* bidirectional GRU: x (B,T,I) -> y (B,T,2H); weights in torch layout */
+int rvcx_op_bigru(rvcx_ctx*, const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                  const float* b_hh, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
+                  const float* b_hh_r, float* y, int B, int T, int I, int H);
+/* scipy.signal.filtfilt(bh, ah, x) of pipeline.py:19-22,329 (float64) */
+int rvcx_op_highpass(rvcx_ctx*, const double* x, double* y, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVCX_H */

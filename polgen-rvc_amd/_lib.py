@@ -1,0 +1,208 @@
+"""ctypes binding of librvcx.so (C ABI declared in include/rvcx.h).
+
+Loading is strict: a missing library is an ImportError-grade failure (``RvcxError``) -- there
+is no CPU fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librvcx.so")
+
+
+class RvcxError(RuntimeError):
+    pass
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32),
+                ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("inter_channels", C.c_int32), ("hidden_channels", C.c_int32),
+                ("filter_channels", C.c_int32), ("n_heads", C.c_int32), ("n_layers", C.c_int32),
+                ("kernel_size", C.c_int32), ("n_resblocks", C.c_int32),
+                ("res_kernels", C.c_int32 * 4), ("res_dilations", (C.c_int32 * 3) * 4),
+                ("n_ups", C.c_int32), ("up_rates", C.c_int32 * 6), ("up_kernels", C.c_int32 * 6),
+                ("up_initial_channel", C.c_int32), ("spk_embed_dim", C.c_int32),
+                ("gin_channels", C.c_int32), ("sr", C.c_int32), ("input_dim", C.c_int32)]
+
+
+class RmvpeCfg(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("en_de_layers", C.c_int32), ("inter_layers", C.c_int32),
+                ("en_out_channels", C.c_int32)]
+
+
+class HubertCfg(C.Structure):
+    _fields_ = [("conv_dim", C.c_int32), ("n_conv", C.c_int32), ("conv_kernels", C.c_int32 * 8),
+                ("conv_strides", C.c_int32 * 8), ("embed_dim", C.c_int32), ("ffn_dim", C.c_int32),
+                ("heads", C.c_int32), ("layers", C.c_int32), ("pos_kernel", C.c_int32),
+                ("pos_groups", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("pitch", C.c_float), ("f0_min", C.c_float), ("f0_max", C.c_float),
+                ("index_rate", C.c_float), ("protect", C.c_float), ("volume_envelope", C.c_float),
+                ("sid", C.c_int32), ("x_pad", C.c_int32), ("x_query", C.c_int32),
+                ("x_center", C.c_int32), ("x_max", C.c_int32), ("seed", C.c_uint64)]
+
+
+_lib = None
+
+# every symbol include/rvcx.h declares (tests/test_abi.py checks the .so exports all of them)
+SYMBOLS = [
+    "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
+    "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index",
+    "rvcx_weights_blob", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
+    "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
+    "rvcx_out_len", "rvcx_convert_batch", "rvcx_noise_len", "rvcx_get_f0", "rvcx_last_timing",
+    "rvcx_flop_counter", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_convtranspose1d",
+    "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
+    "rvcx_op_bigru", "rvcx_op_highpass",
+]
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RvcxError(f"{LIB_PATH} not built (run `make` / __graft_entry__.build()); "
+                            "rvcx has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rvcx_last_error.restype = C.c_char_p
+        _lib.rvcx_version.restype = C.c_char_p
+        _lib.rvcx_flop_counter.restype = C.c_double
+        _lib.rvcx_stream.restype = C.c_void_p
+        _lib.rvcx_out_len.restype = C.c_int64
+        _lib.rvcx_noise_len.restype = C.c_int64
+    return _lib
+
+
+def _p(a: Optional[np.ndarray], ctype=C.c_float):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def i32(a) -> Optional[np.ndarray]:
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def make_table(state: dict):
+    """dict name -> numpy/torch tensor  ->  (ctypes Tensor array, keep-alive list)."""
+    keep, items = [], []
+    for name, t in state.items():
+        if hasattr(t, "detach"):
+            t = t.detach().cpu().numpy()
+        a = np.asarray(t)
+        if a.dtype == np.float32:
+            dt = 0
+        elif a.dtype == np.float16:
+            dt = 1
+        elif a.dtype == np.int64:
+            dt = 2
+        else:
+            a = a.astype(np.float32)
+            dt = 0
+        a = np.ascontiguousarray(a)
+        if a.ndim > 4:
+            raise RvcxError(f"tensor {name} has {a.ndim} dims")
+        keep.append(a)
+        nm = name.encode()
+        keep.append(nm)
+        shp = (C.c_int64 * 4)(*(list(a.shape) + [1] * (4 - a.ndim)))
+        items.append(Tensor(nm, a.ctypes.data, dt, a.ndim, shp))
+    arr = (Tensor * len(items))(*items)
+    return arr, keep
+
+
+class Context:
+    """One rvcx context (= one GPU)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = lib().rvcx_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise RvcxError("rvcx_create: " + (lib().rvcx_last_error(None) or b"").decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rvcx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RvcxError(f"{what}: " + (lib().rvcx_last_error(self._h) or b"").decode())
+
+    # ---- kernel-level ops -------------------------------------------------------------
+    def conv1d(self, x, w, bias=None, res=None, stride=1, dil=1, pad_left=0, Tout=None, groups=1,
+               pre_lrelu=None, act=0, act_slope=0.0, lens_in=None, lens_out=None):
+        x, w = f32(x), f32(w)
+        B, Cin, Tin = x.shape
+        Cout, _, K = w.shape
+        if Tout is None:
+            Tout = (Tin + 2 * pad_left - dil * (K - 1) - 1) // stride + 1
+        y = np.empty((B, Cout, Tout), np.float32)
+        bias = None if bias is None else f32(bias)
+        res = None if res is None else f32(res)
+        li, lo = i32(lens_in), i32(lens_out)
+        self._ck(lib().rvcx_op_conv1d(self._h, _p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Tin, Cout, K,
+                                      stride, dil, pad_left, Tout, groups,
+                                      0 if pre_lrelu is None else 1,
+                                      C.c_float(0.0 if pre_lrelu is None else pre_lrelu), act,
+                                      C.c_float(act_slope), _p(li, C.c_int32), _p(lo, C.c_int32)), "op_conv1d")
+        return y
+
+    def convtranspose1d(self, x, w, bias=None, stride=1, pad=0, pre_lrelu=None):
+        x, w = f32(x), f32(w)
+        B, Cin, Tin = x.shape
+        _, Cout, K = w.shape
+        Tout = (Tin - 1) * stride - 2 * pad + K
+        y = np.empty((B, Cout, Tout), np.float32)
+        bias = None if bias is None else f32(bias)
+        self._ck(lib().rvcx_op_convtranspose1d(self._h, _p(x), _p(w), _p(bias), _p(y), B, Cin, Tin, Cout, K,
+                                               stride, pad, 0 if pre_lrelu is None else 1,
+                                               C.c_float(0.0 if pre_lrelu is None else pre_lrelu)),
+                 "op_convtranspose1d")
+        return y
+
+    def conv2d3x3(self, x, w, bias=None, res=None, act=0):
+        x, w = f32(x), f32(w)
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        y = np.empty((B, Cout, H, W), np.float32)
+        bias = None if bias is None else f32(bias)
+        res = None if res is None else f32(res)
+        self._ck(lib().rvcx_op_conv2d3x3(self._h, _p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, H, W, Cout,
+                                         act), "op_conv2d3x3")
+        return y
+
+    def convtranspose2d(self, x, w, bias=None, act=0):
+        x, w = f32(x), f32(w)
+        B, Cin, H, W = x.shape
+        Cout = w.shape[1]
+        y = np.empty((B, Cout, 2 * H, 2 * W), np.float32)
+        bias = None if bias is None else f32(bias)
+        self._ck(lib().rvcx_op_convtranspose2d(self._h, _p(x), _p(w), _p(bias), _p(y), B, Cin, H, W, Cout, act),
+                 "op_convtranspose2d")
+        return y
+
+    def flop_counter(self, reset=False) -> float:
+        return float(lib().rvcx_flop_counter(self._h, 1 if reset else 0))

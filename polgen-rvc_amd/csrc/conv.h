@@ -1,0 +1,79 @@
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32).
+//
+// One kernel family covers every conv / linear layer of the RVC hot path:
+//   conv1d (any k, stride, dilation, groups), linear (k=1), ConvTranspose1d (polyphase:
+//   a conv with stride*Cout output channels + shuffle store), Conv2d 3x3 on a row-padded
+//   map (flattened to 1-D with taps at {-Wp-1..Wp+1}), ConvTranspose2d 3x3 s2 (polyphase,
+//   4*Cout channels + 2-D shuffle store).
+//
+// GEMM view:  M = Cout (per group), N = output positions, K = ksize * Cin (per group).
+// Weights are pre-packed on the host as Wp[g][kk][ci_pad][co_pad] (co contiguous) so the A
+// fragment of lane (i = lane&31, h = lane>>5) for k-step (kk, ci pair cp) is
+// Wp[kk][2cp+h][co0+i]; the B fragment is X[2cp+h][(n0+j)*stride + off(kk)] read from an
+// LDS tile of the input (time contiguous -> conflict-free ds_read_b32).
+#pragma once
+#include "common.h"
+
+namespace rvcx {
+
+enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
+enum OutMode { OUT_NORMAL = 0, OUT_SHUF1D = 1, OUT_SHUF2D = 2, OUT_TRANSPOSED = 3 };
+enum Acc2 { ACC2_NONE = 0, ACC2_SET = 1, ACC2_ADD = 2, ACC2_ADD_DIV = 3 };
+
+struct ConvArgs {
+  const float* x = nullptr;
+  const float* w = nullptr;      // packed Wp[g][kk][Cin_gp][Cout_gp]
+  const float* bias = nullptr;   // [groups*Cout_g] or null
+  const float* res = nullptr;    // residual added after the activation (same indexing as y)
+  float* y = nullptr;            // may be null when only y2 is wanted
+  float* y2 = nullptr;           // secondary accumulator output (OUT_NORMAL only)
+  const int* lens_in = nullptr;  // per-batch valid input positions (null -> Tin)
+  const int* lens_out = nullptr; // per-batch valid output positions; beyond -> 0 is stored
+  int B = 1;
+  int Cin_g = 0, Cin_gp = 0, Cout_g = 0, Cout_gp = 0, groups = 1;
+  int Tin = 0;                   // input positions per (batch, channel)
+  int Nout = 0;                  // output positions computed per batch (GEMM N)
+  int ksize = 1, kw = 1, rowpitch = 0, dil = 1, pad = 0, stride = 1;
+  long x_bs = 0, y_bs = 0, res_bs = 0, y2_bs = 0;
+  int x_cs = 0, y_cs = 0, res_cs = 0, y2_cs = 0;
+  int pre_act = ACT_NONE;
+  float pre_slope = 0.f;
+  int act = ACT_NONE;
+  float act_slope = 0.f;
+  int out_mode = OUT_NORMAL;
+  int sh_s = 1, sh_pad = 0, sh_cout = 0, sh_tout = 0;  // OUT_SHUF1D
+  int wp_in = 0, wp_out = 0;                            // OUT_SHUF2D
+  int zero_wp = 0;               // >0: force the pad columns of a row-padded 2-D map to 0
+  int acc2_mode = ACC2_NONE;
+  float acc2_div = 1.f;
+  // filled by the launcher
+  int ci_chunk = 0, kk_chunk = 0, wrow = 0, off_min = 0;
+};
+
+// tap offset of kernel element kk relative to n*stride (before subtracting off_min)
+inline int conv_tap_off(const ConvArgs& a, int kk) {
+  return (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad;
+}
+
+void conv_init();                                   // raise dynamic-LDS limits once
+void launch_conv(ConvArgs a, hipStream_t stream);   // picks tile + LDS chunking, launches
+double conv_flops(const ConvArgs& a);               // 2*M*N*K of the *real* (unpadded) problem
+
+// ---------------- host-side weight packing ------------------------------------------------
+int conv_cin_pad(int cin_g);
+int conv_cout_pad(int cout_g);
+// w: (Cout, Cin_g, K) row-major, Cout = groups*Cout_g.  Returns Wp[g][kk][Cin_gp][Cout_gp].
+std::vector<float> pack_conv_weight(const float* w, int cout, int cin_g, int k, int groups);
+// ConvTranspose1d weight (Cin, Cout, K), stride s, padding p -> polyphase conv with s*Cout
+// output channels and M = ceil((K + extra)/s) taps on the low-rate input.  See conv.hip.
+struct PolyPhase1d {
+  std::vector<float> w;     // packed
+  std::vector<float> bias;  // replicated per phase (s*Cout)
+  int taps = 0;             // ksize of the equivalent conv
+  int pad = 0;              // its left padding (taps look back: x[q - m])
+  int cout_total = 0;
+};
+PolyPhase1d pack_convtranspose1d(const float* w, const float* bias, int cin, int cout, int k, int s,
+                                 int p);
+
+}  // namespace rvcx

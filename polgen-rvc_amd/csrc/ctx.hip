@@ -1,0 +1,130 @@
+// Context lifecycle, checkpoint-tensor helpers, packed-layer constructors.
+#include "ctx.h"
+#include "layers.h"
+#include "models.h"
+
+namespace rvcx {
+
+float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+  uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff;
+  uint32_t f;
+  if (exp == 0) {
+    if (man == 0) {
+      f = sign;
+    } else {
+      exp = 127 - 15 + 1;
+      while (!(man & 0x400)) {
+        man <<= 1;
+        --exp;
+      }
+      man &= 0x3ff;
+      f = sign | (exp << 23) | (man << 13);
+    }
+  } else if (exp == 31) {
+    f = sign | 0x7f800000u | (man << 13);
+  } else {
+    f = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float out;
+  std::memcpy(&out, &f, 4);
+  return out;
+}
+
+std::vector<float> TensorTable::f32(const std::string& name) const {
+  const HostTensor& t = raw(name);
+  const int64_t n = t.numel();
+  std::vector<float> out((size_t)n);
+  if (t.dtype == 0) {
+    std::memcpy(out.data(), t.data, (size_t)n * 4);
+  } else if (t.dtype == 1) {
+    const uint16_t* p = static_cast<const uint16_t*>(t.data);
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = half_to_float(p[i]);
+  } else if (t.dtype == 2) {
+    const int64_t* p = static_cast<const int64_t*>(t.data);
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = (float)p[i];
+  } else {
+    fail("unsupported dtype for " + name);
+  }
+  return out;
+}
+
+Ctx::Ctx() {}
+
+Ctx::~Ctx() {
+  hubert.reset();
+  rmvpe.reset();
+  synths.clear();
+  index.reset();
+  if (timer.made)
+    for (auto& e : timer.ev) (void)hipEventDestroy(e);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  if (stream2) (void)hipStreamDestroy(stream2);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups) {
+  ConvW L;
+  L.cin = cin_g * groups;
+  L.cout = cout;
+  L.k = k;
+  L.groups = groups;
+  L.cin_gp = conv_cin_pad(cin_g);
+  L.cout_gp = conv_cout_pad(cout / groups);
+  L.w = c.slab.upload(pack_conv_weight(w, cout, cin_g, k, groups));
+  L.bias = bias ? c.slab.upload(bias, (size_t)cout) : nullptr;
+  return L;
+}
+
+ConvT1dW make_convT1d(Ctx& c, const float* w, const float* bias, int cin, int cout, int k, int s, int p) {
+  PolyPhase1d pp = pack_convtranspose1d(w, bias, cin, cout, k, s, p);
+  ConvT1dW L;
+  L.w.cin = cin;
+  L.w.cout = pp.cout_total;
+  L.w.k = pp.taps;
+  L.w.groups = 1;
+  L.w.cin_gp = conv_cin_pad(cin);
+  L.w.cout_gp = conv_cout_pad(pp.cout_total);
+  L.w.w = c.slab.upload(pp.w);
+  L.w.bias = c.slab.upload(pp.bias);
+  L.stride = s;
+  L.pad_t = p;
+  L.cout_real = cout;
+  L.k_orig = k;
+  L.taps_pad = pp.pad;
+  return L;
+}
+
+ConvT2dW make_convT2d(Ctx& c, const float* w, const float* scale, const float* shift, int cin, int cout) {
+  // y[co][2i+a][2j+b] = sum_ci sum_(dy,dx) Wc[(a,b,co)][ci][(dy,dx)] x[ci][i+dy][j+dx]
+  //   a=0: dy=0 <-> ky=1          a=1: dy=0 <-> ky=2, dy=1 <-> ky=0      (same for b/kx)
+  // (oy = 2*iy - 1 + ky, RMVPE.py:263-271 stride 2, padding 1, output_padding 1)
+  std::vector<float> wc((size_t)4 * cout * cin * 4, 0.f);
+  auto kmap = [](int phase, int d) -> int {
+    if (phase == 0) return d == 0 ? 1 : -1;
+    return d == 0 ? 2 : 0;
+  };
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+              int ky = kmap(a, dy), kx = kmap(b, dx);
+              if (ky < 0 || kx < 0) continue;
+              float v = w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
+              if (scale) v *= scale[co];
+              wc[((((size_t)(a * 2 + b) * cout + co) * cin + ci) * 4) + dy * 2 + dx] = v;
+            }
+  std::vector<float> bias((size_t)4 * cout, 0.f);
+  if (shift)
+    for (int ph = 0; ph < 4; ++ph)
+      for (int co = 0; co < cout; ++co) bias[(size_t)ph * cout + co] = shift[co];
+  ConvT2dW L;
+  L.w = make_conv(c, wc.data(), bias.data(), 4 * cout, cin, 4, 1);
+  L.cout_real = cout;
+  return L;
+}
+
+}  // namespace rvcx

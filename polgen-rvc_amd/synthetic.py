@@ -1,0 +1,300 @@
+"""Deterministic synthetic checkpoints and clips in the *real* checkpoint layouts.
+
+There are no model weights in the build container and no network, so parity and
+benchmark runs use weights produced by a counter-based generator: every tensor is
+drawn from ``numpy.random.Philox(key = crc32(name) ^ seed)``, which makes any
+single tensor reproducible on its own (no stream ordering between tensors) and
+lets 0.85 GB of weights be regenerated on the GPU box instead of being committed.
+
+Layouts follow SURVEY.md Appendix B (names/shapes dumped from the reference):
+  * voice model  : rvc/infer/infer.py:78-105 (``cpt = {"weight", "config", "f0", "version"}``)
+  * rmvpe.pt     : rvc/lib/predictors/RMVPE.py:449-456 (bare state_dict of E2E(4,1,(2,2)))
+  * hubert_base  : fairseq 0.12.2 HubertModel naming (not vendored in the reference)
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# canonical RVC v2 configs (read from the checkpoint by the reference, infer.py:92-97)
+SYNTH_CFG_48K = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11],
+                 [[1, 3, 5], [1, 3, 5], [1, 3, 5]], [12, 10, 2, 2], 512,
+                 [24, 20, 4, 4], 109, 256, 48000]
+SYNTH_CFG_40K = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11],
+                 [[1, 3, 5], [1, 3, 5], [1, 3, 5]], [10, 10, 2, 2], 512,
+                 [16, 16, 4, 4], 109, 256, 40000]
+# reduced config for fast unit tests: channel counts that are NOT multiples of the
+# 32-wide MFMA tile on purpose (exercises the padding / guard paths)
+SYNTH_CFG_TINY = [1025, 32, 48, 48, 96, 2, 2, 3, 0, "1", [3, 7, 11],
+                  [[1, 3, 5], [1, 3, 5], [1, 3, 5]], [4, 3, 2, 2], 80,
+                  [8, 7, 4, 4], 5, 24, 4800]
+
+RMVPE_CFG_FULL = dict(n_blocks=4, n_gru=1, en_de_layers=5, inter_layers=4,
+                      in_channels=1, en_out_channels=16)
+RMVPE_CFG_TINY = dict(n_blocks=1, n_gru=1, en_de_layers=2, inter_layers=1,
+                      in_channels=1, en_out_channels=4)
+
+HUBERT_CFG_BASE = dict(conv_dim=512, conv_kernels=[10, 3, 3, 3, 3, 2, 2],
+                       conv_strides=[5, 2, 2, 2, 2, 2, 2], embed_dim=768, ffn_dim=3072,
+                       heads=12, layers=12, pos_kernel=128, pos_groups=16, final_dim=256)
+HUBERT_CFG_TINY = dict(conv_dim=48, conv_kernels=[10, 3, 3, 3, 3, 2, 2],
+                       conv_strides=[5, 2, 2, 2, 2, 2, 2], embed_dim=128, ffn_dim=160,
+                       heads=2, layers=2, pos_kernel=128, pos_groups=16, final_dim=32)
+
+
+# ----------------------------------------------------------------------------
+# counter-based per-tensor generator
+# ----------------------------------------------------------------------------
+def _rng(name: str, seed: int) -> np.random.Generator:
+    key = (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def _normal(name: str, shape, std: float, seed: int, mean: float = 0.0) -> np.ndarray:
+    x = _rng(name, seed).standard_normal(size=tuple(shape), dtype=np.float32)
+    return (x * np.float32(std) + np.float32(mean)).astype(np.float32)
+
+
+def _smooth_axis0(x: np.ndarray, width: float) -> np.ndarray:
+    """Gaussian low-pass along axis 0 (keeps overall scale)."""
+    n = x.shape[0]
+    r = int(3 * width)
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / width) ** 2)
+    k /= np.sqrt((k ** 2).sum())
+    pad = np.pad(x, ((r, r),) + ((0, 0),) * (x.ndim - 1), mode="wrap")
+    out = np.zeros_like(x)
+    for i, kv in enumerate(k):
+        out += np.float32(kv) * pad[i:i + n]
+    return out.astype(np.float32)
+
+
+class _Table:
+    def __init__(self, seed: int):
+        self.seed = seed
+        self.t: Dict[str, np.ndarray] = {}
+
+    def normal(self, name, shape, std, mean=0.0):
+        self.t[name] = _normal(name, shape, std, self.seed, mean)
+        return self.t[name]
+
+    def conv(self, prefix, shape, gain=1.0, bias=True, fan_in=None, bias_std=0.05, nbias=None):
+        fi = fan_in if fan_in is not None else int(np.prod(shape[1:]))
+        self.normal(prefix + ".weight", shape, gain / math.sqrt(max(fi, 1)))
+        if bias:
+            self.normal(prefix + ".bias", (nbias if nbias is not None else shape[0],), bias_std)
+
+    def wn_conv(self, prefix, shape, gain=1.0, fan_in=None, bias_std=0.05, nbias=None):
+        """weight-normalised conv in the parametrized layout (original0 = g, original1 = v)."""
+        fi = fan_in if fan_in is not None else int(np.prod(shape[1:]))
+        v = self.normal(prefix + ".parametrizations.weight.original1", shape, 1.0)
+        vn = np.sqrt((v.reshape(shape[0], -1).astype(np.float64) ** 2).sum(1))
+        target = gain / math.sqrt(max(fi, 1)) * math.sqrt(int(np.prod(shape[1:])))
+        jitter = 1.0 + 0.1 * _rng(prefix + ".g", self.seed).standard_normal(shape[0])
+        g = (target * jitter * vn / np.maximum(vn, 1e-12)).astype(np.float32)
+        self.t[prefix + ".parametrizations.weight.original0"] = g.reshape(
+            (shape[0],) + (1,) * (len(shape) - 1))
+        self.normal(prefix + ".bias", (nbias if nbias is not None else shape[0],), bias_std)
+
+
+# ----------------------------------------------------------------------------
+# Synthesizer (enc_q removed, as after infer.py:99)
+# ----------------------------------------------------------------------------
+def synth_state(cfg: List, seed: int = 0, input_dim: int = 768) -> Dict[str, np.ndarray]:
+    (_, _, inter, hidden, filt, n_heads, n_layers, ksz, _, _, rks, rds, ups, up_init,
+     upks, spk, gin, _) = cfg
+    T = _Table(seed)
+    kch = hidden // n_heads
+    # enc_p (encoders.py:76-126)
+    T.conv("enc_p.emb_phone", (hidden, input_dim), gain=0.1)
+    T.t["enc_p.emb_pitch.weight"] = _smooth_axis0(
+        _normal("enc_p.emb_pitch.weight", (256, hidden), 0.1, seed), 6.0)
+    for i in range(n_layers):
+        a = f"enc_p.encoder.attn_layers.{i}"
+        T.normal(a + ".emb_rel_k", (1, 21, kch), kch ** -0.5)
+        T.normal(a + ".emb_rel_v", (1, 21, kch), kch ** -0.5)
+        for n in ("conv_q", "conv_k", "conv_v", "conv_o"):
+            T.conv(f"{a}.{n}", (hidden, hidden, 1), gain=1.0)
+        for j in (1, 2):
+            T.normal(f"enc_p.encoder.norm_layers_{j}.{i}.gamma", (hidden,), 0.1, 1.0)
+            T.normal(f"enc_p.encoder.norm_layers_{j}.{i}.beta", (hidden,), 0.05)
+        T.conv(f"enc_p.encoder.ffn_layers.{i}.conv_1", (filt, hidden, ksz), gain=1.0)
+        T.conv(f"enc_p.encoder.ffn_layers.{i}.conv_2", (hidden, filt, ksz), gain=1.0)
+    T.conv("enc_p.proj", (2 * inter, hidden, 1), gain=0.5)
+    # dec (nsf.py:43-118)
+    T.t["dec.m_source.l_linear.weight"] = _normal("dec.m_source.l_linear.weight", (1, 1), 0.1, seed, 1.0)
+    T.normal("dec.m_source.l_linear.bias", (1,), 0.01)
+    T.conv("dec.conv_pre", (up_init, inter, 7), gain=1.0)
+    T.conv("dec.cond", (up_init, gin, 1), gain=0.3)
+    ch = up_init
+    for i, (u, k) in enumerate(zip(ups, upks)):
+        co = up_init // (2 ** (i + 1))
+        # ConvTranspose1d weight is (Cin, Cout, k); g is per *input* channel (dim=0)
+        T.wn_conv(f"dec.ups.{i}", (ch, co, k), gain=1.0, fan_in=max(1, (ch * k) // u), nbias=co)
+        sf0 = int(np.prod(ups[i + 1:])) if i + 1 < len(ups) else 1
+        nk = sf0 * 2 if sf0 > 1 else 1
+        T.conv(f"dec.noise_convs.{i}", (co, 1, nk), gain=1.0)
+        for j, (rk, rd) in enumerate(zip(rks, rds)):
+            for m in range(len(rd)):
+                T.wn_conv(f"dec.resblocks.{i * len(rks) + j}.convs1.{m}", (co, co, rk), gain=0.6)
+                T.wn_conv(f"dec.resblocks.{i * len(rks) + j}.convs2.{m}", (co, co, rk), gain=0.6)
+        ch = co
+    T.conv("dec.conv_post", (1, ch, 7), gain=1.0, bias=False)
+    # flow (residuals.py:109-232): 4 coupling layers at even indices
+    half = inter // 2
+    for f in (0, 2, 4, 6):
+        p = f"flow.flows.{f}"
+        T.conv(p + ".pre", (hidden, half, 1), gain=1.0)
+        for i in range(3):
+            T.wn_conv(f"{p}.enc.in_layers.{i}", (2 * hidden, hidden, 5), gain=1.0)
+            rs = hidden if i == 2 else 2 * hidden
+            T.wn_conv(f"{p}.enc.res_skip_layers.{i}", (rs, hidden, 1), gain=0.7)
+        T.wn_conv(p + ".enc.cond_layer", (2 * hidden * 3, gin, 1), gain=0.5)
+        T.conv(p + ".post", (half, hidden, 1), gain=0.3)
+    T.normal("emb_g.weight", (spk, gin), 0.3)
+    return T.t
+
+
+def synth_checkpoint(cfg: List, seed: int = 0, version: str = "v2") -> dict:
+    """The dict ``torch.load(model.pth)`` returns for a voice model (numpy tensors)."""
+    return {"weight": synth_state(cfg, seed), "config": list(cfg), "f0": 1,
+            "version": version, "sr": f"{cfg[-1] // 1000}k", "info": "synthetic"}
+
+
+# ----------------------------------------------------------------------------
+# RMVPE E2E (RMVPE.py:340-376)
+# ----------------------------------------------------------------------------
+def _bn(T: _Table, prefix: str, c: int):
+    T.normal(prefix + ".weight", (c,), 0.1, 1.0)
+    T.normal(prefix + ".bias", (c,), 0.05)
+    T.normal(prefix + ".running_mean", (c,), 0.05)
+    T.t[prefix + ".running_var"] = (1.0 + 0.1 * np.abs(
+        _normal(prefix + ".running_var", (c,), 1.0, T.seed))).astype(np.float32)
+    T.t[prefix + ".num_batches_tracked"] = np.array(1000, dtype=np.int64)
+
+
+def _conv_block_res(T: _Table, prefix: str, cin: int, cout: int):
+    g = 1.0
+    T.conv(prefix + ".conv.0", (cout, cin, 3, 3), gain=g, bias=False)
+    _bn(T, prefix + ".conv.1", cout)
+    T.conv(prefix + ".conv.3", (cout, cout, 3, 3), gain=g, bias=False)
+    _bn(T, prefix + ".conv.4", cout)
+    if cin != cout:
+        T.conv(prefix + ".shortcut", (cout, cin, 1, 1), gain=0.7)
+
+
+def rmvpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
+    cfg = cfg or RMVPE_CFG_FULL
+    nb, nenc, nint, c0 = cfg["n_blocks"], cfg["en_de_layers"], cfg["inter_layers"], cfg["en_out_channels"]
+    T = _Table(seed + 17)
+    _bn(T, "unet.encoder.bn", cfg["in_channels"])
+    cin, cout = cfg["in_channels"], c0
+    for l in range(nenc):
+        for b in range(nb):
+            _conv_block_res(T, f"unet.encoder.layers.{l}.conv.{b}", cin if b == 0 else cout, cout)
+        cin, cout = cout, cout * 2
+    # intermediate: first layer cin -> cout (=2*cin)
+    for l in range(nint):
+        for b in range(nb):
+            _conv_block_res(T, f"unet.intermediate.layers.{l}.conv.{b}",
+                            cin if (l == 0 and b == 0) else cout, cout)
+    dch = cout
+    for l in range(nenc):
+        oc = dch // 2
+        p = f"unet.decoder.layers.{l}"
+        # ConvTranspose2d weight (Cin, Cout, 3, 3); effective fan-in ~ Cin*9/4
+        T.conv(p + ".conv1.0", (dch, oc, 3, 3), gain=1.4, bias=False, fan_in=max(1, dch * 9 // 4))
+        _bn(T, p + ".conv1.1", oc)
+        for b in range(nb):
+            _conv_block_res(T, f"{p}.conv2.{b}", oc * 2 if b == 0 else oc, oc)
+        dch = oc
+    T.conv("cnn", (3, c0, 3, 3), gain=1.0)
+    H = 256
+    for sfx in ("", "_reverse"):
+        T.normal(f"fc.0.gru.weight_ih_l0{sfx}", (3 * H, 384), 1.0 / math.sqrt(384))
+        T.normal(f"fc.0.gru.weight_hh_l0{sfx}", (3 * H, H), 1.0 / math.sqrt(H))
+        T.normal(f"fc.0.gru.bias_ih_l0{sfx}", (3 * H,), 0.05)
+        T.normal(f"fc.0.gru.bias_hh_l0{sfx}", (3 * H,), 0.05)
+    # smooth across the 360 pitch bins so the salience has a few broad peaks (like a
+    # trained model) instead of 360 i.i.d. values whose argmax is rounding-sensitive
+    w = _normal("fc.1.weight", (360, 2 * H), 1.0, seed + 17)
+    T.t["fc.1.weight"] = (_smooth_axis0(w, 9.0) * np.float32(4.0 / math.sqrt(2 * H))).astype(np.float32)
+    T.t["fc.1.bias"] = _smooth_axis0(_normal("fc.1.bias", (360,), 1.0, seed + 17), 9.0) * np.float32(0.3) - np.float32(8.0 if c0 >= 16 else 10.3)
+    return T.t
+
+
+# ----------------------------------------------------------------------------
+# HuBERT base, fairseq 0.12.2 key names
+# ----------------------------------------------------------------------------
+def hubert_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
+    cfg = cfg or HUBERT_CFG_BASE
+    T = _Table(seed + 31)
+    C, E, Fd = cfg["conv_dim"], cfg["embed_dim"], cfg["ffn_dim"]
+    cin = 1
+    for i, k in enumerate(cfg["conv_kernels"]):
+        T.conv(f"feature_extractor.conv_layers.{i}.0", (C, cin, k), gain=1.6 if i else 1.0, bias=False)
+        cin = C
+    T.normal("feature_extractor.conv_layers.0.2.weight", (C,), 0.1, 1.0)   # GroupNorm(C, C)
+    T.normal("feature_extractor.conv_layers.0.2.bias", (C,), 0.05)
+    T.normal("layer_norm.weight", (C,), 0.1, 1.0)
+    T.normal("layer_norm.bias", (C,), 0.05)
+    T.conv("post_extract_proj", (E, C), gain=1.0)
+    # pos_conv: weight_norm(dim=2) -> g has shape (1,1,K), v (E, E/groups, K)
+    K, G = cfg["pos_kernel"], cfg["pos_groups"]
+    v = T.normal("encoder.pos_conv.0.weight_v", (E, E // G, K), 1.0)
+    vn = np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True))
+    target = 0.7 / math.sqrt(E // G * K) * math.sqrt(E * (E // G))
+    jitter = 1.0 + 0.1 * _rng("encoder.pos_conv.0.g", seed + 31).standard_normal((1, 1, K))
+    T.t["encoder.pos_conv.0.weight_g"] = (target * jitter * vn / np.maximum(vn, 1e-12)).astype(np.float32)
+    T.normal("encoder.pos_conv.0.bias", (E,), 0.05)
+    T.normal("encoder.layer_norm.weight", (E,), 0.1, 1.0)
+    T.normal("encoder.layer_norm.bias", (E,), 0.05)
+    for l in range(cfg["layers"]):
+        p = f"encoder.layers.{l}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            T.conv(f"{p}.self_attn.{n}", (E, E), gain=1.0 if n != "out_proj" else 0.7)
+        T.normal(p + ".self_attn_layer_norm.weight", (E,), 0.1, 1.0)
+        T.normal(p + ".self_attn_layer_norm.bias", (E,), 0.05)
+        T.conv(p + ".fc1", (Fd, E), gain=1.0)
+        T.conv(p + ".fc2", (E, Fd), gain=0.7)
+        T.normal(p + ".final_layer_norm.weight", (E,), 0.1, 1.0)
+        T.normal(p + ".final_layer_norm.bias", (E,), 0.05)
+    # present in real checkpoints, unused by the v2 path (pipeline.py:236 uses final_proj for v1 only)
+    T.normal("mask_emb", (E,), 0.1)
+    T.conv("final_proj", (cfg["final_dim"], E), gain=1.0)
+    return T.t
+
+
+# ----------------------------------------------------------------------------
+# synthetic clips
+# ----------------------------------------------------------------------------
+def make_clip(index: int, seconds: float, sr: int = 16000) -> np.ndarray:
+    """Harmonic-plus-noise 16 kHz mono clip, seed 1000+index, float32 in [-1,1]."""
+    rng = np.random.Generator(np.random.PCG64(1000 + index))
+    n = int(round(seconds * sr))
+    t = np.arange(n, dtype=np.float64) / sr
+    phi = rng.uniform(0, 2 * np.pi)
+    f0 = 220.0 * 2.0 ** (0.25 * np.sin(2 * np.pi * 0.5 * t + phi))
+    phase = 2 * np.pi * np.cumsum(f0) / sr
+    x = np.zeros(n)
+    for h in range(1, 6):
+        x += np.sin(h * phase) / h
+    gate = ((t % 1.0) < 0.8).astype(np.float64)
+    # 5 ms raised-cosine edges on the voiced gate
+    edge = int(0.005 * sr)
+    k = np.hanning(2 * edge + 1)
+    gate = np.convolve(gate, k / k.sum(), mode="same")
+    x = 0.3 * x * gate + 0.01 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def make_index(n: int, dim: int = 768, seed: int = 0) -> np.ndarray:
+    """Synthetic retrieval matrix (the ``big_npy`` of pipeline.py:323)."""
+    return _normal(f"index.{n}.{dim}", (n, dim), 1.0, seed)
+
+
+def to_torch(state: Dict[str, np.ndarray]):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}

@@ -1,0 +1,123 @@
+"""Parity of the MFMA implicit-GEMM conv kernel family (polgen-rvc_amd/csrc/conv.hip) against
+torch-CPU fp32 (floating-point kernel: tolerance 2e-5 relative RMS, fp32 accumulate order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _chk(got, ref, tag=""):
+    ref = ref.numpy() if hasattr(ref, "numpy") else ref
+    e = rms(got - ref) / max(rms(ref), 1e-12)
+    assert np.isfinite(got).all(), tag
+    assert e < TOL, f"{tag}: rel rms err {e:.3e}"
+
+
+CASES_1D = [
+    # B, Cin, Tin, Cout, K, stride, dil, groups
+    (1, 32, 300, 32, 3, 1, 1, 1),
+    (2, 64, 517, 64, 7, 1, 3, 1),
+    (1, 128, 400, 128, 11, 1, 5, 1),
+    (1, 256, 257, 256, 3, 1, 1, 1),
+    (1, 192, 100, 768, 3, 1, 1, 1),
+    (1, 768, 131, 192, 1, 1, 1, 1),
+    (1, 1, 4000, 48, 10, 5, 1, 1),      # HuBERT conv0 shape (Cin=1, strided)
+    (2, 48, 799, 48, 3, 2, 1, 1),
+    (1, 48, 399, 48, 2, 2, 1, 1),
+    (1, 1, 6000, 40, 24, 12, 1, 1),     # noise conv (Cin=1, k=2*stride)
+    (1, 128, 70, 128, 128, 1, 1, 16),   # HuBERT pos_conv (grouped, k=128)
+    (1, 24, 50, 288, 1, 1, 1, 1),       # odd channel counts -> padding guards
+    (3, 5, 33, 7, 5, 1, 1, 1),
+    (1, 32, 1, 1, 7, 1, 1, 1),          # conv_post shape, T=1
+]
+
+
+@pytest.mark.parametrize("case", CASES_1D)
+def test_conv1d(ctx, case):
+    B, Cin, Tin, Cout, K, s, d, g = case
+    gen = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, Tin, generator=gen)
+    w = torch.randn(Cout, Cin // g, K, generator=gen) / (Cin // g * K) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    pad = (K * d - d) // 2 if s == 1 else 0
+    if g > 1:
+        pad = K // 2
+    ref = F.conv1d(x, w, b, stride=s, dilation=d, padding=pad, groups=g)
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), stride=s, dil=d, pad_left=pad, groups=g, Tout=ref.shape[2])
+    _chk(got, ref, str(case))
+
+
+def test_conv1d_fused_epilogue(ctx):
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 333, generator=gen)
+    w = torch.randn(64, 64, 7, generator=gen) / (64 * 7) ** 0.5
+    b = torch.randn(64, generator=gen)
+    r = torch.randn(2, 64, 333, generator=gen)
+    # pre-activation lrelu(0.1) on the input, residual add after (ResBlock1 pattern, residuals.py:45-53)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=9, dilation=3) + r
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), res=r.numpy(), dil=3, pad_left=9, pre_lrelu=0.1)
+    _chk(got, ref, "pre+res")
+    for act, fn in ((1, lambda t: F.leaky_relu(t, 0.1)), (2, F.relu), (3, F.gelu), (4, torch.tanh),
+                    (5, torch.sigmoid)):
+        ref = fn(F.conv1d(x, w, b, padding=3)) + r
+        got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), res=r.numpy(), pad_left=3, act=act, act_slope=0.1)
+        _chk(got, ref, f"act{act}")
+
+
+def test_conv1d_ragged_lengths(ctx):
+    """(B,C,Tmax) batches with per-item lengths must equal running each item alone (zero padding at
+    each item's own end -- the x_mask semantics of encoders.py:120-123)."""
+    gen = torch.Generator().manual_seed(5)
+    lens = [97, 64, 1]
+    x = torch.randn(3, 48, 97, generator=gen)
+    w = torch.randn(96, 48, 3, generator=gen) / 12
+    b = torch.randn(96, generator=gen)
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), pad_left=1, lens_in=lens, lens_out=lens)
+    for i, L in enumerate(lens):
+        ref = F.conv1d(x[i:i + 1, :, :L], w, b, padding=1)[0]
+        _chk(got[i, :, :L], ref, f"item{i}")
+        assert (got[i, :, L:] == 0).all()
+
+
+@pytest.mark.parametrize("case", [(1, 64, 50, 32, 24, 12, 6), (2, 80, 37, 40, 8, 4, 2), (1, 40, 29, 20, 7, 3, 2),
+                                  (1, 128, 100, 64, 16, 10, 3), (1, 64, 300, 32, 4, 2, 1)])
+def test_convtranspose1d(ctx, case):
+    B, Cin, Tin, Cout, K, s, p = case
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, Tin, generator=gen)
+    w = torch.randn(Cin, Cout, K, generator=gen) / (Cin * K / s) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=p)
+    got = ctx.convtranspose1d(x.numpy(), w.numpy(), b.numpy(), stride=s, pad=p, pre_lrelu=0.1)
+    _chk(got, ref, str(case))
+
+
+@pytest.mark.parametrize("case", [(1, 1, 40, 128, 16), (2, 16, 33, 64, 32), (1, 64, 12, 8, 128), (1, 256, 6, 4, 512),
+                                  (1, 4, 64, 128, 3)])
+def test_conv2d3x3(ctx, case):
+    B, Cin, H, W, Cout = case
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn(B, Cout, H, W, generator=gen)
+    ref = F.relu(F.conv2d(x, w, b, padding=1)) + r          # ConvBlockRes tail, RMVPE.py:171-175
+    got = ctx.conv2d3x3(x.numpy(), w.numpy(), b.numpy(), res=r.numpy(), act=2)
+    _chk(got, ref, str(case))
+
+
+@pytest.mark.parametrize("case", [(1, 32, 10, 4, 16), (2, 8, 7, 16, 4), (1, 512, 5, 4, 256), (1, 32, 40, 64, 16)])
+def test_convtranspose2d(ctx, case):
+    B, Cin, H, W, Cout = case
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cin, Cout, 3, 3, generator=gen) / (Cin * 9 / 4) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    ref = F.relu(F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1))
+    got = ctx.convtranspose2d(x.numpy(), w.numpy(), b.numpy(), act=2)
+    _chk(got, ref, str(case))

@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (imported read-only from
+/root/reference in the build container) on deterministic synthetic weights, and check the
+oracle (oracle/*.py) against them while doing so.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--full]
+
+Nothing from /root/reference is copied: the fixtures hold inputs and expected outputs only;
+weights are regenerated on both sides from polgen-rvc_amd/synthetic.py.  Absent third-party
+modules are replaced by import-time stubs; HuBERT (fairseq, absent)
+is represented by transformers.HubertModel with the same synthetic weights mapped onto HF
+names, which is also the cross-check that pins oracle/hubert.py.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import transformers  # noqa: E402  (must be imported before the stubs, Appendix A.1)
+from transformers import HubertConfig, HubertModel
+
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools", "ref_stubs"))
+REF = "/root/reference"
+sys.path.append(REF)
+for name in ("torchcrepe", "faiss", "soundfile", "torchaudio", "local_attention"):
+    sys.modules[name] = types.ModuleType(name)
+ta = types.ModuleType("torchaudio.transforms")
+ta.Resample = object
+sys.modules["torchaudio.transforms"] = ta
+sys.modules["torchaudio"].transforms = ta
+sys.modules["local_attention"].LocalAttention = object
+
+import polgen_rvc_amd  # noqa: E402
+from polgen_rvc_amd import synthetic as S  # noqa: E402
+from oracle import synth as O_synth, rmvpe as O_rmvpe, hubert as O_hubert, pipeline as O_pipe  # noqa: E402
+
+import rvc.infer.pipeline as P  # noqa: E402  (reference)
+from rvc.lib.algorithm.synthesizers import Synthesizer  # noqa: E402
+from rvc.lib.predictors import RMVPE as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_grad_enabled(False)
+
+
+def rms(a):
+    a = np.asarray(a, dtype=np.float64)
+    return float(np.sqrt(np.mean(a * a)))
+
+
+def report(tag, ref, got):
+    ref, got = np.asarray(ref, np.float64), np.asarray(got, np.float64)
+    err = rms(ref - got)
+    print(f"  {tag:34s} rms_ref={rms(ref):.4e} rms_err={err:.3e} max_err={np.abs(ref - got).max():.3e}")
+    return err
+
+
+# ------------------------------------------------------------------ reference model builders
+def ref_synth(cfg, sd):
+    net = Synthesizer(*cfg, use_f0=1, input_dim=sd["enc_p.emb_phone.weight"].shape[1], is_half=False)
+    del net.enc_q
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.missing_keys and not missing.unexpected_keys, missing
+    return net.eval()
+
+
+def ref_rmvpe(cfg, sd):
+    pred = R.RMVPE0Predictor.__new__(R.RMVPE0Predictor)
+    pred.is_half, pred.device, pred.resample_kernel = False, "cpu", {}
+    pred.mel_extractor = R.MelSpectrogram(False, 128, 16000, 1024, 160, None, 30, 8000)
+    model = R.E2E(cfg["n_blocks"], cfg["n_gru"], (2, 2), cfg["en_de_layers"], cfg["inter_layers"],
+                  cfg["in_channels"], cfg["en_out_channels"])
+    model.load_state_dict(sd)
+    pred.model = model.eval()
+    pred.cents_mapping = np.pad(20 * np.arange(360) + 1997.3794084376191, (4, 4))
+    return pred
+
+
+def hf_hubert(cfg, sd):
+    hc = HubertConfig(hidden_size=cfg["embed_dim"], num_hidden_layers=cfg["layers"],
+                      num_attention_heads=cfg["heads"], intermediate_size=cfg["ffn_dim"],
+                      conv_dim=[cfg["conv_dim"]] * 7, conv_kernel=cfg["conv_kernels"],
+                      conv_stride=cfg["conv_strides"], num_conv_pos_embeddings=cfg["pos_kernel"],
+                      num_conv_pos_embedding_groups=cfg["pos_groups"], hidden_dropout=0.0,
+                      attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0,
+                      layerdrop=0.0, final_dropout=0.0, mask_time_prob=0.0)
+    hc._attn_implementation = "eager"
+    m = HubertModel(hc).eval()
+    mp = {}
+    for i in range(7):
+        mp[f"feature_extractor.conv_layers.{i}.conv.weight"] = sd[f"feature_extractor.conv_layers.{i}.0.weight"]
+    mp["feature_extractor.conv_layers.0.layer_norm.weight"] = sd["feature_extractor.conv_layers.0.2.weight"]
+    mp["feature_extractor.conv_layers.0.layer_norm.bias"] = sd["feature_extractor.conv_layers.0.2.bias"]
+    mp["feature_projection.layer_norm.weight"] = sd["layer_norm.weight"]
+    mp["feature_projection.layer_norm.bias"] = sd["layer_norm.bias"]
+    mp["feature_projection.projection.weight"] = sd["post_extract_proj.weight"]
+    mp["feature_projection.projection.bias"] = sd["post_extract_proj.bias"]
+    mp["encoder.pos_conv_embed.conv.bias"] = sd["encoder.pos_conv.0.bias"]
+    mp["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = sd["encoder.pos_conv.0.weight_g"]
+    mp["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = sd["encoder.pos_conv.0.weight_v"]
+    mp["encoder.layer_norm.weight"] = sd["encoder.layer_norm.weight"]
+    mp["encoder.layer_norm.bias"] = sd["encoder.layer_norm.bias"]
+    for l in range(cfg["layers"]):
+        a, b = f"encoder.layers.{l}", f"encoder.layers.{l}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            for wb in ("weight", "bias"):
+                mp[f"{a}.attention.{n}.{wb}"] = sd[f"{b}.self_attn.{n}.{wb}"]
+        for wb in ("weight", "bias"):
+            mp[f"{a}.layer_norm.{wb}"] = sd[f"{b}.self_attn_layer_norm.{wb}"]
+            mp[f"{a}.feed_forward.intermediate_dense.{wb}"] = sd[f"{b}.fc1.{wb}"]
+            mp[f"{a}.feed_forward.output_dense.{wb}"] = sd[f"{b}.fc2.{wb}"]
+            mp[f"{a}.final_layer_norm.{wb}"] = sd[f"{b}.final_layer_norm.{wb}"]
+    res = m.load_state_dict(mp, strict=False)
+    assert not res.unexpected_keys and all("masked_spec_embed" in k for k in res.missing_keys), res
+    return m
+
+
+class HubertAdapter(torch.nn.Module):
+    """``extract_features(source, padding_mask, output_layer)`` around the HF twin (Appendix A.6)."""
+
+    def __init__(self, hf):
+        super().__init__()
+        self.hf = hf
+
+    def extract_features(self, source, padding_mask=None, output_layer=12):
+        out = self.hf(source, output_hidden_states=True)
+        return out.hidden_states[min(output_layer, len(out.hidden_states) - 1)], None
+
+
+class Cfg:
+    def __init__(self, geo):
+        self.device, self.is_half = "cpu", False
+        self.x_pad, self.x_query, self.x_center, self.x_max = geo
+
+
+# ------------------------------------------------------------------ stage goldens
+def gold_synth(tag, cfg, T, seed):
+    print(f"[synth {tag}] T={T}")
+    sd = S.to_torch(S.synth_state(cfg, seed))
+    net = ref_synth(cfg, sd)
+    c = O_synth.cfg_fields(cfg)
+    g = torch.Generator().manual_seed(100 + seed)
+    phone = torch.randn(1, T, 768, generator=g)
+    pitch = torch.randint(1, 256, (1, T), generator=g)
+    f0 = 100 + 300 * torch.rand(1, T, generator=g)
+    f0[:, T // 3: T // 3 + max(2, T // 8)] = 0          # an unvoiced stretch
+    pitch[f0 == 0] = 1
+    z_noise = torch.randn(1, c["inter"], T, generator=g)
+    src_noise = torch.randn(1, T * c["upp"], 1, generator=g)
+    draws = [z_noise, src_noise]
+    orig = torch.randn_like
+    it = iter(draws)
+    torch.randn_like = lambda x, **kw: next(it)
+    try:
+        o, x_mask, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, f0, torch.tensor([0]))
+    finally:
+        torch.randn_like = orig
+    oo, parts = O_synth.synthesizer_infer(sd, cfg, phone, torch.tensor([T]), pitch, f0, torch.tensor([0]),
+                                          z_noise, src_noise, return_parts=True)
+    report("m_p", m_p, parts["m_p"]); report("logs_p", logs_p, parts["logs_p"])
+    report("z", z, parts["z"])
+    e = report("audio", o, oo)
+    assert e < 1e-5, e
+    np.savez_compressed(os.path.join(GOLD, f"synth_{tag}.npz"), seed=seed, cfg=json.dumps(cfg),
+                        phone=phone.numpy(), pitch=pitch.numpy(), f0=f0.numpy(), z_noise=z_noise.numpy(),
+                        src_noise=src_noise.numpy().astype(np.float32), m_p=m_p.numpy(), logs_p=logs_p.numpy(),
+                        z_p=z_p.numpy(), z=z.numpy(), audio=o.numpy())
+
+
+def gold_rmvpe(tag, cfg, seconds, seed, stride=1):
+    print(f"[rmvpe {tag}] {seconds}s")
+    sd = S.to_torch(S.rmvpe_state(cfg, seed))
+    pred = ref_rmvpe(cfg, sd)
+    audio = S.make_clip(7 + seed, seconds).astype(np.float64)
+    a = torch.from_numpy(audio).float().unsqueeze(0)
+    mel = pred.mel_extractor(a, center=True)
+    hid = pred.mel2hidden(mel).squeeze(0).numpy()
+    f0 = pred.infer_from_audio_with_pitch(audio, thred=0.03, f0_min=50, f0_max=1100)
+    of0, ohid, omel = O_rmvpe.infer_f0(sd, cfg, audio, return_hidden=True)
+    report("mel", mel, omel); e1 = report("hidden", hid, ohid); e2 = report("f0", f0, of0)
+    assert e1 < 1e-5 and e2 < 1e-2, (e1, e2)
+    print(f"  voiced frames {int((f0 > 0).sum())}/{len(f0)}  hidden max {hid.max():.3f}")
+    np.savez_compressed(os.path.join(GOLD, f"rmvpe_{tag}.npz"), seed=seed, cfg=json.dumps(cfg),
+                        audio=audio.astype(np.float32), mel=mel.numpy()[:, :, ::stride],
+                        hidden=hid[::stride], f0=f0, stride=stride)
+
+
+def gold_hubert(tag, cfg, seconds, seed):
+    print(f"[hubert {tag}] {seconds}s  (HF twin; fairseq absent -> parity unpinned by the reference)")
+    sd = S.to_torch(S.hubert_state(cfg, seed))
+    hf = hf_hubert(cfg, sd)
+    wav = torch.from_numpy(S.make_clip(3 + seed, seconds)).unsqueeze(0)
+    out = hf(wav, output_hidden_states=True)
+    L = cfg["layers"]
+    mine, parts = O_hubert.extract_features(sd, cfg, wav, L, return_parts=True)
+    e = report(f"layer{L}", out.hidden_states[L], mine)
+    report("layer1", out.hidden_states[1], O_hubert.extract_features(sd, cfg, wav, 1))
+    assert e < 2e-5, e
+    np.savez_compressed(os.path.join(GOLD, f"hubert_{tag}.npz"), seed=seed, cfg=json.dumps(cfg),
+                        wav=wav.numpy(), out=out.hidden_states[L].numpy(),
+                        out_l1=out.hidden_states[1].numpy())
+
+
+def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0_min, f0_max, seed,
+                     tgt_sr):
+    (hcfg, hsd), (rcfg, rsd), (scfg, ssd) = models_cfg
+    vc = P.VC(tgt_sr, Cfg(geo))
+    vc.model_rmvpe = ref_rmvpe(rcfg, rsd)
+    hub = HubertAdapter(hf_hubert(hcfg, hsd))
+    net = ref_synth(scfg, ssd)
+    draws = []
+    orig = torch.randn_like
+
+    def cap(x, **kw):
+        d = orig(x, **kw)
+        draws.append(d.clone())
+        return d
+    raw = []
+    orig_vc = vc.vc
+
+    def vc_cap(*a, **kw):
+        r = orig_vc(*a, **kw)
+        raw.append(r.copy())
+        return r
+    vc.vc = vc_cap
+    torch.randn_like = cap
+    torch.manual_seed(seed)
+    try:
+        pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, "rmvpe+", None, 0, 1, 3,
+                          tgt_sr, 0, volume_envelope, "v2", protect, 128, None, f0_min, f0_max)
+    finally:
+        torch.randn_like = orig
+    noises = [(draws[2 * i], draws[2 * i + 1]) for i in range(len(draws) // 2)]
+    return pcm, raw, noises
+
+
+def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, protect, f0_min, f0_max,
+                  full_store=True):
+    hcfg, rcfg, scfg = cfgs
+    print(f"[pipeline {tag}] {seconds}s geo={geo} pitch={pitch} env={volume_envelope}")
+    hsd, rsd, ssd = (S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.rmvpe_state(rcfg, seed)),
+                     S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])))
+    tgt_sr = scfg[-1]
+    audio = S.make_clip(clip, seconds)
+    t0 = time.time()
+    pcm, raw, noises = run_ref_pipeline(((hcfg, hsd), (rcfg, rsd), (scfg, ssd)), geo, audio, pitch,
+                                        volume_envelope, protect, f0_min, f0_max, seed, tgt_sr)
+    t_ref = time.time() - t0
+    models = O_pipe.Models(hsd, hcfg, rsd, rcfg, ssd, scfg)
+    t0 = time.time()
+    opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(tgt_sr, *geo), audio, pitch, 0, None, 0.0,
+                                  volume_envelope, protect, f0_min, f0_max, noises=noises, return_parts=True)
+    t_or = time.time() - t0
+    print(f"  chunks={len(raw)}  ref {t_ref:.1f}s  oracle {t_or:.1f}s  out={pcm.shape}")
+    e = 0.0
+    for i, (a, b) in enumerate(zip(raw, parts["raw"])):
+        e = max(e, report(f"vc chunk {i} f32", a, b))
+    d = np.abs(pcm.astype(np.int32) - opcm.astype(np.int32))
+    print(f"  pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
+    assert e < 1e-4 and d.max() <= 2, (e, d.max())
+    rawcat = np.concatenate(raw)
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch,
+                 volume_envelope=volume_envelope, protect=protect, f0_min=f0_min, f0_max=f0_max,
+                 cfgs=json.dumps([hcfg, rcfg, scfg]), n_chunks=len(raw),
+                 chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
+                 coarse=parts["coarse"].astype(np.int16),
+                 sha256=hashlib.sha256(pcm.tobytes()).hexdigest(),
+                 block_rms=np.array([rms(rawcat[i:i + 4096]) for i in range(0, len(rawcat), 4096)], np.float32))
+    if full_store:
+        store.update(pcm=pcm, raw=rawcat.astype(np.float32))
+        for i, (zn, sn) in enumerate(noises):
+            store[f"z_noise_{i}"] = zn.numpy()
+            store[f"src_noise_{i}"] = sn.numpy()
+    else:
+        store.update(pcm_samples=pcm[::997], raw_samples=rawcat[::997].astype(np.float32), noise_seed=seed)
+    np.savez_compressed(os.path.join(GOLD, f"pipeline_{tag}.npz"), **store)
+
+
+def gold_layouts():
+    """Key/shape listings of the reference's own modules (the checkpoint contracts)."""
+    out = {}
+    net = Synthesizer(*S.SYNTH_CFG_48K, use_f0=1, input_dim=768, is_half=False)
+    del net.enc_q
+    out["synth_48k"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    m = R.E2E(4, 1, (2, 2))
+    out["rmvpe"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(GOLD, "layouts.json"), "w") as f:
+        json.dump(out, f)
+    mine = S.synth_state(S.SYNTH_CFG_48K)
+    assert set(mine) == set(out["synth_48k"]), set(mine) ^ set(out["synth_48k"])
+    for k, v in mine.items():
+        assert list(v.shape) == out["synth_48k"][k], k
+    mine = S.rmvpe_state(S.RMVPE_CFG_FULL)
+    assert set(mine) == set(out["rmvpe"]), set(mine) ^ set(out["rmvpe"])
+    for k, v in mine.items():
+        assert list(v.shape) == out["rmvpe"][k], (k, v.shape, out["rmvpe"][k])
+    print("[layouts] synthetic layouts == reference module layouts "
+          f"(synth {len(out['synth_48k'])} tensors, rmvpe {len(out['rmvpe'])} tensors)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also run the full-size C1/C2 pipelines (minutes)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    tiny = (S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY)
+    steps = {
+        "layouts": gold_layouts,
+        "synth_tiny": lambda: gold_synth("tiny", S.SYNTH_CFG_TINY, 37, 1),
+        "synth_48k": lambda: gold_synth("48k_T24", S.SYNTH_CFG_48K, 24, 0),
+        "rmvpe_tiny": lambda: gold_rmvpe("tiny", S.RMVPE_CFG_TINY, 0.7, 1),
+        "rmvpe_full": lambda: gold_rmvpe("full_1s", S.RMVPE_CFG_FULL, 1.0, 0),
+        "hubert_tiny": lambda: gold_hubert("tiny", S.HUBERT_CFG_TINY, 0.5, 1),
+        "hubert_base": lambda: gold_hubert("base_1s", S.HUBERT_CFG_BASE, 1.0, 0),
+        "pipe_tiny": lambda: gold_pipeline("tiny_single", tiny, (1, 6, 38, 41), 2.0, 11, 1, 0, 1.0, 0.33, 50, 1100),
+        # CI's canonical argument set (test_cli.yml:43): -p -0.5 -rms 0.25 -pro 0.33 -f0min 1 -f0max 1100
+        "pipe_tiny_ci": lambda: gold_pipeline("tiny_ciargs", tiny, (1, 6, 38, 41), 2.5, 12, 1, -0.5, 0.25, 0.33, 1, 1100),
+        # small geometry to force the multi-chunk branch (pipeline.py:381-415)
+        "pipe_tiny_chunks": lambda: gold_pipeline("tiny_chunked", tiny, (1, 1, 2, 3), 7.3, 13, 1, 2, 1.0, 0.33, 50, 1100),
+    }
+    if a.full:
+        full40 = (S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL, S.SYNTH_CFG_40K)
+        full48 = (S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL, S.SYNTH_CFG_48K)
+        steps["pipe_c1"] = lambda: gold_pipeline("c1_5s_40k", full40, (1, 6, 38, 41), 5.0, 0, 0, 0, 1.0, 0.33,
+                                                 50, 1100, full_store=False)
+        steps["pipe_c2"] = lambda: gold_pipeline("c2_30s_48k", full48, (1, 6, 38, 41), 30.0, 0, 0, 0, 1.0, 0.33,
+                                                 50, 1100, full_store=False)
+    for k, fn in steps.items():
+        if a.only and a.only not in k:
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()
