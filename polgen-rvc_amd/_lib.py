@@ -204,5 +204,51 @@ class Context:
                  "op_convtranspose2d")
         return y
 
+    def attention(self, q, k, v, heads, scale, emb_rel_k=None, emb_rel_v=None, window=10, lens=None):
+        q, k, v = f32(q), f32(k), f32(v)
+        B, HD, T = q.shape
+        D = HD // heads
+        out = np.empty_like(q)
+        ek = None if emb_rel_k is None else f32(emb_rel_k)
+        ev = None if emb_rel_v is None else f32(emb_rel_v)
+        li = i32(lens)
+        self._ck(lib().rvcx_op_attention(self._h, _p(q), _p(k), _p(v), _p(out), B, heads, D, T, C.c_float(scale),
+                                         _p(ek), _p(ev), window, _p(li, C.c_int32)), "op_attention")
+        return out
+
+    def layernorm_c(self, x, gamma, beta, eps=1e-5):
+        x = f32(x)
+        B, Cc, T = x.shape
+        y = np.empty_like(x)
+        self._ck(lib().rvcx_op_layernorm_c(self._h, _p(x), _p(f32(gamma)), _p(f32(beta)), _p(y), B, Cc, T,
+                                           C.c_float(eps)), "op_layernorm_c")
+        return y
+
+    # ---- models -----------------------------------------------------------------------
+    def load_synth(self, cfg_struct, state: dict) -> int:
+        tbl, keep = make_table(state)
+        mid = C.c_int(-1)
+        self._ck(lib().rvcx_load_synth(self._h, C.byref(cfg_struct), tbl, len(tbl), C.byref(mid)), "load_synth")
+        return mid.value
+
+    def synth_upp(self, model_id: int) -> int:
+        return int(lib().rvcx_synth_upp(self._h, model_id))
+
+    def synth_infer(self, model_id, phone, pitch, pitchf, lens=None, sid=None, z_noise=None, src_noise=None,
+                    seed=0):
+        phone, pitchf = f32(phone), f32(pitchf)
+        pitch = i32(pitch)
+        B, T, _ = phone.shape
+        upp = self.synth_upp(model_id)
+        out = np.empty((B, T * upp), np.float32)
+        lens = i32(np.full(B, T) if lens is None else lens)
+        sid = i32(np.zeros(B) if sid is None else sid)
+        zn = None if z_noise is None else f32(z_noise)
+        sn = None if src_noise is None else f32(src_noise)
+        self._ck(lib().rvcx_synth_infer(self._h, model_id, B, T, _p(lens, C.c_int32), _p(phone),
+                                        _p(pitch, C.c_int32), _p(pitchf), _p(sid, C.c_int32), _p(zn), _p(sn),
+                                        C.c_uint64(seed), _p(out)), "synth_infer")
+        return out
+
     def flop_counter(self, reset=False) -> float:
         return float(lib().rvcx_flop_counter(self._h, 1 if reset else 0))

@@ -32,6 +32,14 @@ static thread_local std::string g_last_error;
     return -1;                                \
   }
 
+// copy n elements from host-or-device memory into the arena
+template <typename T>
+static T* any_to_dev(Ctx& c, const T* p, size_t n) {
+  T* d = c.arena.alloc<T>(n);
+  RVCX_HIP(hipMemcpyAsync(d, p, n * sizeof(T), hipMemcpyDefault, c.stream));
+  return d;
+}
+
 extern "C" {
 
 const char* rvcx_version(void) { return "rvcx 0.1.0 (gfx950)"; }
@@ -221,5 +229,163 @@ int rvcx_op_convtranspose2d(rvcx_ctx* ctx, const float* x, const float* w, const
   C->arena.reset();
   API_END
 }
+
+// ------------------------------------------------------------------------------------------
+// model loading
+// ------------------------------------------------------------------------------------------
+static TensorTable make_table(const rvcx_tensor* tbl, int n) {
+  TensorTable t;
+  for (int i = 0; i < n; ++i) {
+    HostTensor h;
+    h.data = tbl[i].data;
+    h.dtype = tbl[i].dtype;
+    for (int d = 0; d < tbl[i].ndim; ++d) h.shape.push_back(tbl[i].shape[d]);
+    t.add(tbl[i].name, std::move(h));
+  }
+  return t;
+}
+
+int rvcx_load_synth(rvcx_ctx* ctx, const rvcx_synth_cfg* cfg, const rvcx_tensor* tbl, int n, int* model_id) {
+  API_BEGIN(ctx)
+  ensure_slab(*C);
+  TensorTable t = make_table(tbl, n);
+  auto m = synth_load(*C, *cfg, t);
+  int id = -1;
+  for (size_t i = 0; i < C->synths.size(); ++i)
+    if (!C->synths[i]) id = (int)i;
+  if (id < 0) {
+    C->synths.emplace_back();
+    id = (int)C->synths.size() - 1;
+  }
+  C->synths[id] = std::move(m);
+  *model_id = id;
+  API_END
+}
+
+int rvcx_unload_synth(rvcx_ctx* ctx, int model_id) {
+  API_BEGIN(ctx)
+  if (model_id < 0 || model_id >= (int)C->synths.size()) fail("bad model id");
+  C->synths[model_id].reset();   // slab space is reclaimed when the context is destroyed
+  API_END
+}
+
+static SynthModel& get_synth(Ctx& c, int id) {
+  if (id < 0 || id >= (int)c.synths.size() || !c.synths[id]) fail("synth model not loaded");
+  return *c.synths[id];
+}
+
+int rvcx_synth_upp(rvcx_ctx* ctx, int model_id) {
+  if (!ctx || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
+  return ctx->c.synths[model_id]->upp;
+}
+
+int rvcx_weights_blob(rvcx_ctx* ctx, void** dev_ptr, int64_t* nbytes) {
+  API_BEGIN(ctx)
+  *dev_ptr = C->slab.base();
+  *nbytes = (int64_t)C->slab.used();
+  API_END
+}
+
+
+int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
+                     const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
+                     const float* src_noise, uint64_t seed, float* out) {
+  API_BEGIN(ctx)
+  SynthModel& M = get_synth(*C, model_id);
+  const int D = M.cfg.input_dim, inter = M.cfg.inter_channels;
+  const size_t Tupp = (size_t)T * M.upp;
+  C->arena.reserve(synth_arena_bytes(M, B, T) + (size_t)B * T * D * 8 + (size_t)B * Tupp * 8);
+  C->arena.reset();
+  float* ph = any_to_dev(*C, phone, (size_t)B * T * D);
+  float* ph_ct = C->arena.alloc<float>((size_t)B * T * D);
+  launch_transpose(ph, ph_ct, B, T, D, C->stream);
+  SynthIO io;
+  io.B = B;
+  io.T = T;
+  io.lens_host = lens;
+  io.phone_ct = ph_ct;
+  io.pitch = any_to_dev<int>(*C, pitch, (size_t)B * T);
+  io.pitchf = any_to_dev(*C, pitchf, (size_t)B * T);
+  io.sid_host = sid;
+  float* zn = C->arena.alloc<float>((size_t)B * inter * T);
+  float* sn = C->arena.alloc<float>((size_t)B * Tupp);
+  if (z_noise) RVCX_HIP(hipMemcpyAsync(zn, z_noise, (size_t)B * inter * T * 4, hipMemcpyDefault, C->stream));
+  else launch_randn(zn, (size_t)B * inter * T, seed, 0, C->stream);
+  if (src_noise) RVCX_HIP(hipMemcpyAsync(sn, src_noise, (size_t)B * Tupp * 4, hipMemcpyDefault, C->stream));
+  else launch_randn(sn, (size_t)B * Tupp, seed, (uint64_t)1 << 40, C->stream);
+  io.z_noise = zn;
+  io.src_noise = sn;
+  float* dout = C->arena.alloc<float>((size_t)B * Tupp);
+  io.out = dout;
+  synth_forward(*C, M, io, nullptr);
+  RVCX_HIP(hipMemcpyAsync(out, dout, (size_t)B * Tupp * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_op_attention(rvcx_ctx* ctx, const float* q, const float* k, const float* v, float* out, int B, int H,
+                      int D, int T, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
+                      const int32_t* lens) {
+  API_BEGIN(ctx)
+  const size_t n = (size_t)B * H * D * T;
+  C->arena.reserve(n * 16 + attention_scratch_floats(B, H, T, window) * 4 + (64 << 20));
+  C->arena.reset();
+  float *dq = to_dev(*C, q, n), *dk = to_dev(*C, k, n), *dv = to_dev(*C, v, n);
+  float* dout = C->arena.alloc<float>(n);
+  float *ek = nullptr, *ev = nullptr, *scratch = nullptr;
+  if (emb_rel_k) {
+    ek = to_dev(*C, emb_rel_k, (size_t)(2 * window + 1) * D);
+    ev = to_dev(*C, emb_rel_v, (size_t)(2 * window + 1) * D);
+    scratch = C->arena.alloc<float>(attention_scratch_floats(B, H, T, window));
+  }
+  launch_attention(dq, dk, dv, dout, B, H, D, T, T, (long)H * D * T, (long)H * D * T, scale, ek, ev, window,
+                   to_dev_i(*C, lens, B), scratch, C->stream);
+  to_host(*C, out, dout, n);
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_op_layernorm_c(rvcx_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int B,
+                        int Cc, int T, float eps) {
+  API_BEGIN(ctx)
+  const size_t n = (size_t)B * Cc * T;
+  C->arena.reserve(n * 8 + (64 << 20));
+  C->arena.reset();
+  float* dx = to_dev(*C, x, n);
+  float* dy = C->arena.alloc<float>(n);
+  launch_layernorm_c(dx, to_dev(*C, gamma, Cc), to_dev(*C, beta, Cc), dy, B, Cc, T, eps, nullptr, C->stream);
+  to_host(*C, y, dy, n);
+  C->arena.reset();
+  API_END
+}
+
+// ------------------------------------------------------------------------------------------
+// entry points not implemented yet return an error (never a silent fallback)
+// ------------------------------------------------------------------------------------------
+#define NOT_IMPL(ctxp, name)                    \
+  do {                                          \
+    g_last_error = name ": not implemented";    \
+    if (ctxp) (ctxp)->c.last_error = g_last_error; \
+    return -1;                                  \
+  } while (0)
+
+int rvcx_load_hubert(rvcx_ctx* c, const rvcx_hubert_cfg*, const rvcx_tensor*, int) { NOT_IMPL(c, "rvcx_load_hubert"); }
+int rvcx_load_rmvpe(rvcx_ctx* c, const rvcx_rmvpe_cfg*, const rvcx_tensor*, int) { NOT_IMPL(c, "rvcx_load_rmvpe"); }
+int rvcx_load_index(rvcx_ctx* c, const float*, int64_t, int) { NOT_IMPL(c, "rvcx_load_index"); }
+int rvcx_rmvpe_f0(rvcx_ctx* c, int, const float*, int64_t, float, float, float, float*, float*) { NOT_IMPL(c, "rvcx_rmvpe_f0"); }
+int rvcx_rmvpe_frames(int64_t n) { return (int)(1 + n / 160); }
+int rvcx_hubert_features(rvcx_ctx* c, int, const float*, int64_t, int, float*) { NOT_IMPL(c, "rvcx_hubert_features"); }
+int rvcx_hubert_frames(rvcx_ctx* c, int64_t) { NOT_IMPL(c, "rvcx_hubert_frames"); }
+int rvcx_index_blend(rvcx_ctx* c, float*, int, float, int64_t*, float*) { NOT_IMPL(c, "rvcx_index_blend"); }
+int64_t rvcx_out_len(rvcx_ctx* c, int, int64_t, const rvcx_params*) { NOT_IMPL(c, "rvcx_out_len"); }
+int rvcx_convert_batch(rvcx_ctx* c, int, int, const float* const*, const int64_t*, const rvcx_params*,
+                       const float* const*, int16_t* const*, float* const*) { NOT_IMPL(c, "rvcx_convert_batch"); }
+int64_t rvcx_noise_len(rvcx_ctx* c, int, int64_t, const rvcx_params*) { NOT_IMPL(c, "rvcx_noise_len"); }
+int rvcx_get_f0(rvcx_ctx* c, const float*, int64_t, const rvcx_params*, int32_t*, float*, int64_t*) { NOT_IMPL(c, "rvcx_get_f0"); }
+int rvcx_last_timing(rvcx_ctx* c, float*) { NOT_IMPL(c, "rvcx_last_timing"); }
+int rvcx_op_bigru(rvcx_ctx* c, const float*, const float*, const float*, const float*, const float*, const float*,
+                  const float*, const float*, const float*, float*, int, int, int, int) { NOT_IMPL(c, "rvcx_op_bigru"); }
+int rvcx_op_highpass(rvcx_ctx* c, const double*, double*, int64_t) { NOT_IMPL(c, "rvcx_op_highpass"); }
 
 }  // extern "C"

@@ -1,0 +1,254 @@
+// Flash-style self-attention on the fp32 matrix cores for channel-first (B, H*D, T) tensors,
+// with the optional windowed relative-position terms of the RVC TextEncoder
+// (rvc/lib/algorithm/attentions.py:63-113) -- and, without them, the HuBERT encoder attention.
+//
+// Per wave: 32 queries.  S^T = K^T Q is computed "swapped" (rows = keys, cols = queries) so a
+// lane owns one query column: the row-reduction of the online softmax is 16 in-register ops
+// plus one cross-half shuffle, and the softmaxed registers are *already* the B fragment of
+// O^T += V P^T (MFMA k-slot s of lane-half h <-> key (s&3)+8(s>>2)+4h; V's A fragment is read
+// from LDS with the same permutation, so P never moves between lanes).
+#include "ops.h"
+
+namespace rvcx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KT = 32;     // keys per tile
+constexpr int VROW = 33;   // odd pitch: conflict-free strided A-fragment reads of V
+
+template <int DT>  // D <= 32*DT
+__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                   const float* __restrict__ v, float* __restrict__ out,
+                                                   float* __restrict__ m_out, float* __restrict__ l_out,
+                                                   const float* __restrict__ relq, int H, int D, int T,
+                                                   int ld, long in_bs, long out_bs, float scale, int window,
+                                                   const int* lens) {
+  __shared__ float Ks[32 * DT * KT];
+  __shared__ float Vs[32 * DT * VROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int len = lens ? lens[b] : T;
+  const long base = (long)b * in_bs + (long)hd * D * ld;
+  const long obase = (long)b * out_bs + (long)hd * D * ld;
+  const float* qb = q + base;
+  const float* kb = k + base;
+  const float* vb = v + base;
+  const int nsteps = D / 2;
+
+  // Q fragment (B operand of S^T): lane (i,h), step s -> Q[2s+h][q0+i] * scale
+  float qreg[16 * DT];
+  const int qi = q0 + i;
+#pragma unroll
+  for (int s = 0; s < 16 * DT; ++s) {
+    float val = 0.f;
+    if (s < nsteps && qi < T) val = qb[(long)(2 * s + h) * ld + qi] * scale;
+    qreg[s] = val;
+  }
+
+  f32x16 acc_o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nrel = 2 * window + 1;
+  const float* relrow = relq ? relq + (((long)b * H + hd) * T + min(qi, T - 1)) * nrel : nullptr;
+
+  for (int k0 = 0; k0 < len; k0 += KT) {
+    __syncthreads();
+    // ---- stage K [D][32] and V [D][33] tiles (zero beyond D / len)
+    for (int idx = tid; idx < 32 * DT * KT; idx += 256) {
+      const int d = idx / KT, kk = idx % KT;
+      const int key = k0 + kk;
+      float kv = 0.f, vv = 0.f;
+      if (d < D && key < len) {
+        kv = kb[(long)d * ld + key];
+        vv = vb[(long)d * ld + key];
+      }
+      Ks[d * KT + kk] = kv;
+      Vs[d * VROW + kk] = vv;
+    }
+    __syncthreads();
+    // ---- S^T tile: rows = keys, cols = queries
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16 * DT; ++s) {
+      if (s < nsteps) {
+        const float a = Ks[(2 * s + h) * KT + i];
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], sacc, 0, 0, 0);
+      }
+    }
+    // ---- relative-position logits on the diagonal band, key masking
+    const bool band = relq && (k0 <= q0 + 31 + window) && (k0 + KT - 1 >= q0 - window);
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float sv = sacc[r];
+      if (band) {
+        const int rel = key - qi + window;
+        if (rel >= 0 && rel < nrel && qi < T) sv += relrow[rel];
+      }
+      if (key >= len) sv = -INFINITY;
+      sacc[r] = sv;
+      mloc = fmaxf(mloc, sv);
+    }
+    const float mtile = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mtile);
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float lloc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (sacc[r] == -INFINITY) ? 0.f : expf(sacc[r] - m_new);
+      sacc[r] = p;
+      lloc += p;
+    }
+    l_run = l_run * alpha + lloc + __shfl_xor(lloc, 32);
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[dt][r] *= alpha;
+      // ---- O^T += V P^T
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int kidx = (s & 3) + 8 * (s >> 2) + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const float a = Vs[(dt * 32 + i) * VROW + kidx];
+        acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sacc[s], acc_o[dt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- normalise and store (coalesced along queries)
+  if (qi < T) {
+    const float inv = 1.f / l_run;
+    float* ob = out + obase;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (d < D) ob[(long)d * ld + qi] = (qi < len) ? acc_o[dt][r] * inv : 0.f;
+      }
+    if (m_out && h == 0) {
+      m_out[((long)b * H + hd) * T + qi] = m_run;
+      l_out[((long)b * H + hd) * T + qi] = l_run;
+    }
+  }
+}
+
+// relq[b][h][t][r] = sum_d (q[d][t]*scale) * Ek[r][d]      (attentions.py:83-86)
+__global__ void rel_logits_kernel(const float* __restrict__ q, const float* __restrict__ ek,
+                                  float* __restrict__ relq, int H, int D, int T, int ld, long in_bs,
+                                  float scale, int nrel) {
+  extern __shared__ float eks[];  // [nrel][D]
+  for (int idx = threadIdx.x; idx < nrel * D; idx += blockDim.x) eks[idx] = ek[idx];
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* qb = q + (long)b * in_bs + (long)hd * D * ld;
+  float acc[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float qv = qb[(long)d * ld + t] * scale;
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+      if (r < nrel) acc[r] = fmaf(qv, eks[r * D + d], acc[r]);
+  }
+  float* o = relq + (((long)b * H + hd) * T + t) * nrel;
+#pragma unroll
+  for (int r = 0; r < 32; ++r)
+    if (r < nrel) o[r] = acc[r];
+}
+
+// out[d][t] += sum_r p[t][t+r-w] * Ev[r][d], p recomputed on the band from (m, l)
+// (attentions.py:106-111)
+__global__ __launch_bounds__(256) void rel_values_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ relq,
+                                                         const float* __restrict__ m_in,
+                                                         const float* __restrict__ l_in,
+                                                         const float* __restrict__ ev, float* __restrict__ out,
+                                                         int H, int D, int T, int ld, long in_bs, long out_bs, float scale,
+                                                         int window, const int* lens) {
+  extern __shared__ float sm[];  // evs [nrel][D] ; ps [64][nrel+1]
+  const int nrel = 2 * window + 1;
+  float* evs = sm;
+  float* ps = sm + nrel * D;
+  const int tq = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * 64 + tq;
+  const int len = lens ? lens[b] : T;
+  for (int idx = threadIdx.x; idx < nrel * D; idx += 256) evs[idx] = ev[idx];
+  const long base = (long)b * in_bs + (long)hd * D * ld;
+  const long obase = (long)b * out_bs + (long)hd * D * ld;
+  if (t < T) {
+    const float m = m_in[((long)b * H + hd) * T + t], l = l_in[((long)b * H + hd) * T + t];
+    for (int r = part; r < nrel; r += 4) {
+      const int key = t + r - window;
+      float p = 0.f;
+      if (key >= 0 && key < len) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s = fmaf(q[base + (long)d * ld + t] * scale, k[base + (long)d * ld + key], s);
+        s += relq[(((long)b * H + hd) * T + t) * nrel + r];
+        p = expf(s - m) / l;
+      }
+      ps[tq * (nrel + 1) + r] = p;
+    }
+  }
+  __syncthreads();
+  if (t < T && t < len) {
+    for (int d = part; d < D; d += 4) {
+      float acc = 0.f;
+      for (int r = 0; r < nrel; ++r) acc = fmaf(ps[tq * (nrel + 1) + r], evs[r * D + d], acc);
+      out[obase + (long)d * ld + t] += acc;
+    }
+  }
+}
+
+void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
+                      int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
+                      const int* lens, float* scratch, hipStream_t stream) {
+  RVCX_CHECK(D % 2 == 0 && D <= 96, "attention: head dim must be even and <= 96");
+  const int nrel = 2 * window + 1;
+  float *relq = nullptr, *mb = nullptr, *lb = nullptr;
+  if (emb_rel_k) {
+    RVCX_CHECK(nrel <= 32 && scratch != nullptr, "attention: window too large / no scratch");
+    relq = scratch;
+    mb = relq + (size_t)B * H * T * nrel;
+    lb = mb + (size_t)B * H * T;
+    hipLaunchKernelGGL(rel_logits_kernel, dim3(cdiv(T, 128), H, B), dim3(128), nrel * D * sizeof(float), stream,
+                       q, emb_rel_k, relq, H, D, T, ld, in_bs, scale, nrel);
+  }
+  dim3 grid(cdiv(T, 128), H, B);
+  const int DT = cdiv(D, 32);
+  if (DT == 1)
+    hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mb, lb, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens);
+  else if (DT == 2)
+    hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mb, lb, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens);
+  else
+    hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mb, lb, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens);
+  if (emb_rel_v) {
+    size_t lds = ((size_t)nrel * D + 64 * (nrel + 1)) * sizeof(float);
+    hipLaunchKernelGGL(rel_values_kernel, dim3(cdiv(T, 64), H, B), dim3(256), lds, stream, q, k, relq, mb, lb,
+                       emb_rel_v, out, H, D, T, ld, in_bs, out_bs, scale, window, lens);
+  }
+  RVCX_HIP(hipGetLastError());
+}
+
+size_t attention_scratch_floats(int B, int H, int T, int window) {
+  return (size_t)B * H * T * (2 * window + 1) + 2 * (size_t)B * H * T;
+}
+
+double attention_flops(int B, int H, int D, int T) { return 4.0 * B * H * (double)T * T * D; }
+
+}  // namespace rvcx

@@ -1,13 +1,129 @@
-// Model containers (weights packed in the slab) and their forward passes.
+// Model containers (weights folded + packed into the slab) and their forward passes.
 #pragma once
+#include "../../include/rvcx.h"
 #include "ctx.h"
 #include "layers.h"
 
 namespace rvcx {
 
-struct SynthModel { int dummy = 0; };
-struct RmvpeModel { int dummy = 0; };
-struct HubertModel { int dummy = 0; };
-struct IndexData { int dummy = 0; };
+// ------------------------------------------------------------------------------ Synthesizer
+struct SynthModel {
+  rvcx_synth_cfg cfg{};
+  int upp = 1;
+  // TextEncoder (rvc/lib/algorithm/encoders.py:76-126)
+  ConvW emb_phone;
+  const float* emb_pitch = nullptr;  // (256, hidden)
+  struct EncLayer {
+    ConvW qkv, o, ffn1, ffn2;
+    const float *rel_k = nullptr, *rel_v = nullptr;      // (21, hidden/heads)
+    const float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+  };
+  std::vector<EncLayer> enc;
+  ConvW proj;
+  // ResidualCouplingBlock (rvc/lib/algorithm/residuals.py:109-232), layers 0..3 = flows.{0,2,4,6}
+  struct Flow {
+    ConvW pre, post, cond, in_l[3], rs_l[3];
+  };
+  Flow flows[4];
+  // GeneratorNSF (rvc/lib/algorithm/nsf.py:43-144)
+  ConvW conv_pre, cond, conv_post;
+  float lin_w = 1.f, lin_b = 0.f;
+  struct Stage {
+    ConvT1dW up;
+    ConvW noise;
+    int noise_stride = 1, noise_pad = 0;
+    int ch = 0;
+    ConvW c1[4][3], c2[4][3];
+  };
+  std::vector<Stage> stages;
+  const float* emb_g = nullptr;  // (spk, gin)
+};
+
+std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const TensorTable& t);
+
+struct SynthIO {
+  int B = 1, T = 0;
+  const int* lens_host = nullptr;     // (B) or null = all T
+  const float* phone_ct = nullptr;    // device (B, input_dim, T) channel-first
+  const int* pitch = nullptr;         // device (B,T)
+  const float* pitchf = nullptr;      // device (B,T)
+  const int* sid_host = nullptr;      // (B)
+  const float* z_noise = nullptr;     // device (B,inter,T)
+  const float* src_noise = nullptr;   // device (B,T*upp)
+  float* out = nullptr;               // device (B, T*upp)
+  // optional taps for parity tests (device, may be null)
+  float* stats_out = nullptr;         // (B, 2*inter, T) = [m_p ; logs_p]
+  float* z_out = nullptr;             // (B, inter, T)
+};
+size_t synth_arena_bytes(const SynthModel& m, int B, int T);
+void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_ms /*3 or null*/);
+
+// ------------------------------------------------------------------------------ RMVPE
+struct RmvpeModel {
+  rvcx_rmvpe_cfg cfg{};
+  ConvW stft;        // (1026, 1, 1024) Hann-windowed Fourier basis, stride 160
+  ConvW melfb;       // (128, 513) as a 1x1 conv
+  float bn0_scale = 1.f, bn0_shift = 0.f;
+  struct Block {
+    ConvW c1, c2, sc;   // 3x3 + folded BN (x2), optional 1x1 shortcut
+    bool has_sc = false;
+    int cin = 0, cout = 0;
+  };
+  std::vector<std::vector<Block>> enc, inter;
+  struct Dec {
+    ConvT2dW up;
+    std::vector<Block> blocks;
+    int cout = 0;
+  };
+  std::vector<Dec> dec;
+  ConvW cnn;         // 3x3, 16 -> 3, bias
+  ConvW gru_ih;      // (2*3H, 384) both directions stacked, bias = b_ih
+  const float* whh_t = nullptr;  // (2, H, 3H)
+  const float* bhh = nullptr;    // (2, 3H)
+  ConvW fc;          // (360, 512) + bias, sigmoid
+};
+std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const TensorTable& t);
+size_t rmvpe_arena_bytes(const RmvpeModel& m, int B, int64_t n);
+// audio: device (B,n) f32.  f0: device (B, 1+n/160).  hidden: device (B, frames, 360) or null.
+void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
+                   float f0_max, float* f0, float* hidden, hipStream_t s);
+
+// ------------------------------------------------------------------------------ HuBERT
+struct HubertModel {
+  rvcx_hubert_cfg cfg{};
+  std::vector<ConvW> convs;
+  const float *gn_g = nullptr, *gn_b = nullptr, *ln0_g = nullptr, *ln0_b = nullptr;
+  ConvW proj, pos_conv;
+  const float *eln_g = nullptr, *eln_b = nullptr;
+  struct Layer {
+    ConvW qkv, o, fc1, fc2;
+    const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  };
+  std::vector<Layer> layers;
+};
+std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, const TensorTable& t);
+int hubert_frames(const HubertModel& m, int64_t n);
+size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n);
+// wav: device (B,n).  feats_ct: device (B, embed, T') channel-first.
+void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
+                    float* feats_ct, hipStream_t s);
+
+// ------------------------------------------------------------------------------ retrieval index
+struct IndexData {
+  ConvW mat;                    // big_npy (N, dim) packed as a 1x1 conv (N out channels)
+  const float* rows = nullptr;  // (N, dim) row-major for the gather
+  const float* norms = nullptr; // |b|^2 (N)
+  int64_t n = 0;
+  int dim = 0;
+};
+std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim);
+size_t index_arena_bytes(const IndexData& ix, int T);
+// feats_ct (dim, T) channel-first in/out (device); ids (T,8) int64 / dist (T,8) optional device outputs
+void index_blend(Ctx& c, const IndexData& ix, float* feats_ct, int T, float index_rate, int64_t* ids,
+                 float* dist, hipStream_t s);
+
+// ------------------------------------------------------------------------------ host helpers
+// weight-norm fold  w = g * v / ||v||  over all dims except `dim` (0 or 2)
+std::vector<float> wn_weight(const TensorTable& t, const std::string& prefix, int dim = 0);
 
 }  // namespace rvcx

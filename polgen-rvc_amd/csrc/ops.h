@@ -1,6 +1,81 @@
-// Non-GEMM kernels (normalisation, scans, resampling, element-wise glue).
+// Non-GEMM kernels (normalisation, scans, resampling, element-wise glue) + attention/GRU launchers.
 #pragma once
 #include "common.h"
 
 namespace rvcx {
+
+// ---- attention.hip
+void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
+                      int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
+                      const int* lens, float* scratch, hipStream_t stream);
+size_t attention_scratch_floats(int B, int H, int T, int window);
+double attention_flops(int B, int H, int D, int T);
+
+// ---- gru.hip
+// gi: (B, T, 2*3H) input projections (+b_ih) for [fwd | rev]; whh: (2, 3H, H); bhh: (2, 3H); y: (B, T, 2H)
+void launch_bigru(const float* gi, const float* whh, const float* bhh, float* y, int B, int T, int H,
+                  hipStream_t stream);
+
+// ---- ops.hip
+// LayerNorm over channels of (B,C,T): y = (x-mean)/sqrt(var+eps)*gamma+beta  [normalization.py:13-16]
+void launch_layernorm_c(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                        float eps, const int* lens, hipStream_t s);
+// per-(b,c) normalisation over time + GELU (GroupNorm(C,C) of the HuBERT extractor)
+void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                           float eps, hipStream_t s);
+// (B,R,Cc) -> (B,Cc,R)
+void launch_transpose(const float* x, float* y, int B, int R, int Cc, hipStream_t s);
+// x[c][t] = lrelu((x[c][t] + emb[pitch[t]][c]) * scale, slope) * (t<len)     [encoders.py:116-123]
+void launch_embed_pitch(float* x, const float* emb, const int* pitch, int B, int C, int T, float scale,
+                        float slope, const int* lens, hipStream_t s);
+// z = (m + exp(logs) * noise * 0.66666) * mask ; stats = [m ; logs] (B,2C,T)   [synthesizers.py:174]
+void launch_sample_z(const float* stats, const float* noise, float* z, int B, int C, int T, const int* lens,
+                     hipStream_t s);
+// y[c] = x[C-1-c]                                                            [residuals.py:81-88]
+void launch_flip_channels(const float* x, float* y, int B, int C, int T, hipStream_t s);
+// acts = tanh(a[:H]+g[:H]) * sigmoid(a[H:]+g[H:]); a (B,2H,T), g (B,gstride) at offset goff  [commons.py:79-86]
+void launch_wn_gate(const float* a, const float* g, int goff, int gstride, float* acts, int B, int H, int T,
+                    hipStream_t s);
+// x = (x + rs[:H]) * mask ; out (+)= rs[H:]   (last layer: out += rs)          [modules.py:76-83]
+void launch_wn_res_skip(float* x, float* out, const float* rs, int B, int H, int T, int last, int first,
+                        const int* lens, hipStream_t s);
+// x1 = (x1 - m) * mask on channels [half, 2*half) of x (B,2*half,T)             [residuals.py:226-227]
+void launch_coupling_sub(float* x, const float* m, int B, int half, int T, const int* lens, hipStream_t s);
+// x (B,C,T) *= mask
+void launch_mask(float* x, int B, int C, int T, const int* lens, hipStream_t s);
+// x[b][c][t] += g[b][c]
+void launch_add_channel_bias(float* x, const float* g, int B, int C, int T, hipStream_t s);
+// NSF harmonic source: f0 (B,T) -> har (B,T*upp) = tanh(w*(sine*uv + namp*noise) + b)  [generators.py:117-156, nsf.py:36-40]
+void launch_sine_source(const float* f0, const float* noise, float* har, int B, int T, int upp, float sr,
+                        float lin_w, float lin_b, const int* lens, double* scratch, hipStream_t s);
+// standard normal noise, Philox4x32-10 + Box-Muller
+void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+// tanh(conv_post) is done in the conv epilogue; final leaky_relu(0.01) is its prologue.
+
+// ---- RMVPE helpers
+// reflect-pad 1-D signals: x (B,n) -> y (B,n+2p)
+void launch_reflect_pad(const float* x, float* y, int B, int n, int p, hipStream_t s);
+// |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F)
+void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s);
+// log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp
+void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, float bn_scale, float bn_shift,
+                     hipStream_t s);
+// 2x2 average pool on row-padded maps: (B*C, H, Wp) -> (B*C, H/2, W/2+2)
+void launch_avgpool2(const float* x, float* y, int planes, int H, int Wp, long x_ps, long y_ps, hipStream_t s);
+// copy channels of row-padded maps between buffers with different batch strides
+void launch_copy_strided(const float* x, float* y, int B, long n, long x_bs, long y_bs, hipStream_t s);
+// cnn output (B,3,T,Wp) -> GRU input (B, 3*128, T) channel-first (k = c*128+f)
+void launch_gru_input(const float* x, float* y, int B, int Cc, int T, int Wp, hipStream_t s);
+// salience (B,T,360) [row stride ld] -> f0 Hz (B,T)   [RMVPE.py:472-476,494-516]
+void launch_decode_f0(const float* sal, float* f0, int B, int T, int ld, float thred, float f0_min, float f0_max,
+                      hipStream_t s);
+// f0 (n) -> f0 * 2^(pitch/12), coarse 1..255      [pipeline.py:183,193-201] (float64 arithmetic)
+void launch_f0_coarse(const float* f0_in, float* f0_out, int* coarse, int n, double pitch, double f0_min,
+                      double f0_max, hipStream_t s);
+
+// ---- pipeline glue
+// feats (C,T) -> x2 nearest upsample, protect mix; writes phone (C, 2T') cropped to p_len  [pipeline.py:252-270]
+void launch_upsample_protect(const float* feats, const float* feats0, const float* pitchf, float* out, int C,
+                             int Th, int p_len, float protect, int use_protect, hipStream_t s);
+
 }  // namespace rvcx

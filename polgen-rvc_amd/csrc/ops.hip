@@ -1,0 +1,516 @@
+// Non-GEMM kernels.  All memory-bound: coalesced along the contiguous (time) axis, one pass
+// where the math allows, wavefront/LDS reductions for the normalisations.
+#include "ops.h"
+
+namespace rvcx {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {
+  return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+}
+
+// ------------------------------------------------------------------ LayerNorm over channels
+// block = 64 time steps x 4 channel slices; two-pass moments (mean, then centred variance)
+__global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          int C, int T, float eps, const int* lens) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 64 + tx;
+  const bool valid = t < T;
+  const float* xb = x + (long)b * C * T;
+  float* yb = y + (long)b * C * T;
+  float s = 0.f;
+  if (valid)
+    for (int c = part; c < C; c += 4) s += xb[(long)c * T + t];
+  red[part][tx] = s;
+  __syncthreads();
+  const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+  __syncthreads();
+  float v = 0.f;
+  if (valid)
+    for (int c = part; c < C; c += 4) {
+      const float d = xb[(long)c * T + t] - mean;
+      v += d * d;
+    }
+  red[part][tx] = v;
+  __syncthreads();
+  const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (!valid) return;
+  const bool live = !lens || t < lens[b];
+  for (int c = part; c < C; c += 4) {
+    const float o = (xb[(long)c * T + t] - mean) * rstd * gamma[c] + beta[c];
+    yb[(long)c * T + t] = live ? o : 0.f;
+  }
+}
+
+void launch_layernorm_c(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                        float eps, const int* lens, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, 64), B), dim3(256), 0, s, x, gamma, beta, y, C, T, eps, lens);
+}
+
+// ------------------------------------------------------------------ GroupNorm(C,C) + GELU
+__global__ __launch_bounds__(256) void groupnorm_gelu_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             int C, int T, float eps) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* xr = x + ((long)b * C + c) * T;
+  float* yr = y + ((long)b * C + c) * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f;
+  for (int t = tid; t < T; t += 256) s += xr[t];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)T;
+  __syncthreads();
+  float v = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float d = xr[t] - mean;
+    v += d * d;
+  }
+  v = wave_sum(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  const float var = (red[0] + red[1] + red[2] + red[3]) / (float)T;
+  const float rstd = 1.f / sqrtf(var + eps);
+  const float g = gamma[c], bb = beta[c];
+  for (int t = tid; t < T; t += 256) yr[t] = gelu_erf((xr[t] - mean) * rstd * g + bb);
+}
+
+void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                           float eps, hipStream_t s) {
+  hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3(C, B), dim3(256), 0, s, x, gamma, beta, y, C, T, eps);
+}
+
+// ------------------------------------------------------------------ batched transpose
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const float* xb = x + (long)b * R * Cc;
+  float* yb = y + (long)b * R * Cc;
+  int c = blockIdx.x * 32 + threadIdx.x;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    int r = blockIdx.y * 32 + j;
+    if (r < R && c < Cc) tile[j][threadIdx.x] = xb[(long)r * Cc + c];
+  }
+  __syncthreads();
+  int r2 = blockIdx.y * 32 + threadIdx.x;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    int c2 = blockIdx.x * 32 + j;
+    if (r2 < R && c2 < Cc) yb[(long)c2 * R + r2] = tile[threadIdx.x][j];
+  }
+}
+
+void launch_transpose(const float* x, float* y, int B, int R, int Cc, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(32, 8), 0, s, x, y, R, Cc);
+}
+
+// ------------------------------------------------------------------ element-wise glue
+#define EW_GRID(n) dim3((unsigned)std::min<long>(cdiv64((n), 256), 1 << 20)), dim3(256)
+
+__global__ void embed_pitch_kernel(float* x, const float* emb, const int* pitch, int C, int T, float scale,
+                                   float slope, const int* lens, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bc = idx / T;
+    const int c = bc % C, b = bc / C;
+    float v = (x[idx] + emb[(long)pitch[(long)b * T + t] * C + c]) * scale;
+    v = v > 0.f ? v : v * slope;
+    if (lens && t >= lens[b]) v = 0.f;
+    x[idx] = v;
+  }
+}
+void launch_embed_pitch(float* x, const float* emb, const int* pitch, int B, int C, int T, float scale,
+                        float slope, const int* lens, hipStream_t s) {
+  long n = (long)B * C * T;
+  hipLaunchKernelGGL(embed_pitch_kernel, EW_GRID(n), 0, s, x, emb, pitch, C, T, scale, slope, lens, n);
+}
+
+__global__ void sample_z_kernel(const float* stats, const float* noise, float* z, int C, int T, const int* lens,
+                                long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bc = idx / T;
+    const int c = bc % C, b = bc / C;
+    const float m = stats[((long)b * 2 * C + c) * T + t];
+    const float logs = stats[((long)b * 2 * C + C + c) * T + t];
+    float v = m + expf(logs) * noise[idx] * 0.66666f;
+    if (lens && t >= lens[b]) v = 0.f;
+    z[idx] = v;
+  }
+}
+void launch_sample_z(const float* stats, const float* noise, float* z, int B, int C, int T, const int* lens,
+                     hipStream_t s) {
+  long n = (long)B * C * T;
+  hipLaunchKernelGGL(sample_z_kernel, EW_GRID(n), 0, s, stats, noise, z, C, T, lens, n);
+}
+
+__global__ void flip_channels_kernel(const float* x, float* y, int C, int T, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bc = idx / T;
+    const int c = bc % C;
+    const long b = bc / C;
+    y[idx] = x[(b * C + (C - 1 - c)) * T + t];
+  }
+}
+void launch_flip_channels(const float* x, float* y, int B, int C, int T, hipStream_t s) {
+  long n = (long)B * C * T;
+  hipLaunchKernelGGL(flip_channels_kernel, EW_GRID(n), 0, s, x, y, C, T, n);
+}
+
+__global__ void wn_gate_kernel(const float* a, const float* g, int goff, int gstride, float* acts, int H, int T,
+                               long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bc = idx / T;
+    const int c = bc % H;
+    const long b = bc / H;
+    const float ta = a[(b * 2 * H + c) * T + t] + g[b * gstride + goff + c];
+    const float sa = a[(b * 2 * H + H + c) * T + t] + g[b * gstride + goff + H + c];
+    acts[idx] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+  }
+}
+void launch_wn_gate(const float* a, const float* g, int goff, int gstride, float* acts, int B, int H, int T,
+                    hipStream_t s) {
+  long n = (long)B * H * T;
+  hipLaunchKernelGGL(wn_gate_kernel, EW_GRID(n), 0, s, a, g, goff, gstride, acts, H, T, n);
+}
+
+__global__ void wn_res_skip_kernel(float* x, float* out, const float* rs, int H, int T, int last, int first,
+                                   const int* lens, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bc = idx / T;
+    const int c = bc % H;
+    const long b = bc / H;
+    const bool live = !lens || t < lens[b];
+    if (!last) {
+      const float r = rs[(b * 2 * H + c) * T + t];
+      const float sk = rs[(b * 2 * H + H + c) * T + t];
+      x[idx] = live ? (x[idx] + r) : 0.f;
+      out[idx] = first ? sk : out[idx] + sk;
+    } else {
+      const float sk = rs[(b * H + c) * T + t];
+      const float o = first ? sk : out[idx] + sk;
+      out[idx] = live ? o : 0.f;   // WaveNet returns output * x_mask
+    }
+  }
+}
+void launch_wn_res_skip(float* x, float* out, const float* rs, int B, int H, int T, int last, int first,
+                        const int* lens, hipStream_t s) {
+  long n = (long)B * H * T;
+  hipLaunchKernelGGL(wn_res_skip_kernel, EW_GRID(n), 0, s, x, out, rs, H, T, last, first, lens, n);
+}
+
+__global__ void coupling_sub_kernel(float* x, const float* m, int half, int T, const int* lens, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bc = idx / T;
+    const int c = bc % half;
+    const long b = bc / half;
+    const long xi = (b * 2 * half + half + c) * T + t;
+    float v = x[xi] - m[idx];
+    if (lens && t >= lens[b]) v = 0.f;
+    x[xi] = v;
+  }
+}
+void launch_coupling_sub(float* x, const float* m, int B, int half, int T, const int* lens, hipStream_t s) {
+  long n = (long)B * half * T;
+  hipLaunchKernelGGL(coupling_sub_kernel, EW_GRID(n), 0, s, x, m, half, T, lens, n);
+}
+
+__global__ void mask_kernel(float* x, int C, int T, const int* lens, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long b = idx / ((long)C * T);
+    if (t >= lens[b]) x[idx] = 0.f;
+  }
+}
+void launch_mask(float* x, int B, int C, int T, const int* lens, hipStream_t s) {
+  if (!lens) return;
+  long n = (long)B * C * T;
+  hipLaunchKernelGGL(mask_kernel, EW_GRID(n), 0, s, x, C, T, lens, n);
+}
+
+__global__ void add_channel_bias_kernel(float* x, const float* g, int T, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256)
+    x[idx] += g[idx / T];
+}
+void launch_add_channel_bias(float* x, const float* g, int B, int C, int T, hipStream_t s) {
+  long n = (long)B * C * T;
+  hipLaunchKernelGGL(add_channel_bias_kernel, EW_GRID(n), 0, s, x, g, T, n);
+}
+
+// ------------------------------------------------------------------ NSF harmonic source
+// phase prefix per frame (float64): P[t] = frac(sum_{t'<t} upp * rad[t']), rad = (f0/sr) % 1 in fp32.
+// sin(2*pi*cumsum) is invariant to the integer "cumsum_shift" of generators.py:140-146, so the
+// per-sample phase is P[t] + (jj+1)*rad[t] without ever materialising the 1.5M-sample cumsum.
+__global__ void sine_prefix_kernel(const float* f0, double* P, float* rad_out, int T, int upp, float sr) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  double acc = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const float rad = fmodf(f0[(long)b * T + t] / sr, 1.0f);
+    P[(long)b * T + t] = acc;
+    rad_out[(long)b * T + t] = rad;
+    acc += (double)rad * upp;
+    acc -= floor(acc);
+  }
+}
+
+__global__ void sine_source_kernel(const float* f0, const double* P, const float* rad, const float* noise,
+                                   float* har, int T, int upp, float lin_w, float lin_b, const int* lens,
+                                   long total) {
+  const long per = (long)T * upp;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long b = idx / per;
+    const long j = idx - b * per;
+    const int t = j / upp, jj = j - (long)t * upp;
+    const float f = f0[b * T + t];
+    double ph = P[b * T + t] + (double)(jj + 1) * (double)rad[b * T + t];
+    ph -= floor(ph);
+    const float sine = (float)sin(ph * 6.283185307179586476925) * 0.1f;
+    const float uv = f > 0.f ? 1.f : 0.f;
+    const float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
+    float v = sine * uv + namp * noise[idx];
+    v = tanhf(lin_w * v + lin_b);
+    if (lens && t >= lens[b]) v = 0.f;
+    har[idx] = v;
+  }
+}
+
+void launch_sine_source(const float* f0, const float* noise, float* har, int B, int T, int upp, float sr,
+                        float lin_w, float lin_b, const int* lens, double* scratch, hipStream_t s) {
+  double* P = scratch;
+  float* rad = reinterpret_cast<float*>(scratch + (size_t)B * T);
+  hipLaunchKernelGGL(sine_prefix_kernel, dim3(B), dim3(64), 0, s, f0, P, rad, T, upp, sr);
+  long n = (long)B * T * upp;
+  hipLaunchKernelGGL(sine_source_kernel, EW_GRID(n), 0, s, f0, P, rad, noise, har, T, upp, lin_w, lin_b, lens, n);
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 normal noise
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ void randn_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = blockIdx.x * 256UL + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+    const uint64_t ctr = offset + q;
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x52564358u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c0, c1, c2, c3, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)c0 + 0.5f) * 2.3283064365386963e-10f, u1 = ((float)c1 + 0.5f) * 2.3283064365386963e-10f;
+    const float u2 = ((float)c2 + 0.5f) * 2.3283064365386963e-10f, u3 = ((float)c3 + 0.5f) * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    float v[4] = {r0 * cosf(6.2831853f * u1), r0 * sinf(6.2831853f * u1), r1 * cosf(6.2831853f * u3),
+                  r1 * sinf(6.2831853f * u3)};
+    for (int e = 0; e < 4; ++e)
+      if (q * 4 + e < n) out[q * 4 + e] = v[e];
+  }
+}
+void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(randn_kernel, EW_GRID((long)((n + 3) / 4)), 0, s, out, n, seed, offset);
+}
+
+// ------------------------------------------------------------------ RMVPE helpers
+__global__ void reflect_pad_kernel(const float* x, float* y, int n, int p, long total) {
+  const int np2 = n + 2 * p;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long b = idx / np2;
+    int j = (int)(idx - b * np2) - p;
+    if (j < 0) j = -j;
+    if (j >= n) j = 2 * (n - 1) - j;
+    y[idx] = x[b * n + j];
+  }
+}
+void launch_reflect_pad(const float* x, float* y, int B, int n, int p, hipStream_t s) {
+  long tot = (long)B * (n + 2 * p);
+  hipLaunchKernelGGL(reflect_pad_kernel, EW_GRID(tot), 0, s, x, y, n, p, tot);
+}
+
+__global__ void magnitude_kernel(const float* ft, float* mag, int nb, int F, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long b = idx / ((long)nb * F);
+    const long r = idx - b * nb * F;
+    const float re = ft[b * 2 * nb * F + r], im = ft[b * 2 * nb * F + (long)nb * F + r];
+    mag[idx] = sqrtf(re * re + im * im);
+  }
+}
+void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s) {
+  long tot = (long)B * nb * F;
+  hipLaunchKernelGGL(magnitude_kernel, EW_GRID(tot), 0, s, ft, mag, nb, F, tot);
+}
+
+__global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, int Tp, float sc, float sh,
+                                long total) {
+  const int Wp = nmel + 2;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int col = idx % Wp;
+    const long bt = idx / Wp;
+    const int t = bt % Tp;
+    const long b = bt / Tp;
+    float v = 0.f;
+    if (col > 0 && col < Wp - 1) {
+      const int src = t < F ? t : 2 * F - 2 - t;   // F.pad(mel, (0,pad), "reflect"), RMVPE.py:465
+      const float mv = mel[(b * nmel + (col - 1)) * F + src];
+      v = logf(fmaxf(mv, 1e-5f)) * sc + sh;
+    }
+    out[idx] = v;
+  }
+}
+void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, float bn_scale, float bn_shift,
+                     hipStream_t s) {
+  long tot = (long)B * Tp * (nmel + 2);
+  hipLaunchKernelGGL(mel_post_kernel, EW_GRID(tot), 0, s, mel, out, nmel, F, Tp, bn_scale, bn_shift, tot);
+}
+
+__global__ void avgpool2_kernel(const float* x, float* y, int H, int Wp, long x_ps, long y_ps, long total) {
+  const int W2 = (Wp - 2) / 2, Wpo = W2 + 2, H2 = H / 2;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int col = idx % Wpo;
+    const long pr = idx / Wpo;
+    const int i = pr % H2;
+    const long p = pr / H2;
+    float v = 0.f;
+    if (col > 0 && col < Wpo - 1) {
+      const float* r0 = x + p * x_ps + (long)(2 * i) * Wp + 1 + 2 * (col - 1);
+      const float* r1 = r0 + Wp;
+      v = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
+    }
+    y[p * y_ps + (long)i * Wpo + col] = v;
+  }
+}
+void launch_avgpool2(const float* x, float* y, int planes, int H, int Wp, long x_ps, long y_ps, hipStream_t s) {
+  long tot = (long)planes * (H / 2) * ((Wp - 2) / 2 + 2);
+  hipLaunchKernelGGL(avgpool2_kernel, EW_GRID(tot), 0, s, x, y, H, Wp, x_ps, y_ps, tot);
+}
+
+__global__ void copy_strided_kernel(const float* x, float* y, long n, long x_bs, long y_bs, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long b = idx / n, r = idx - b * n;
+    y[b * y_bs + r] = x[b * x_bs + r];
+  }
+}
+void launch_copy_strided(const float* x, float* y, int B, long n, long x_bs, long y_bs, hipStream_t s) {
+  long tot = (long)B * n;
+  hipLaunchKernelGGL(copy_strided_kernel, EW_GRID(tot), 0, s, x, y, n, x_bs, y_bs, tot);
+}
+
+__global__ void gru_input_kernel(const float* x, float* y, int Cc, int T, int Wp, long total) {
+  const int W = Wp - 2;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % T;
+    const long bk = idx / T;
+    const int kf = bk % (Cc * W);
+    const long b = bk / (Cc * W);
+    const int c = kf / W, f = kf % W;
+    y[idx] = x[((b * Cc + c) * T + t) * Wp + 1 + f];
+  }
+}
+void launch_gru_input(const float* x, float* y, int B, int Cc, int T, int Wp, hipStream_t s) {
+  long tot = (long)B * Cc * (Wp - 2) * T;
+  hipLaunchKernelGGL(gru_input_kernel, EW_GRID(tot), 0, s, x, y, Cc, T, Wp, tot);
+}
+
+// to_local_average_cents + decode + range gate.  numpy semantics reproduced: first-max argmax,
+// float32 salience x float64 cents mapping, float32 weight sum in numpy's 8-lane pairwise order.
+__global__ void decode_f0_kernel(const float* sal, float* f0, int T, int ld, float thred, float f0_min,
+                                 float f0_max, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const float* s = sal + idx * ld;
+    int center = 0;
+    float mx = s[0];
+    for (int i = 1; i < 360; ++i)
+      if (s[i] > mx) {
+        mx = s[i];
+        center = i;
+      }
+    float w[9];
+    double pw[9];
+    for (int k = 0; k < 9; ++k) {
+      const int bin = center - 4 + k;
+      const bool in = bin >= 0 && bin < 360;
+      w[k] = in ? s[bin] : 0.f;
+      const double cm = in ? (20.0 * bin + 1997.3794084376191) : 0.0;
+      pw[k] = (double)w[k] * cm;
+    }
+    const double psum = (((pw[0] + pw[1]) + (pw[2] + pw[3])) + ((pw[4] + pw[5]) + (pw[6] + pw[7]))) + pw[8];
+    const float wsum = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];
+    double cents = psum / (double)wsum;
+    if (mx <= thred) cents = 0.0;
+    double f = 10.0 * pow(2.0, cents / 1200.0);
+    if (f == 10.0) f = 0.0;
+    if (f < (double)f0_min || f > (double)f0_max) f = 0.0;
+    f0[idx] = (float)f;
+  }
+}
+void launch_decode_f0(const float* sal, float* f0, int B, int T, int ld, float thred, float f0_min, float f0_max,
+                      hipStream_t s) {
+  long tot = (long)B * T;
+  hipLaunchKernelGGL(decode_f0_kernel, EW_GRID(tot), 0, s, sal, f0, T, ld, thred, f0_min, f0_max, tot);
+}
+
+__global__ void f0_coarse_kernel(const float* f0_in, float* f0_out, int* coarse, int n, double shift, double mel_min,
+                                 double mel_max) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const double f = (double)f0_in[idx] * shift;
+    double m = 1127.0 * log(1.0 + f / 700.0);
+    if (m > 0.0) m = (m - mel_min) * 254.0 / (mel_max - mel_min) + 1.0;
+    if (m <= 1.0) m = 1.0;
+    if (m > 255.0) m = 255.0;
+    coarse[idx] = (int)rint(m);
+    f0_out[idx] = (float)f;
+  }
+}
+void launch_f0_coarse(const float* f0_in, float* f0_out, int* coarse, int n, double pitch, double f0_min,
+                      double f0_max, hipStream_t s) {
+  const double mel_min = 1127.0 * std::log(1.0 + f0_min / 700.0), mel_max = 1127.0 * std::log(1.0 + f0_max / 700.0);
+  hipLaunchKernelGGL(f0_coarse_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, f0_in, f0_out, coarse, n,
+                     std::pow(2.0, pitch / 12.0), mel_min, mel_max);
+}
+
+__global__ void upsample_protect_kernel(const float* feats, const float* feats0, const float* pitchf, float* out,
+                                        int Th, int p_len, float protect, int use_protect, long total) {
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = idx % p_len;
+    const long c = idx / p_len;
+    const int src = t >> 1;
+    float v = feats[c * Th + src];
+    if (use_protect) {
+      const float ff = pitchf[t] < 1.f ? protect : 1.f;
+      v = v * ff + feats0[c * Th + src] * (1.f - ff);
+    }
+    out[idx] = v;
+  }
+}
+void launch_upsample_protect(const float* feats, const float* feats0, const float* pitchf, float* out, int C,
+                             int Th, int p_len, float protect, int use_protect, hipStream_t s) {
+  long tot = (long)C * p_len;
+  hipLaunchKernelGGL(upsample_protect_kernel, EW_GRID(tot), 0, s, feats, feats0, pitchf, out, Th, p_len, protect,
+                     use_protect, tot);
+}
+
+}  // namespace rvcx

@@ -1,0 +1,398 @@
+// Synthesizer.infer (rvc/lib/algorithm/synthesizers.py:163-188): TextEncoder -> z sampling ->
+// reverse ResidualCouplingBlock -> GeneratorNSF, as a sequence of MFMA conv launches with fused
+// epilogues plus a few memory-bound glue kernels.  Layout: (B, C, T) channel-first, T contiguous.
+#include <cmath>
+
+#include "models.h"
+#include "ops.h"
+
+namespace rvcx {
+
+std::vector<float> wn_weight(const TensorTable& t, const std::string& p, int dim) {
+  if (t.has(p + ".weight")) return t.f32(p + ".weight");
+  std::string gn = p + ".parametrizations.weight.original0", vn = p + ".parametrizations.weight.original1";
+  if (!t.has(gn)) {
+    gn = p + ".weight_g";
+    vn = p + ".weight_v";
+  }
+  std::vector<float> g = t.f32(gn), v = t.f32(vn);
+  const auto shp = t.shape(vn);
+  RVCX_CHECK(shp.size() == 3, "weight-norm tensor must be 3-D: " + p);
+  const int64_t d0 = shp[0], d1 = shp[1], d2 = shp[2];
+  std::vector<float> w(v.size());
+  if (dim == 0) {
+    RVCX_CHECK((int64_t)g.size() == d0, "weight_g shape: " + p);
+    for (int64_t a = 0; a < d0; ++a) {
+      double ss = 0.0;
+      for (int64_t i = 0; i < d1 * d2; ++i) ss += (double)v[a * d1 * d2 + i] * v[a * d1 * d2 + i];
+      const float sc = g[a] / (float)std::sqrt(ss);
+      for (int64_t i = 0; i < d1 * d2; ++i) w[a * d1 * d2 + i] = v[a * d1 * d2 + i] * sc;
+    }
+  } else {  // dim == 2 (HuBERT pos_conv): norm over dims (0,1) per k
+    RVCX_CHECK((int64_t)g.size() == d2, "weight_g shape: " + p);
+    for (int64_t k = 0; k < d2; ++k) {
+      double ss = 0.0;
+      for (int64_t i = 0; i < d0 * d1; ++i) ss += (double)v[i * d2 + k] * v[i * d2 + k];
+      const float sc = g[k] / (float)std::sqrt(ss);
+      for (int64_t i = 0; i < d0 * d1; ++i) w[i * d2 + k] = v[i * d2 + k] * sc;
+    }
+  }
+  return w;
+}
+
+static ConvW load_conv(Ctx& c, const TensorTable& t, const std::string& p, bool wn = false, bool bias = true) {
+  std::vector<float> w = wn ? wn_weight(t, p) : t.f32(p + ".weight");
+  const auto shp = wn ? t.shape(t.has(p + ".weight") ? p + ".weight"
+                                : (t.has(p + ".weight_v") ? p + ".weight_v"
+                                                          : p + ".parametrizations.weight.original1"))
+                      : t.shape(p + ".weight");
+  const int cout = (int)shp[0], cin = (int)shp[1], k = shp.size() > 2 ? (int)shp[2] : 1;
+  std::vector<float> b;
+  if (bias && t.has(p + ".bias")) b = t.f32(p + ".bias");
+  return make_conv(c, w.data(), b.empty() ? nullptr : b.data(), cout, cin, k, 1);
+}
+
+std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const TensorTable& t) {
+  auto M = std::make_unique<SynthModel>();
+  M->cfg = cfg;
+  M->upp = 1;
+  for (int i = 0; i < cfg.n_ups; ++i) M->upp *= cfg.up_rates[i];
+  const int hid = cfg.hidden_channels;
+  RVCX_CHECK(cfg.n_resblocks <= 4 && cfg.n_ups <= 6, "synth cfg out of range");
+  // ---- enc_p
+  M->emb_phone = load_conv(c, t, "enc_p.emb_phone");
+  M->emb_pitch = c.slab.upload(t.f32("enc_p.emb_pitch.weight"));
+  for (int i = 0; i < cfg.n_layers; ++i) {
+    SynthModel::EncLayer L;
+    const std::string a = "enc_p.encoder.attn_layers." + std::to_string(i);
+    // fused q/k/v projection: one (3*hid, hid) 1x1 conv
+    std::vector<float> w, b;
+    for (const char* n : {".conv_q", ".conv_k", ".conv_v"}) {
+      auto wi = t.f32(a + n + ".weight");
+      auto bi = t.f32(a + n + ".bias");
+      w.insert(w.end(), wi.begin(), wi.end());
+      b.insert(b.end(), bi.begin(), bi.end());
+    }
+    L.qkv = make_conv(c, w.data(), b.data(), 3 * hid, hid, 1, 1);
+    L.o = load_conv(c, t, a + ".conv_o");
+    L.rel_k = c.slab.upload(t.f32(a + ".emb_rel_k"));
+    L.rel_v = c.slab.upload(t.f32(a + ".emb_rel_v"));
+    RVCX_CHECK(t.shape(a + ".emb_rel_k")[1] == 21, "rel-pos window must be 10");
+    const std::string is = std::to_string(i);
+    L.g1 = c.slab.upload(t.f32("enc_p.encoder.norm_layers_1." + is + ".gamma"));
+    L.b1 = c.slab.upload(t.f32("enc_p.encoder.norm_layers_1." + is + ".beta"));
+    L.g2 = c.slab.upload(t.f32("enc_p.encoder.norm_layers_2." + is + ".gamma"));
+    L.b2 = c.slab.upload(t.f32("enc_p.encoder.norm_layers_2." + is + ".beta"));
+    L.ffn1 = load_conv(c, t, "enc_p.encoder.ffn_layers." + is + ".conv_1");
+    L.ffn2 = load_conv(c, t, "enc_p.encoder.ffn_layers." + is + ".conv_2");
+    M->enc.push_back(L);
+  }
+  M->proj = load_conv(c, t, "enc_p.proj");
+  // ---- flow
+  for (int f = 0; f < 4; ++f) {
+    const std::string p = "flow.flows." + std::to_string(2 * f);
+    auto& F = M->flows[f];
+    F.pre = load_conv(c, t, p + ".pre");
+    F.post = load_conv(c, t, p + ".post");
+    F.cond = load_conv(c, t, p + ".enc.cond_layer", true);
+    for (int i = 0; i < 3; ++i) {
+      F.in_l[i] = load_conv(c, t, p + ".enc.in_layers." + std::to_string(i), true);
+      F.rs_l[i] = load_conv(c, t, p + ".enc.res_skip_layers." + std::to_string(i), true);
+    }
+  }
+  // ---- dec
+  {
+    auto lw = t.f32("dec.m_source.l_linear.weight");
+    auto lb = t.f32("dec.m_source.l_linear.bias");
+    M->lin_w = lw[0];
+    M->lin_b = lb[0];
+  }
+  M->conv_pre = load_conv(c, t, "dec.conv_pre");
+  M->cond = load_conv(c, t, "dec.cond");
+  M->conv_post = load_conv(c, t, "dec.conv_post", false, false);
+  int ch = cfg.up_initial_channel;
+  for (int i = 0; i < cfg.n_ups; ++i) {
+    SynthModel::Stage S;
+    const int u = cfg.up_rates[i], k = cfg.up_kernels[i], co = cfg.up_initial_channel >> (i + 1);
+    const std::string p = "dec.ups." + std::to_string(i);
+    // ConvTranspose1d weight (Cin, Cout, K), weight-norm over dim 0 (= Cin)
+    std::vector<float> w = wn_weight(t, p, 0);
+    std::vector<float> b = t.f32(p + ".bias");
+    S.up = make_convT1d(c, w.data(), b.data(), ch, co, k, u, (k - u) / 2);
+    int sf0 = 1;
+    for (int j = i + 1; j < cfg.n_ups; ++j) sf0 *= cfg.up_rates[j];
+    S.noise = load_conv(c, t, "dec.noise_convs." + std::to_string(i));
+    S.noise_stride = sf0;
+    S.noise_pad = sf0 > 1 ? sf0 / 2 : 0;
+    S.ch = co;
+    for (int j = 0; j < cfg.n_resblocks; ++j)
+      for (int m = 0; m < 3; ++m) {
+        const std::string rp = "dec.resblocks." + std::to_string(i * cfg.n_resblocks + j);
+        S.c1[j][m] = load_conv(c, t, rp + ".convs1." + std::to_string(m), true);
+        S.c2[j][m] = load_conv(c, t, rp + ".convs2." + std::to_string(m), true);
+      }
+    M->stages.push_back(S);
+    ch = co;
+  }
+  M->emb_g = c.slab.upload(t.f32("emb_g.weight"));
+  return M;
+}
+
+size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
+  const auto& cf = m.cfg;
+  size_t enc = (size_t)B * T * (size_t)(cf.input_dim + 8 * cf.hidden_channels + 2 * cf.filter_channels +
+                                        4 * cf.inter_channels + 64);
+  size_t dec = (size_t)B * T * m.upp * 3;  // har, noise, out
+  size_t mx = 0, sum = (size_t)B * T * cf.up_initial_channel;
+  long tt = T;
+  for (size_t i = 0; i < m.stages.size(); ++i) {
+    tt *= cf.up_rates[i];
+    const size_t n = (size_t)B * tt * m.stages[i].ch;
+    mx = std::max(mx, n);
+    sum += n + 1024;
+  }
+  return (enc + dec + sum + 3 * mx) * sizeof(float) + ((size_t)64 << 20);
+}
+
+namespace {
+
+struct Timer3 {
+  Ctx& c;
+  float* ms;
+  hipEvent_t e[4];
+  Timer3(Ctx& cc, float* m) : c(cc), ms(m) {
+    if (ms)
+      for (auto& x : e) RVCX_HIP(hipEventCreate(&x));
+  }
+  void mark(int i) {
+    if (ms) RVCX_HIP(hipEventRecord(e[i], c.stream));
+  }
+  void finish() {
+    if (!ms) return;
+    RVCX_HIP(hipEventSynchronize(e[3]));
+    for (int i = 0; i < 3; ++i) RVCX_HIP(hipEventElapsedTime(&ms[i], e[i], e[i + 1]));
+    for (auto& x : e) (void)hipEventDestroy(x);
+  }
+};
+
+int* upload_ints(Ctx& c, const std::vector<int>& v) {
+  int* d = c.arena.alloc<int>(v.size());
+  RVCX_HIP(hipMemcpyAsync(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, c.stream));
+  return d;
+}
+
+}  // namespace
+
+void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_ms) {
+  const auto& cf = m.cfg;
+  const int B = io.B, T = io.T, hid = cf.hidden_channels, inter = cf.inter_channels, filt = cf.filter_channels;
+  const int heads = cf.n_heads, kc = hid / heads, half = inter / 2, gin = cf.gin_channels;
+  hipStream_t s = c.stream;
+  Arena& A = c.arena;
+  Timer3 tm(c, stage_ms);
+  tm.mark(0);
+
+  // per-stage valid lengths (ragged batches); null when every item spans the full T
+  bool ragged = false;
+  if (io.lens_host)
+    for (int b = 0; b < B; ++b) ragged |= io.lens_host[b] != T;
+  std::vector<const int*> lens_stage(m.stages.size() + 2, nullptr);
+  const int* lens = nullptr;
+  if (ragged) {
+    std::vector<int> l(io.lens_host, io.lens_host + B);
+    lens = upload_ints(c, l);
+    lens_stage[0] = lens;
+    for (size_t i = 0; i < m.stages.size(); ++i) {
+      for (auto& x : l) x *= cf.up_rates[i];
+      lens_stage[i + 1] = upload_ints(c, l);
+    }
+  }
+  std::vector<int> sidv(io.sid_host, io.sid_host + B);
+
+  // ================================================================ TextEncoder
+  float* x = A.alloc<float>((size_t)B * hid * T);
+  {
+    ConvArgs a = conv1d_args(m.emb_phone, io.phone_ct, x, B, T, T);
+    c.conv(a);
+    launch_embed_pitch(x, m.emb_pitch, io.pitch, B, hid, T, std::sqrt((float)hid), 0.1f, lens, s);
+  }
+  float* qkv = A.alloc<float>((size_t)B * 3 * hid * T);
+  float* att = A.alloc<float>((size_t)B * hid * T);
+  float* tmp = A.alloc<float>((size_t)B * hid * T);
+  float* hbuf = A.alloc<float>((size_t)B * filt * T);
+  float* scratch = A.alloc<float>(attention_scratch_floats(B, heads, T, 10));
+  const float scale = 1.f / std::sqrt((float)kc);
+  for (const auto& L : m.enc) {
+    ConvArgs a = conv1d_args(L.qkv, x, qkv, B, T, T);
+    c.conv(a);
+    launch_attention(qkv, qkv + (size_t)hid * T, qkv + (size_t)2 * hid * T, att, B, heads, kc, T, T,
+                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, s);
+    c.flops += attention_flops(B, heads, kc, T);
+    a = conv1d_args(L.o, att, tmp, B, T, T);
+    conv_set_res(a, x, hid, T);
+    c.conv(a);
+    launch_layernorm_c(tmp, L.g1, L.b1, x, B, hid, T, 1e-5f, nullptr, s);
+    // FFN (attentions.py:195-203): conv_1(pad(x*mask)) -> relu -> conv_2(pad(h*mask)) * mask
+    const int k = L.ffn1.k, pl = (k - 1) / 2;
+    a = conv1d_args(L.ffn1, x, hbuf, B, T, T, 1, 1, pl);
+    a.act = ACT_RELU;
+    a.lens_in = lens;
+    a.lens_out = lens;
+    c.conv(a);
+    a = conv1d_args(L.ffn2, hbuf, tmp, B, T, T, 1, 1, pl);
+    a.lens_in = lens;
+    conv_set_res(a, x, hid, T);      // x + y; positions beyond len are never read by valid frames
+    c.conv(a);
+    launch_layernorm_c(tmp, L.g2, L.b2, x, B, hid, T, 1e-5f, nullptr, s);
+  }
+  float* stats = io.stats_out ? io.stats_out : A.alloc<float>((size_t)B * 2 * inter * T);
+  {
+    launch_mask(x, B, hid, T, lens, s);                       // x = x * x_mask (encoders.py:72)
+    ConvArgs a = conv1d_args(m.proj, x, stats, B, T, T);
+    a.lens_out = lens;
+    c.conv(a);
+  }
+  tm.mark(1);
+
+  // ================================================================ z_p and the reverse flow
+  float* z = A.alloc<float>((size_t)B * inter * T);
+  float* z2 = A.alloc<float>((size_t)B * inter * T);
+  launch_sample_z(stats, io.z_noise, z, B, inter, T, lens, s);
+  // speaker embedding g (B, gin)
+  float* g = A.alloc<float>((size_t)B * gin);
+  for (int b = 0; b < B; ++b)
+    RVCX_HIP(hipMemcpyAsync(g + (size_t)b * gin, m.emb_g + (size_t)sidv[b] * gin, gin * sizeof(float),
+                            hipMemcpyDeviceToDevice, s));
+  {
+    float* h = att;       // reuse (B,hid,T)
+    float* xin = qkv;     // (B,2*hid,T) fits in the 3*hid buffer
+    float* acts = tmp;
+    float* rs = hbuf;     // needs 2*hid*T <= filt*T
+    RVCX_CHECK(filt >= 2 * hid, "buffer reuse assumes filter_channels >= 2*hidden");
+    float* wout = A.alloc<float>((size_t)B * hid * T);
+    float* mbuf = A.alloc<float>((size_t)B * half * T);
+    float* gc = A.alloc<float>((size_t)B * 6 * hid);
+    for (int f = 3; f >= 0; --f) {
+      const auto& F = m.flows[f];
+      launch_flip_channels(z, z2, B, inter, T, s);
+      std::swap(z, z2);
+      ConvArgs a = conv1d_args(F.pre, z, h, B, T, T);
+      a.x_bs = (long)inter * T;          // reads only the first `half` channels of z
+      a.lens_out = lens;
+      c.conv(a);
+      a = conv1d_args(F.cond, g, gc, B, 1, 1);
+      c.conv(a);
+      for (int i = 0; i < 3; ++i) {
+        a = conv1d_args(F.in_l[i], h, xin, B, T, T, 1, 1, (F.in_l[i].k - 1) / 2);
+        a.lens_in = lens;
+        c.conv(a);
+        launch_wn_gate(xin, gc, i * 2 * hid, 6 * hid, acts, B, hid, T, s);
+        a = conv1d_args(F.rs_l[i], acts, rs, B, T, T);
+        c.conv(a);
+        launch_wn_res_skip(h, wout, rs, B, hid, T, i == 2, i == 0, lens, s);
+      }
+      a = conv1d_args(F.post, wout, mbuf, B, T, T);
+      a.lens_out = lens;
+      c.conv(a);
+      launch_coupling_sub(z, mbuf, B, half, T, lens, s);
+    }
+  }
+  if (io.z_out)
+    RVCX_HIP(hipMemcpyAsync(io.z_out, z, (size_t)B * inter * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+  tm.mark(2);
+
+  // ================================================================ NSF-HiFi-GAN decoder
+  const long Tupp = (long)T * m.upp;
+  float* har = A.alloc<float>((size_t)B * Tupp);
+  {
+    double* sc = A.alloc<double>((size_t)B * T * 2);
+    launch_sine_source(io.pitchf, io.src_noise, har, B, T, m.upp, (float)cf.sr, m.lin_w, m.lin_b, lens, sc, s);
+  }
+  const int C0 = cf.up_initial_channel;
+  float* cur = A.alloc<float>((size_t)B * C0 * T);
+  {
+    ConvArgs a = conv1d_args(m.conv_pre, z, cur, B, T, T, 1, 1, 3);
+    a.lens_in = lens;
+    c.conv(a);
+    float* gcond = A.alloc<float>((size_t)B * C0);
+    a = conv1d_args(m.cond, g, gcond, B, 1, 1);
+    c.conv(a);
+    launch_add_channel_bias(cur, gcond, B, C0, T, s);
+  }
+  long Tin = T;
+  for (size_t i = 0; i < m.stages.size(); ++i) {
+    const auto& S = m.stages[i];
+    const long Tout = Tin * cf.up_rates[i];
+    const size_t n = (size_t)B * S.ch * Tout;
+    float* xs = A.alloc<float>(n);      // survives the stage (next stage's input)
+    const size_t stage_mark = A.mark();
+    float* xu = A.alloc<float>(n);
+    float* xc = A.alloc<float>(n);
+    float* xt = A.alloc<float>(n);
+    const int* lin = lens_stage[i];
+    const int* lout = lens_stage[i + 1];
+    ConvArgs a = convT1d_args(S.up, cur, xu, B, (int)Tin, (int)Tout);
+    a.pre_act = ACT_LRELU;
+    a.pre_slope = 0.1f;
+    a.lens_in = lin;
+    a.lens_out = lout;
+    c.conv(a);
+    // x = x + noise_conv(har_source)   (nsf.py:129)
+    a = conv1d_args(S.noise, har, xu, B, (int)Tupp, (int)Tout, S.noise_stride, 1, S.noise_pad);
+    conv_set_res(a, xu, S.ch, (int)Tout);
+    a.lens_in = lens_stage[m.stages.size()];
+    a.lens_out = lout;
+    c.conv(a);
+    // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53)
+    const int nk = cf.n_resblocks;
+    for (int j = 0; j < nk; ++j) {
+      const int k = cf.res_kernels[j];
+      const float* xin = xu;
+      for (int mi = 0; mi < 3; ++mi) {
+        const int d = cf.res_dilations[j][mi];
+        a = conv1d_args(S.c1[j][mi], xin, xt, B, (int)Tout, (int)Tout, 1, d, (k * d - d) / 2);
+        a.pre_act = ACT_LRELU;
+        a.pre_slope = 0.1f;
+        a.act = ACT_LRELU;       // the leaky_relu that precedes c2, applied once here
+        a.act_slope = 0.1f;
+        a.lens_in = lout;
+        a.lens_out = lout;
+        c.conv(a);
+        a = conv1d_args(S.c2[j][mi], xt, xc, B, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
+        conv_set_res(a, xin, S.ch, (int)Tout);
+        a.lens_in = lout;
+        a.lens_out = lout;
+        if (mi == 2) {           // last conv of the block: accumulate into xs, skip the plain store
+          a.y = nullptr;
+          a.y2 = xs;
+          a.y2_bs = (long)S.ch * Tout;
+          a.y2_cs = (int)Tout;
+          a.acc2_mode = j == 0 ? ACC2_SET : (j == nk - 1 ? ACC2_ADD_DIV : ACC2_ADD);
+          a.acc2_div = (float)nk;
+          if (nk == 1) a.acc2_mode = ACC2_SET;
+        }
+        c.conv(a);
+        xin = xc;
+      }
+    }
+    cur = xs;
+    Tin = Tout;
+    A.reset(stage_mark);
+  }
+  {
+    // x = leaky_relu(x) [default slope 0.01, nsf.py:142]; tanh(conv_post(x))
+    const auto& S = m.stages.back();
+    ConvArgs a = conv1d_args(m.conv_post, cur, io.out, B, (int)Tin, (int)Tin, 1, 1, 3);
+    a.pre_act = ACT_LRELU;
+    a.pre_slope = 0.01f;
+    a.act = ACT_TANH;
+    a.lens_in = lens_stage[m.stages.size()];
+    a.lens_out = lens_stage[m.stages.size()];
+    (void)S;
+    c.conv(a);
+  }
+  tm.mark(3);
+  tm.finish();
+}
+
+}  // namespace rvcx

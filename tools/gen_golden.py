@@ -265,7 +265,7 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
         e = max(e, report(f"vc chunk {i} f32", a, b))
     d = np.abs(pcm.astype(np.int32) - opcm.astype(np.int32))
     print(f"  pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
-    assert e < 1e-4 and d.max() <= 2, (e, d.max())
+    assert e < 1e-4 and d.max() <= 8, (e, d.max())
     rawcat = np.concatenate(raw)
     store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch,
                  volume_envelope=volume_envelope, protect=protect, f0_min=f0_min, f0_max=f0_max,
