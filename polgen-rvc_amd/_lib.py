@@ -250,5 +250,50 @@ class Context:
                                         C.c_uint64(seed), _p(out)), "synth_infer")
         return out
 
+    def load_rmvpe(self, cfg_struct, state: dict):
+        tbl, keep = make_table(state)
+        self._ck(lib().rvcx_load_rmvpe(self._h, C.byref(cfg_struct), tbl, len(tbl)), "load_rmvpe")
+
+    def load_hubert(self, cfg_struct, state: dict):
+        tbl, keep = make_table(state)
+        self._ck(lib().rvcx_load_hubert(self._h, C.byref(cfg_struct), tbl, len(tbl)), "load_hubert")
+
+    def rmvpe_f0(self, audio, thred=0.03, f0_min=50, f0_max=1100, return_hidden=False):
+        audio = f32(audio)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B, n = audio.shape
+        F = 1 + n // 160
+        f0 = np.empty((B, F), np.float32)
+        hid = np.empty((B, F, 360), np.float32) if return_hidden else None
+        self._ck(lib().rvcx_rmvpe_f0(self._h, B, _p(audio), C.c_int64(n), C.c_float(thred), C.c_float(f0_min),
+                                     C.c_float(f0_max), _p(f0), _p(hid)), "rmvpe_f0")
+        return (f0, hid) if return_hidden else f0
+
+    def hubert_frames(self, n: int) -> int:
+        return int(lib().rvcx_hubert_frames(self._h, C.c_int64(n)))
+
+    def hubert_features(self, wav, embed_dim, output_layer=12):
+        wav = f32(wav)
+        if wav.ndim == 1:
+            wav = wav[None]
+        B, n = wav.shape
+        T = self.hubert_frames(n)
+        out = np.empty((B, T, embed_dim), np.float32)
+        self._ck(lib().rvcx_hubert_features(self._h, B, _p(wav), C.c_int64(n), output_layer, _p(out)),
+                 "hubert_features")
+        return out
+
+    def bigru(self, x, sd, prefix="fc.0.gru"):
+        x = f32(x)
+        B, T, I = x.shape
+        g = lambda n: f32(sd[f"{prefix}.{n}"])
+        H = g("weight_hh_l0").shape[1]
+        y = np.empty((B, T, 2 * H), np.float32)
+        a = [g("weight_ih_l0"), g("weight_hh_l0"), g("bias_ih_l0"), g("bias_hh_l0"), g("weight_ih_l0_reverse"),
+             g("weight_hh_l0_reverse"), g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")]
+        self._ck(lib().rvcx_op_bigru(self._h, _p(x), *[_p(t) for t in a], _p(y), B, T, I, H), "op_bigru")
+        return y
+
     def flop_counter(self, reset=False) -> float:
         return float(lib().rvcx_flop_counter(self._h, 1 if reset else 0))

@@ -360,6 +360,104 @@ int rvcx_op_layernorm_c(rvcx_ctx* ctx, const float* x, const float* gamma, const
   API_END
 }
 
+int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor* tbl, int n) {
+  API_BEGIN(ctx)
+  ensure_slab(*C);
+  TensorTable t = make_table(tbl, n);
+  C->rmvpe = rmvpe_load(*C, *cfg, t);
+  API_END
+}
+
+int rvcx_load_hubert(rvcx_ctx* ctx, const rvcx_hubert_cfg* cfg, const rvcx_tensor* tbl, int n) {
+  API_BEGIN(ctx)
+  ensure_slab(*C);
+  TensorTable t = make_table(tbl, n);
+  C->hubert = hubert_load(*C, *cfg, t);
+  API_END
+}
+
+int rvcx_rmvpe_f0(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float thred, float f0_min, float f0_max,
+                  float* f0, float* hidden) {
+  API_BEGIN(ctx)
+  if (!C->rmvpe) fail("rmvpe not loaded");
+  const int F = (int)(1 + n / 160);
+  C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, B, n) + (size_t)B * (n + (size_t)F * 362) * 4);
+  C->arena.reset();
+  float* da = any_to_dev(*C, audio, (size_t)B * n);
+  float* df0 = C->arena.alloc<float>((size_t)B * F);
+  float* dh = hidden ? C->arena.alloc<float>((size_t)B * F * 360) : nullptr;
+  rmvpe_forward(*C, *C->rmvpe, B, da, n, thred, f0_min, f0_max, df0, dh, C->stream);
+  RVCX_HIP(hipMemcpyAsync(f0, df0, (size_t)B * F * 4, hipMemcpyDefault, C->stream));
+  if (hidden) RVCX_HIP(hipMemcpyAsync(hidden, dh, (size_t)B * F * 360 * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_hubert_frames(rvcx_ctx* ctx, int64_t n) {
+  if (!ctx || !ctx->c.hubert) return -1;
+  return hubert_frames(*ctx->c.hubert, n);
+}
+
+int rvcx_hubert_features(rvcx_ctx* ctx, int B, const float* wav, int64_t n, int output_layer, float* feats) {
+  API_BEGIN(ctx)
+  if (!C->hubert) fail("hubert not loaded");
+  const int T = hubert_frames(*C->hubert, n), E = C->hubert->cfg.embed_dim;
+  if (T <= 0) fail("hubert: input too short");
+  C->arena.reserve(hubert_arena_bytes(*C->hubert, B, n) + (size_t)B * (n + (size_t)2 * T * E) * 4);
+  C->arena.reset();
+  float* dw = any_to_dev(*C, wav, (size_t)B * n);
+  float* fct = C->arena.alloc<float>((size_t)B * E * T);
+  float* ftc = C->arena.alloc<float>((size_t)B * E * T);
+  hubert_forward(*C, *C->hubert, B, dw, n, output_layer, fct, C->stream);
+  launch_transpose(fct, ftc, B, E, T, C->stream);   // (B,E,T) -> (B,T,E)
+  RVCX_HIP(hipMemcpyAsync(feats, ftc, (size_t)B * E * T * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_op_bigru(rvcx_ctx* ctx, const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                  const float* b_hh, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
+                  const float* b_hh_r, float* y, int B, int T, int I, int H) {
+  API_BEGIN(ctx)
+  ensure_slab(*C);
+  const int H3 = 3 * H;
+  C->arena.reserve(((size_t)B * T * (2 * I + 2 * H3 + 4 * H)) * 4 + (64 << 20));
+  C->arena.reset();
+  std::vector<float> wih((size_t)2 * H3 * I), bih((size_t)2 * H3), whh_t((size_t)2 * H * H3), bhh((size_t)2 * H3);
+  const float* wi[2] = {w_ih, w_ih_r};
+  const float* wh[2] = {w_hh, w_hh_r};
+  const float* bi[2] = {b_ih, b_ih_r};
+  const float* bh[2] = {b_hh, b_hh_r};
+  for (int d = 0; d < 2; ++d) {
+    std::memcpy(&wih[(size_t)d * H3 * I], wi[d], (size_t)H3 * I * 4);
+    std::memcpy(&bih[(size_t)d * H3], bi[d], (size_t)H3 * 4);
+    std::memcpy(&bhh[(size_t)d * H3], bh[d], (size_t)H3 * 4);
+    for (int j = 0; j < H3; ++j)
+      for (int k = 0; k < H; ++k) whh_t[((size_t)d * H + k) * H3 + j] = wh[d][(size_t)j * H + k];
+  }
+  ConvW Wih = make_conv(*C, wih.data(), bih.data(), 2 * H3, I, 1, 1);
+  const float* dwhh = C->slab.upload(whh_t);
+  const float* dbhh = C->slab.upload(bhh);
+  float* dx = to_dev(*C, x, (size_t)B * T * I);
+  float* dxt = C->arena.alloc<float>((size_t)B * T * I);
+  launch_transpose(dx, dxt, B, T, I, C->stream);   // (B,T,I) -> (B,I,T)
+  float* gi = C->arena.alloc<float>((size_t)B * T * 2 * H3);
+  ConvArgs a = conv1d_args(Wih, dxt, gi, B, T, T);
+  a.out_mode = OUT_TRANSPOSED;
+  a.y_bs = (long)T * 2 * H3;
+  a.y_cs = 2 * H3;
+  C->conv(a);
+  float* gy = C->arena.alloc<float>((size_t)B * 2 * H * T);
+  launch_bigru(gi, dwhh, dbhh, gy, B, T, H, C->stream);
+  float* gyt = C->arena.alloc<float>((size_t)B * 2 * H * T);
+  launch_transpose(gy, gyt, B, 2 * H, T, C->stream);  // (B,2H,T) -> (B,T,2H)
+  to_host(*C, y, gyt, (size_t)B * T * 2 * H);
+  C->arena.reset();
+  API_END
+}
+
 // ------------------------------------------------------------------------------------------
 // entry points not implemented yet return an error (never a silent fallback)
 // ------------------------------------------------------------------------------------------
@@ -370,13 +468,8 @@ int rvcx_op_layernorm_c(rvcx_ctx* ctx, const float* x, const float* gamma, const
     return -1;                                  \
   } while (0)
 
-int rvcx_load_hubert(rvcx_ctx* c, const rvcx_hubert_cfg*, const rvcx_tensor*, int) { NOT_IMPL(c, "rvcx_load_hubert"); }
-int rvcx_load_rmvpe(rvcx_ctx* c, const rvcx_rmvpe_cfg*, const rvcx_tensor*, int) { NOT_IMPL(c, "rvcx_load_rmvpe"); }
 int rvcx_load_index(rvcx_ctx* c, const float*, int64_t, int) { NOT_IMPL(c, "rvcx_load_index"); }
-int rvcx_rmvpe_f0(rvcx_ctx* c, int, const float*, int64_t, float, float, float, float*, float*) { NOT_IMPL(c, "rvcx_rmvpe_f0"); }
 int rvcx_rmvpe_frames(int64_t n) { return (int)(1 + n / 160); }
-int rvcx_hubert_features(rvcx_ctx* c, int, const float*, int64_t, int, float*) { NOT_IMPL(c, "rvcx_hubert_features"); }
-int rvcx_hubert_frames(rvcx_ctx* c, int64_t) { NOT_IMPL(c, "rvcx_hubert_frames"); }
 int rvcx_index_blend(rvcx_ctx* c, float*, int, float, int64_t*, float*) { NOT_IMPL(c, "rvcx_index_blend"); }
 int64_t rvcx_out_len(rvcx_ctx* c, int, int64_t, const rvcx_params*) { NOT_IMPL(c, "rvcx_out_len"); }
 int rvcx_convert_batch(rvcx_ctx* c, int, int, const float* const*, const int64_t*, const rvcx_params*,
@@ -384,8 +477,6 @@ int rvcx_convert_batch(rvcx_ctx* c, int, int, const float* const*, const int64_t
 int64_t rvcx_noise_len(rvcx_ctx* c, int, int64_t, const rvcx_params*) { NOT_IMPL(c, "rvcx_noise_len"); }
 int rvcx_get_f0(rvcx_ctx* c, const float*, int64_t, const rvcx_params*, int32_t*, float*, int64_t*) { NOT_IMPL(c, "rvcx_get_f0"); }
 int rvcx_last_timing(rvcx_ctx* c, float*) { NOT_IMPL(c, "rvcx_last_timing"); }
-int rvcx_op_bigru(rvcx_ctx* c, const float*, const float*, const float*, const float*, const float*, const float*,
-                  const float*, const float*, const float*, float*, int, int, int, int) { NOT_IMPL(c, "rvcx_op_bigru"); }
 int rvcx_op_highpass(rvcx_ctx* c, const double*, double*, int64_t) { NOT_IMPL(c, "rvcx_op_highpass"); }
 
 }  // extern "C"

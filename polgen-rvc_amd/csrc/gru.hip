@@ -22,7 +22,7 @@ __global__ __launch_bounds__(3 * H) void bigru_kernel(const float* __restrict__ 
   const float* W = whh_t + (long)dir * H * 3 * H;
   const float bj = bhh[dir * 3 * H + j];
   const float* gib = gi + (long)b * T * 6 * H + dir * 3 * H;
-  float* yb = y + (long)b * T * 2 * H + dir * H;
+  float* yb = y + ((long)b * 2 + dir) * H * T;
   if (j < H) hs[j] = 0.f;
   __syncthreads();
   for (int step = 0; step < T; ++step) {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(3 * H) void bigru_kernel(const float* __restrict__ 
       const float n = tanhf(g[2 * H + j] + r * gh[2 * H + j]);
       const float hn = (1.f - z) * n + z * hs[j];
       hs[j] = hn;
-      yb[(long)t * 2 * H + j] = hn;
+      yb[(long)j * T + t] = hn;
     }
     __syncthreads();
   }

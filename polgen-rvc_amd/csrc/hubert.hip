@@ -1,0 +1,156 @@
+// HuBERT-base / ContentVec content encoder: HubertModel.extract_features(source, padding_mask=False,
+// output_layer=L)[0] of fairseq 0.12.2 (loaded at rvc/infer/infer.py:67-74, called at
+// rvc/infer/pipeline.py:228-236).  fairseq is not vendored in the reference, so the arithmetic follows
+// the published architecture (extractor mode "default": GroupNorm after conv 0, no conv bias; post-LN
+// encoder; pos_conv k=128 g=16 weight_norm(dim=2) + SamePad + GELU).
+// Activations stay channel-first (B, C, T): every Linear is a 1x1 MFMA conv, QKV is one fused GEMM.
+#include <cmath>
+
+#include "models.h"
+#include "ops.h"
+
+namespace rvcx {
+
+std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, const TensorTable& t) {
+  auto M = std::make_unique<HubertModel>();
+  M->cfg = cfg;
+  const int E = cfg.embed_dim;
+  for (int i = 0; i < cfg.n_conv; ++i) {
+    const std::string p = "feature_extractor.conv_layers." + std::to_string(i) + ".0.weight";
+    auto w = t.f32(p);
+    const auto shp = t.shape(p);
+    RVCX_CHECK((int)shp[2] == cfg.conv_kernels[i], "hubert conv kernel mismatch");
+    M->convs.push_back(make_conv(c, w.data(), nullptr, (int)shp[0], (int)shp[1], (int)shp[2], 1));
+  }
+  M->gn_g = c.slab.upload(t.f32("feature_extractor.conv_layers.0.2.weight"));
+  M->gn_b = c.slab.upload(t.f32("feature_extractor.conv_layers.0.2.bias"));
+  M->ln0_g = c.slab.upload(t.f32("layer_norm.weight"));
+  M->ln0_b = c.slab.upload(t.f32("layer_norm.bias"));
+  {
+    auto w = t.f32("post_extract_proj.weight");
+    auto b = t.f32("post_extract_proj.bias");
+    M->proj = make_conv(c, w.data(), b.data(), E, cfg.conv_dim, 1, 1);
+  }
+  {
+    std::vector<float> w = wn_weight(t, "encoder.pos_conv.0", 2);
+    auto b = t.f32("encoder.pos_conv.0.bias");
+    M->pos_conv = make_conv(c, w.data(), b.data(), E, E / cfg.pos_groups, cfg.pos_kernel, cfg.pos_groups);
+  }
+  M->eln_g = c.slab.upload(t.f32("encoder.layer_norm.weight"));
+  M->eln_b = c.slab.upload(t.f32("encoder.layer_norm.bias"));
+  for (int l = 0; l < cfg.layers; ++l) {
+    HubertModel::Layer L;
+    const std::string p = "encoder.layers." + std::to_string(l);
+    std::vector<float> w, b;
+    for (const char* n : {".self_attn.q_proj", ".self_attn.k_proj", ".self_attn.v_proj"}) {
+      auto wi = t.f32(p + n + ".weight");
+      auto bi = t.f32(p + n + ".bias");
+      w.insert(w.end(), wi.begin(), wi.end());
+      b.insert(b.end(), bi.begin(), bi.end());
+    }
+    L.qkv = make_conv(c, w.data(), b.data(), 3 * E, E, 1, 1);
+    auto lin = [&](const std::string& n, int co, int ci) {
+      auto wi = t.f32(p + n + ".weight");
+      auto bi = t.f32(p + n + ".bias");
+      return make_conv(c, wi.data(), bi.data(), co, ci, 1, 1);
+    };
+    L.o = lin(".self_attn.out_proj", E, E);
+    L.fc1 = lin(".fc1", cfg.ffn_dim, E);
+    L.fc2 = lin(".fc2", E, cfg.ffn_dim);
+    L.ln1_g = c.slab.upload(t.f32(p + ".self_attn_layer_norm.weight"));
+    L.ln1_b = c.slab.upload(t.f32(p + ".self_attn_layer_norm.bias"));
+    L.ln2_g = c.slab.upload(t.f32(p + ".final_layer_norm.weight"));
+    L.ln2_b = c.slab.upload(t.f32(p + ".final_layer_norm.bias"));
+    M->layers.push_back(L);
+  }
+  return M;
+}
+
+int hubert_frames(const HubertModel& m, int64_t n) {
+  int64_t t = n;
+  for (int i = 0; i < m.cfg.n_conv; ++i) t = (t - m.cfg.conv_kernels[i]) / m.cfg.conv_strides[i] + 1;
+  return (int)t;
+}
+
+size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
+  const int64_t t0 = (n - m.cfg.conv_kernels[0]) / m.cfg.conv_strides[0] + 1;
+  const int T = hubert_frames(m, n);
+  size_t conv = 2 * (size_t)m.cfg.conv_dim * t0;
+  size_t enc = (size_t)T * (size_t)(6 * m.cfg.embed_dim + m.cfg.ffn_dim + 64);
+  return (size_t)B * (conv + enc) * sizeof(float) + ((size_t)64 << 20);
+}
+
+void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
+                    float* feats_ct, hipStream_t s) {
+  Arena& A = c.arena;
+  const auto& cf = m.cfg;
+  const int C = cf.conv_dim, E = cf.embed_dim;
+  const int64_t t0 = (n - cf.conv_kernels[0]) / cf.conv_strides[0] + 1;
+  RVCX_CHECK(t0 > 0, "hubert: input too short");
+  float* bufa = A.alloc<float>((size_t)B * C * t0);
+  float* bufb = A.alloc<float>((size_t)B * C * t0);
+  // ---- conv feature extractor
+  int64_t Tin = n;
+  const float* x = wav;
+  float* y = bufa;
+  for (int i = 0; i < cf.n_conv; ++i) {
+    const int64_t Tout = (Tin - cf.conv_kernels[i]) / cf.conv_strides[i] + 1;
+    RVCX_CHECK(Tout > 0, "hubert: input too short");
+    ConvArgs a = conv1d_args(m.convs[i], x, y, B, (int)Tin, (int)Tout, cf.conv_strides[i], 1, 0);
+    if (i > 0) a.act = ACT_GELU;
+    c.conv_on(a, s);
+    if (i == 0) {
+      float* z = (y == bufa) ? bufb : bufa;
+      launch_groupnorm_gelu(y, m.gn_g, m.gn_b, z, B, C, (int)Tout, 1e-5f, s);
+      y = z;
+    }
+    x = y;
+    y = (y == bufa) ? bufb : bufa;
+    Tin = Tout;
+  }
+  const int T = (int)Tin;
+  // ---- LayerNorm(C) -> proj -> x + gelu(pos_conv(x)) -> LayerNorm(E)
+  float* ln = y;
+  launch_layernorm_c(x, m.ln0_g, m.ln0_b, ln, B, C, T, 1e-5f, nullptr, s);
+  float* h = A.alloc<float>((size_t)B * E * T);
+  float* h2 = A.alloc<float>((size_t)B * E * T);
+  {
+    ConvArgs a = conv1d_args(m.proj, ln, h, B, T, T);
+    c.conv_on(a, s);
+    a = conv1d_args(m.pos_conv, h, h2, B, T, T, 1, 1, cf.pos_kernel / 2);   // SamePad: drop the last frame
+    a.act = ACT_GELU;
+    conv_set_res(a, h, E, T);
+    c.conv_on(a, s);
+    launch_layernorm_c(h2, m.eln_g, m.eln_b, h, B, E, T, 1e-5f, nullptr, s);
+  }
+  // ---- post-LN transformer layers
+  float* qkv = A.alloc<float>((size_t)B * 3 * E * T);
+  float* att = A.alloc<float>((size_t)B * E * T);
+  float* ff = A.alloc<float>((size_t)B * cf.ffn_dim * T);
+  const int hd = E / cf.heads;
+  const float scale = 1.f / std::sqrt((float)hd);
+  const int nl = std::min(output_layer, cf.layers);
+  for (int l = 0; l < nl; ++l) {
+    const auto& L = m.layers[l];
+    ConvArgs a = conv1d_args(L.qkv, h, qkv, B, T, T);
+    c.conv_on(a, s);
+    launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T,
+                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, s);
+    c.flops += attention_flops(B, cf.heads, hd, T);
+    a = conv1d_args(L.o, att, h2, B, T, T);
+    conv_set_res(a, h, E, T);
+    c.conv_on(a, s);
+    launch_layernorm_c(h2, L.ln1_g, L.ln1_b, h, B, E, T, 1e-5f, nullptr, s);
+    a = conv1d_args(L.fc1, h, ff, B, T, T);
+    a.act = ACT_GELU;
+    c.conv_on(a, s);
+    a = conv1d_args(L.fc2, ff, h2, B, T, T);
+    conv_set_res(a, h, E, T);
+    c.conv_on(a, s);
+    launch_layernorm_c(h2, L.ln2_g, L.ln2_b, (l == nl - 1) ? feats_ct : h, B, E, T, 1e-5f, nullptr, s);
+  }
+  if (nl == 0) RVCX_HIP(hipMemcpyAsync(feats_ct, h, (size_t)B * E * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RVCX_HIP(hipGetLastError());
+}
+
+}  // namespace rvcx

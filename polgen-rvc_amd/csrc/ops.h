@@ -12,7 +12,8 @@ size_t attention_scratch_floats(int B, int H, int T, int window);
 double attention_flops(int B, int H, int D, int T);
 
 // ---- gru.hip
-// gi: (B, T, 2*3H) input projections (+b_ih) for [fwd | rev]; whh: (2, 3H, H); bhh: (2, 3H); y: (B, T, 2H)
+// gi: (B, T, 2*3H) input projections (+b_ih) for [fwd | rev]; whh_t: (2, H, 3H); bhh: (2, 3H);
+// y: (B, 2H, T) channel-first (feeds the classifier conv directly)
 void launch_bigru(const float* gi, const float* whh, const float* bhh, float* y, int B, int T, int H,
                   hipStream_t stream);
 
@@ -53,8 +54,8 @@ void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStrea
 // tanh(conv_post) is done in the conv epilogue; final leaky_relu(0.01) is its prologue.
 
 // ---- RMVPE helpers
-// reflect-pad 1-D signals: x (B,n) -> y (B,n+2p)
-void launch_reflect_pad(const float* x, float* y, int B, int n, int p, hipStream_t s);
+// reflect-pad 1-D signals: x (B,n) -> y (B,n+2p) written with batch stride y_bs
+void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s);
 // |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F)
 void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s);
 // log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp

@@ -336,19 +336,20 @@ void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStrea
 }
 
 // ------------------------------------------------------------------ RMVPE helpers
-__global__ void reflect_pad_kernel(const float* x, float* y, int n, int p, long total) {
+__global__ void reflect_pad_kernel(const float* x, float* y, int n, int p, long y_bs, long total) {
   const int np2 = n + 2 * p;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long b = idx / np2;
-    int j = (int)(idx - b * np2) - p;
+    const long o = idx - b * np2;
+    int j = (int)o - p;
     if (j < 0) j = -j;
     if (j >= n) j = 2 * (n - 1) - j;
-    y[idx] = x[b * n + j];
+    y[b * y_bs + o] = x[b * n + j];
   }
 }
-void launch_reflect_pad(const float* x, float* y, int B, int n, int p, hipStream_t s) {
+void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s) {
   long tot = (long)B * (n + 2 * p);
-  hipLaunchKernelGGL(reflect_pad_kernel, EW_GRID(tot), 0, s, x, y, n, p, tot);
+  hipLaunchKernelGGL(reflect_pad_kernel, EW_GRID(tot), 0, s, x, y, n, p, y_bs, tot);
 }
 
 __global__ void magnitude_kernel(const float* ft, float* mag, int nb, int F, long total) {
