@@ -117,16 +117,18 @@ int rvcx_index_blend(rvcx_ctx*, float* feats_hd, int T, float index_rate, int64_
                      float* dist_hd);
 
 /* ---- whole path ------------------------------------------------------------------------ */
-/* number of int16 samples VC.pipeline returns for an n-sample 16 kHz input */
+/* capacity (in samples) the caller must provide per output buffer for an n-sample 16 kHz input;
+ * the exact count VC.pipeline produces depends on the silence-aligned cut points (and is exactly
+ * (n/160)*upp - 2*upp... for single-chunk clips); rvcx_convert_batch reports it in out_n */
 int64_t rvcx_out_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* VC.pipeline for a batch of utterances -- rvc/infer/pipeline.py:289-467 with
  * f0_method="rmvpe+", pitch_guidance=1, resample_sr=0, f0_file=None.
  * wav16k[i] (n[i] samples, 16 kHz mono f32, host or device); out[i] caller-allocated int16
- * buffers of rvcx_out_len samples (host or device); out_f32[i] optional pre-quantisation
- * float waveform; noise[i] optional packed parity noise (see rvcx_noise_len). */
+ * buffers of rvcx_out_len samples (host or device); out_f32[i] optional (same capacity) float
+ * waveform before int16 quantisation; out_n[i] receives the number of samples produced; noise[i] optional packed parity noise (see rvcx_noise_len). */
 int rvcx_convert_batch(rvcx_ctx*, int model_id, int B, const float* const* wav16k_hd,
                        const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
-                       int16_t* const* out_hd, float* const* out_f32_hd);
+                       int16_t* const* out_hd, float* const* out_f32_hd, int64_t* out_n);
 /* floats of parity noise rvcx_convert_batch consumes for one n-sample utterance: for each
  * chunk in order, z_noise (inter*T) then src_noise (T*upp) -- the draw order of the reference */
 int64_t rvcx_noise_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);

@@ -172,3 +172,37 @@ def infer_f0(sd, cfg, audio: np.ndarray, thred=0.03, f0_min=50, f0_max=1100, ret
     hid = mel2hidden(sd, cfg, mel).squeeze(0).numpy()
     f0 = decode_f0(hid, thred, f0_min, f0_max)
     return (f0, hid, mel) if return_hidden else f0
+
+
+def unstable_frames(hid: np.ndarray, thred=0.03, f0_min=50, f0_max=1100, rel=2e-4, cents_tol=0.05) -> np.ndarray:
+    """Frames whose decoded f0 could change under a relative perturbation ``rel`` of the salience
+    (~20x the fp32 rounding noise): a competing maximum >= 2 bins away, an adjacent-bin tie that moves
+    the local average by more than ``cents_tol`` cents, a salience max near the voicing threshold, or an
+    f0 near the range gate.  Used by tools/gen_golden.py to pick well-conditioned parity instances:
+    decisions taken on exact ties are not reproducible across BLAS builds even for the reference."""
+    T = hid.shape[0]
+    c = np.argmax(hid, axis=1)
+    top = hid[np.arange(T), c]
+    bad = np.zeros(T, bool)
+    masked = hid.copy()
+    for off in (-1, 0, 1):
+        idx = np.clip(c + off, 0, 359)
+        masked[np.arange(T), idx] = -1
+    bad |= masked.max(1) >= top * (1 - rel)
+    cm = np.pad(20 * np.arange(360) + CENTS_BASE, (4, 4))
+    salp = np.pad(hid, ((0, 0), (4, 4)))
+
+    def cents_at(center):
+        idx = center[:, None] + np.arange(9)[None, :]
+        w = np.take_along_axis(salp, idx, axis=1).astype(np.float64)
+        return (w * cm[idx]).sum(1) / w.sum(1)
+    base = cents_at(c)
+    for off in (-1, 1):
+        cc = np.clip(c + off, 0, 359)
+        near = hid[np.arange(T), cc] >= top * (1 - rel)
+        bad |= near & (np.abs(cents_at(cc) - base) > cents_tol)
+    voiced = top > thred
+    bad |= np.abs(top - thred) < thred * rel * 10
+    f0 = 10 * 2 ** (base / 1200)
+    bad |= voiced & ((np.abs(f0 - f0_min) < f0_min * 1e-4) | (np.abs(f0 - f0_max) < f0_max * 1e-4))
+    return np.where(bad)[0]

@@ -295,5 +295,85 @@ class Context:
         self._ck(lib().rvcx_op_bigru(self._h, _p(x), *[_p(t) for t in a], _p(y), B, T, I, H), "op_bigru")
         return y
 
+    def load_index(self, big_npy):
+        if big_npy is None:
+            self._ck(lib().rvcx_load_index(self._h, None, C.c_int64(0), 0), "load_index")
+            return
+        b = f32(big_npy)
+        self._ck(lib().rvcx_load_index(self._h, _p(b), C.c_int64(b.shape[0]), int(b.shape[1])), "load_index")
+
+    def index_blend(self, feats, index_rate):
+        f = f32(feats).copy()
+        T = f.shape[0]
+        ids = np.empty((T, 8), np.int64)
+        dist = np.empty((T, 8), np.float32)
+        self._ck(lib().rvcx_index_blend(self._h, _p(f), T, C.c_float(index_rate), _p(ids, C.c_int64), _p(dist)),
+                 "index_blend")
+        return f, ids, dist
+
+    def highpass(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._ck(lib().rvcx_op_highpass(self._h, _p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.shape[0])),
+                 "op_highpass")
+        return y
+
+    def get_f0(self, wav, params: "Params"):
+        wav = f32(wav)
+        n = wav.shape[0]
+        cap = (n + 2 * 16000 * params.x_pad) // 160 + 8
+        coarse = np.empty(cap, np.int32)
+        f0 = np.empty(cap, np.float32)
+        pl = C.c_int64(0)
+        self._ck(lib().rvcx_get_f0(self._h, _p(wav), C.c_int64(n), C.byref(params), _p(coarse, C.c_int32), _p(f0),
+                                   C.byref(pl)), "get_f0")
+        return coarse[:pl.value].copy(), f0[:pl.value].copy()
+
+    def out_capacity(self, model_id, n, params) -> int:
+        return int(lib().rvcx_out_len(self._h, model_id, C.c_int64(n), C.byref(params)))
+
+    def noise_capacity(self, model_id, n, params) -> int:
+        return int(lib().rvcx_noise_len(self._h, model_id, C.c_int64(n), C.byref(params)))
+
+    def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False):
+        """VC.pipeline for a list of 16 kHz mono float32 clips -> list of int16 arrays
+        (and the pre-quantisation float waveforms when want_f32)."""
+        B = len(wavs)
+        wavs = [f32(w) for w in wavs]
+        ns = (C.c_int64 * B)(*[w.shape[0] for w in wavs])
+        wp = (C.POINTER(C.c_float) * B)(*[_p(w) for w in wavs])
+        caps = [self.out_capacity(model_id, w.shape[0], params) for w in wavs]
+        outs = [np.empty(c, np.int16) for c in caps]
+        op = (C.POINTER(C.c_int16) * B)(*[_p(o, C.c_int16) for o in outs])
+        f32s, fp = None, None
+        if want_f32:
+            f32s = [np.empty(c, np.float32) for c in caps]
+            fp = (C.POINTER(C.c_float) * B)(*[_p(o) for o in f32s])
+        nz, npp = None, None
+        if noises is not None:
+            nz = []
+            for w, nv in zip(wavs, noises):
+                cap = self.noise_capacity(model_id, w.shape[0], params)
+                buf = np.zeros(cap, np.float32)
+                nv = f32(nv).ravel()
+                if nv.shape[0] > cap:
+                    raise RvcxError("noise longer than rvcx_noise_len")
+                buf[:nv.shape[0]] = nv
+                nz.append(buf)
+            npp = (C.POINTER(C.c_float) * B)(*[_p(b) for b in nz])
+        out_n = (C.c_int64 * B)()
+        self._ck(lib().rvcx_convert_batch(self._h, model_id, B, wp, ns, C.byref(params), npp, op, fp, out_n),
+                 "convert_batch")
+        pcm = [o[:out_n[i]].copy() for i, o in enumerate(outs)]
+        if want_f32:
+            return pcm, [o[:out_n[i]].copy() for i, o in enumerate(f32s)]
+        return pcm
+
+    def last_timing(self):
+        ms = (C.c_float * 9)()
+        lib().rvcx_last_timing(self._h, ms)
+        names = ["highpass", "rmvpe", "hubert", "index", "enc_p", "flow", "decoder", "post", "total"]
+        return dict(zip(names, [float(v) for v in ms]))
+
     def flop_counter(self, reset=False) -> float:
         return float(lib().rvcx_flop_counter(self._h, 1 if reset else 0))

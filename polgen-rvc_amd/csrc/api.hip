@@ -5,6 +5,7 @@
 #include "layers.h"
 #include "models.h"
 #include "ops.h"
+#include "pipeline.h"
 
 using namespace rvcx;
 
@@ -458,6 +459,128 @@ int rvcx_op_bigru(rvcx_ctx* ctx, const float* x, const float* w_ih, const float*
   API_END
 }
 
+int rvcx_load_index(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim) {
+  API_BEGIN(ctx)
+  if (!big_npy || n == 0) {
+    C->index.reset();
+  } else {
+    ensure_slab(*C);
+    C->index = index_load(*C, big_npy, n, dim);
+  }
+  API_END
+}
+
+int rvcx_index_blend(rvcx_ctx* ctx, float* feats, int T, float index_rate, int64_t* ids, float* dist) {
+  API_BEGIN(ctx)
+  if (!C->index) fail("index not loaded");
+  const int D = C->index->dim;
+  C->arena.reserve(index_arena_bytes(*C->index, T) + (size_t)T * (2 * D + 24) * 4 + (64 << 20));
+  C->arena.reset();
+  float* f = any_to_dev(*C, feats, (size_t)T * D);
+  float* fct = C->arena.alloc<float>((size_t)T * D);
+  launch_transpose(f, fct, 1, T, D, C->stream);
+  int64_t* dids = C->arena.alloc<int64_t>((size_t)T * 8);
+  float* ddist = C->arena.alloc<float>((size_t)T * 8);
+  index_blend(*C, *C->index, fct, T, index_rate, dids, ddist, C->stream);
+  launch_transpose(fct, f, 1, D, T, C->stream);
+  RVCX_HIP(hipMemcpyAsync(feats, f, (size_t)T * D * 4, hipMemcpyDefault, C->stream));
+  if (ids) RVCX_HIP(hipMemcpyAsync(ids, dids, (size_t)T * 8 * 8, hipMemcpyDefault, C->stream));
+  if (dist) RVCX_HIP(hipMemcpyAsync(dist, ddist, (size_t)T * 8 * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->arena.reset();
+  API_END
+}
+
+int64_t rvcx_out_len(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  if (!ctx || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
+  return out_capacity(*ctx->c.synths[model_id], n, *p);
+}
+
+int64_t rvcx_noise_len(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  if (!ctx || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
+  return noise_len_for(ctx->c, *ctx->c.synths[model_id], n, *p);
+}
+
+int rvcx_convert_batch(rvcx_ctx* ctx, int model_id, int B, const float* const* wav16k, const int64_t* n,
+                       const rvcx_params* p, const float* const* noise, int16_t* const* out, float* const* out_f32,
+                       int64_t* out_n) {
+  API_BEGIN(ctx)
+  SynthModel& M = get_synth(*C, model_id);
+  size_t need = 0;
+  for (int i = 0; i < B; ++i) {
+    size_t b = convert_arena_bytes(*C, model_id, n[i], *p) + (size_t)n[i] * 4;
+    if (noise && noise[i]) b += (size_t)noise_len_for(*C, M, n[i], *p) * 4;
+    need = std::max(need, b);
+  }
+  C->arena.reserve(need);
+  float tsum[9] = {0};
+  for (int i = 0; i < B; ++i) {
+    C->arena.reset();
+    const long cap = out_capacity(M, n[i], *p);
+    float* dw = any_to_dev(*C, wav16k[i], (size_t)n[i]);
+    const float* dn = nullptr;
+    if (noise && noise[i]) dn = any_to_dev(*C, noise[i], (size_t)noise_len_for(*C, M, n[i], *p));
+    short* dpcm = C->arena.alloc<short>((size_t)cap);
+    float* df32 = (out_f32 && out_f32[i]) ? C->arena.alloc<float>((size_t)cap) : nullptr;
+    float ms[9];
+    const long got = convert_one(*C, model_id, dw, n[i], *p, dn, dpcm, df32, ms);
+    for (int k = 0; k < 9; ++k) tsum[k] += ms[k];
+    RVCX_HIP(hipMemcpyAsync(out[i], dpcm, (size_t)got * sizeof(short), hipMemcpyDefault, C->stream));
+    if (df32) RVCX_HIP(hipMemcpyAsync(out_f32[i], df32, (size_t)got * sizeof(float), hipMemcpyDefault, C->stream));
+    RVCX_HIP(hipStreamSynchronize(C->stream));
+    if (out_n) out_n[i] = got;
+  }
+  for (int k = 0; k < 9; ++k) C->timing[k] = tsum[k];
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0,
+                int64_t* p_len) {
+  API_BEGIN(ctx)
+  if (!C->rmvpe) fail("rmvpe not loaded");
+  const long t_pad = 16000L * p->x_pad, n_pad = n + 2 * t_pad;
+  C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, 1, n_pad) + (size_t)n_pad * 48 + (64 << 20));
+  C->arena.reset();
+  float* dw = any_to_dev(*C, wav16k, (size_t)n);
+  double* ext = C->arena.alloc<double>((size_t)n + 64);
+  float* a32 = C->arena.alloc<float>((size_t)n);
+  launch_highpass(dw, nullptr, ext, nullptr, a32, n, C->stream);
+  float* apad = C->arena.alloc<float>((size_t)n_pad);
+  launch_reflect_pad(a32, apad, 1, (int)n, (int)t_pad, n_pad, C->stream);
+  const long pl = n_pad / 160;
+  int* dc = C->arena.alloc<int>((size_t)pl + 8);
+  float* df = C->arena.alloc<float>((size_t)pl + 8);
+  get_f0_device(*C, apad, n_pad, *p, dc, df);
+  RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)pl * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)pl * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  *p_len = pl;
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_last_timing(rvcx_ctx* ctx, float* ms9) {
+  if (!ctx) return -1;
+  for (int k = 0; k < 9; ++k) ms9[k] = ctx->c.timing[k];
+  return 0;
+}
+
+int rvcx_op_highpass(rvcx_ctx* ctx, const double* x, double* y, int64_t n) {
+  API_BEGIN(ctx)
+  C->arena.reserve((size_t)n * 32 + (64 << 20));
+  C->arena.reset();
+  double* dx = C->arena.alloc<double>((size_t)n);
+  RVCX_HIP(hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, C->stream));
+  double* ext = C->arena.alloc<double>((size_t)n + 64);
+  double* dy = C->arena.alloc<double>((size_t)n);
+  launch_highpass(nullptr, dx, ext, dy, nullptr, n, C->stream);
+  RVCX_HIP(hipMemcpyAsync(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->arena.reset();
+  API_END
+}
+
 // ------------------------------------------------------------------------------------------
 // entry points not implemented yet return an error (never a silent fallback)
 // ------------------------------------------------------------------------------------------
@@ -468,15 +591,6 @@ int rvcx_op_bigru(rvcx_ctx* ctx, const float* x, const float* w_ih, const float*
     return -1;                                  \
   } while (0)
 
-int rvcx_load_index(rvcx_ctx* c, const float*, int64_t, int) { NOT_IMPL(c, "rvcx_load_index"); }
 int rvcx_rmvpe_frames(int64_t n) { return (int)(1 + n / 160); }
-int rvcx_index_blend(rvcx_ctx* c, float*, int, float, int64_t*, float*) { NOT_IMPL(c, "rvcx_index_blend"); }
-int64_t rvcx_out_len(rvcx_ctx* c, int, int64_t, const rvcx_params*) { NOT_IMPL(c, "rvcx_out_len"); }
-int rvcx_convert_batch(rvcx_ctx* c, int, int, const float* const*, const int64_t*, const rvcx_params*,
-                       const float* const*, int16_t* const*, float* const*) { NOT_IMPL(c, "rvcx_convert_batch"); }
-int64_t rvcx_noise_len(rvcx_ctx* c, int, int64_t, const rvcx_params*) { NOT_IMPL(c, "rvcx_noise_len"); }
-int rvcx_get_f0(rvcx_ctx* c, const float*, int64_t, const rvcx_params*, int32_t*, float*, int64_t*) { NOT_IMPL(c, "rvcx_get_f0"); }
-int rvcx_last_timing(rvcx_ctx* c, float*) { NOT_IMPL(c, "rvcx_last_timing"); }
-int rvcx_op_highpass(rvcx_ctx* c, const double*, double*, int64_t) { NOT_IMPL(c, "rvcx_op_highpass"); }
 
 }  // extern "C"

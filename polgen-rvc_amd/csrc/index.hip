@@ -1,0 +1,186 @@
+// Retrieval blend of VC.vc (rvc/infer/pipeline.py:239-250): index.search(k=8) over the stored
+// feature matrix, weights (1/d)^2 normalised, weighted sum of the neighbours, lerp by index_rate.
+// faiss-cpu is not vendored in the reference; this implements exact squared-L2 search
+// (IndexFlatL2 semantics: d = |q|^2 + |b|^2 - 2 q.b with the dot products on the fp32 MFMA GEMM).
+#include "models.h"
+#include "ops.h"
+
+namespace rvcx {
+
+constexpr int TOPK = 8;
+
+std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim) {
+  auto ix = std::make_unique<IndexData>();
+  ix->n = n;
+  ix->dim = dim;
+  ix->mat = make_conv(c, big_npy, nullptr, (int)n, dim, 1, 1);
+  ix->rows = c.slab.upload(big_npy, (size_t)n * dim);
+  std::vector<float> norms((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    float s = 0.f;
+    for (int d = 0; d < dim; ++d) s += big_npy[i * dim + d] * big_npy[i * dim + d];
+    norms[(size_t)i] = s;
+  }
+  ix->norms = c.slab.upload(norms);
+  return ix;
+}
+
+constexpr int SPLITS = 32;
+
+size_t index_arena_bytes(const IndexData& ix, int T) {
+  return ((size_t)ix.n * T + (size_t)T * (SPLITS * TOPK * 2 + 64)) * sizeof(float) + (1 << 20);
+}
+
+namespace {
+
+__global__ void qnorm_kernel(const float* feats, float* qn, int dim, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float s = 0.f;
+  for (int d = 0; d < dim; ++d) {
+    const float v = feats[(long)d * T + t];
+    s += v * v;
+  }
+  qn[t] = s;
+}
+
+__device__ __forceinline__ void topk_insert(float (&bd)[TOPK], int (&bi)[TOPK], float d, int id) {
+  if (d >= bd[TOPK - 1]) return;
+  bd[TOPK - 1] = d;
+  bi[TOPK - 1] = id;
+#pragma unroll
+  for (int k = TOPK - 1; k > 0; --k) {
+    if (bd[k] < bd[k - 1]) {
+      const float td = bd[k];
+      bd[k] = bd[k - 1];
+      bd[k - 1] = td;
+      const int ti = bi[k];
+      bi[k] = bi[k - 1];
+      bi[k - 1] = ti;
+    }
+  }
+}
+
+// dots (N, T): block = 64 queries x 4 row slices, grid.y = row splits.  Partial top-8 per (split, query).
+__global__ __launch_bounds__(256) void topk_partial_kernel(const float* __restrict__ dots,
+                                                           const float* __restrict__ bn,
+                                                           const float* __restrict__ qn, float* pd, int* pi,
+                                                           long N, int T, int splits) {
+  __shared__ float sd[4][64][TOPK];
+  __shared__ int si[4][64][TOPK];
+  const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
+  const long rows_per = (N + splits - 1) / splits;
+  const long r0 = blockIdx.y * rows_per, r1 = min(N, r0 + rows_per);
+  float bd[TOPK];
+  int bi[TOPK];
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) {
+    bd[k] = INFINITY;
+    bi[k] = -1;
+  }
+  if (t < T) {
+    const float q = qn[t];
+    for (long r = r0 + part; r < r1; r += 4) {
+      float d = q + bn[r] - 2.f * dots[r * T + t];
+      d = fmaxf(d, 0.f);
+      topk_insert(bd, bi, d, (int)r);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) {
+    sd[part][tx][k] = bd[k];
+    si[part][tx][k] = bi[k];
+  }
+  __syncthreads();
+  if (part == 0 && t < T) {
+    for (int p = 1; p < 4; ++p)
+#pragma unroll
+      for (int k = 0; k < TOPK; ++k) topk_insert(bd, bi, sd[p][tx][k], si[p][tx][k]);
+    for (int k = 0; k < TOPK; ++k) {
+      pd[((long)blockIdx.y * T + t) * TOPK + k] = bd[k];
+      pi[((long)blockIdx.y * T + t) * TOPK + k] = bi[k];
+    }
+  }
+}
+
+// merge the per-split candidates, then blend: one block per query
+__global__ __launch_bounds__(256) void merge_blend_kernel(const float* pd, const int* pi, int splits,
+                                                          const float* __restrict__ rows, float* feats, int dim,
+                                                          int T, float rate, float one_minus, long long* ids_out,
+                                                          float* dist_out) {
+  __shared__ float fd[TOPK];
+  __shared__ int fi[TOPK];
+  __shared__ float fw[TOPK];
+  const int t = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float bd[TOPK];
+    int bi[TOPK];
+    for (int k = 0; k < TOPK; ++k) {
+      bd[k] = INFINITY;
+      bi[k] = -1;
+    }
+    for (int s = 0; s < splits; ++s)
+      for (int k = 0; k < TOPK; ++k) {
+        const float d = pd[((long)s * T + t) * TOPK + k];
+        const int id = pi[((long)s * T + t) * TOPK + k];
+        if (id < 0) continue;
+        // stable w.r.t. row id on exact ties (smaller id first), like a sequential scan
+        if (d < bd[TOPK - 1] || (d == bd[TOPK - 1] && id < bi[TOPK - 1])) {
+          int pos = TOPK - 1;
+          while (pos > 0 && (d < bd[pos - 1] || (d == bd[pos - 1] && id < bi[pos - 1]))) {
+            bd[pos] = bd[pos - 1];
+            bi[pos] = bi[pos - 1];
+            --pos;
+          }
+          bd[pos] = d;
+          bi[pos] = id;
+        }
+      }
+    float w[TOPK];
+    for (int k = 0; k < TOPK; ++k) {
+      const float inv = 1.f / bd[k];
+      w[k] = inv * inv;                                  // np.square(1 / score)
+    }
+    const float ws = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));  // numpy pairwise
+    for (int k = 0; k < TOPK; ++k) {
+      fd[k] = bd[k];
+      fi[k] = bi[k];
+      fw[k] = w[k] / ws;
+      if (ids_out) ids_out[(long)t * TOPK + k] = bi[k];
+      if (dist_out) dist_out[(long)t * TOPK + k] = bd[k];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < dim; c += 256) {
+    float acc = rows[(long)fi[0] * dim + c] * fw[0];
+#pragma unroll
+    for (int k = 1; k < TOPK; ++k) acc = acc + rows[(long)fi[k] * dim + c] * fw[k];
+    const long o = (long)c * T + t;
+    feats[o] = acc * rate + one_minus * feats[o];
+  }
+}
+
+}  // namespace
+
+void index_blend(Ctx& c, const IndexData& ix, float* feats_ct, int T, float index_rate, int64_t* ids, float* dist,
+                 hipStream_t s) {
+  RVCX_CHECK(ix.n >= TOPK, "index: fewer than 8 stored vectors");
+  Arena& A = c.arena;
+  float* dots = A.alloc<float>((size_t)ix.n * T);
+  {
+    ConvArgs a = conv1d_args(ix.mat, feats_ct, dots, 1, T, T);
+    c.conv_on(a, s);
+  }
+  float* qn = A.alloc<float>((size_t)T);
+  hipLaunchKernelGGL(qnorm_kernel, dim3(cdiv(T, 256)), dim3(256), 0, s, feats_ct, qn, ix.dim, T);
+  float* pd = A.alloc<float>((size_t)SPLITS * T * TOPK);
+  int* pi = A.alloc<int>((size_t)SPLITS * T * TOPK);
+  hipLaunchKernelGGL(topk_partial_kernel, dim3(cdiv(T, 64), SPLITS), dim3(256), 0, s, dots, ix.norms, qn, pd, pi,
+                     (long)ix.n, T, SPLITS);
+  hipLaunchKernelGGL(merge_blend_kernel, dim3(T), dim3(256), 0, s, pd, pi, SPLITS, ix.rows, feats_ct, ix.dim, T,
+                     index_rate, (float)(1.0 - (double)index_rate), reinterpret_cast<long long*>(ids), dist);
+  RVCX_HIP(hipGetLastError());
+}
+
+}  // namespace rvcx

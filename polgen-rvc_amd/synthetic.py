@@ -217,11 +217,12 @@ def rmvpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
         T.normal(f"fc.0.gru.weight_hh_l0{sfx}", (3 * H, H), 1.0 / math.sqrt(H))
         T.normal(f"fc.0.gru.bias_ih_l0{sfx}", (3 * H,), 0.05)
         T.normal(f"fc.0.gru.bias_hh_l0{sfx}", (3 * H,), 0.05)
-    # smooth across the 360 pitch bins so the salience has a few broad peaks (like a
-    # trained model) instead of 360 i.i.d. values whose argmax is rounding-sensitive
+    # smooth across the 360 pitch bins (correlation ~1.6 bins, like the label blur of a trained
+    # model): peaks are narrower than the +-4-bin averaging window of to_local_average_cents, so an
+    # argmax flip between adjacent bins barely moves the decoded f0
     w = _normal("fc.1.weight", (360, 2 * H), 1.0, seed + 17)
-    T.t["fc.1.weight"] = (_smooth_axis0(w, 9.0) * np.float32(4.0 / math.sqrt(2 * H))).astype(np.float32)
-    T.t["fc.1.bias"] = _smooth_axis0(_normal("fc.1.bias", (360,), 1.0, seed + 17), 9.0) * np.float32(0.3) - np.float32(8.0 if c0 >= 16 else 10.3)
+    T.t["fc.1.weight"] = (_smooth_axis0(w, 1.6) * np.float32(4.0 / math.sqrt(2 * H))).astype(np.float32)
+    T.t["fc.1.bias"] = _smooth_axis0(_normal("fc.1.bias", (360,), 1.0, seed + 17), 9.0) * np.float32(0.3) - np.float32(10.5 if c0 >= 16 else 11.5)
     return T.t
 
 

@@ -175,11 +175,30 @@ def gold_synth(tag, cfg, T, seed):
                         z_p=z_p.numpy(), z=z.numpy(), audio=o.numpy())
 
 
+def stable_seed(rcfg, audio_pad_f32, seed, f0_min=50, f0_max=1100, pitch=0.0):
+    """First seed >= `seed` (step 100) for which every frame's f0 decision is well-conditioned."""
+    for k in range(40):
+        sd_ = S.to_torch(S.rmvpe_state(rcfg, seed + 100 * k))
+        f0_, hid_, _ = O_rmvpe.infer_f0(sd_, rcfg, audio_pad_f32, 0.03, f0_min, f0_max, return_hidden=True)
+        bad = O_rmvpe.unstable_frames(hid_, 0.03, f0_min, f0_max)
+        # coarse quantisation ties (np.rint at .5)
+        f0m = 1127 * np.log(1 + f0_ * 2 ** (pitch / 12) / 700)
+        m0, m1 = 1127 * np.log(1 + f0_min / 700), 1127 * np.log(1 + f0_max / 700)
+        q = (f0m - m0) * 254 / (m1 - m0) + 1
+        tie = (f0_ > 0) & (np.abs(q - np.floor(q) - 0.5) < 1e-3)
+        vf = (f0_ > 0).mean()
+        print(f"  seed {seed + 100 * k}: unstable frames {len(bad)}, coarse ties {int(tie.sum())}, voiced {vf:.2f}")
+        if len(bad) == 0 and not tie.any() and 0.15 < vf < 0.995:
+            return seed + 100 * k
+    raise RuntimeError("no stable seed found")
+
+
 def gold_rmvpe(tag, cfg, seconds, seed, stride=1):
     print(f"[rmvpe {tag}] {seconds}s")
+    audio = S.make_clip(7 + seed, seconds).astype(np.float64)
+    seed = stable_seed(cfg, audio.astype(np.float32), seed)
     sd = S.to_torch(S.rmvpe_state(cfg, seed))
     pred = ref_rmvpe(cfg, sd)
-    audio = S.make_clip(7 + seed, seconds).astype(np.float64)
     a = torch.from_numpy(audio).float().unsqueeze(0)
     mel = pred.mel_extractor(a, center=True)
     hid = pred.mel2hidden(mel).squeeze(0).numpy()
@@ -246,6 +265,9 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
                   full_store=True):
     hcfg, rcfg, scfg = cfgs
     print(f"[pipeline {tag}] {seconds}s geo={geo} pitch={pitch} env={volume_envelope}")
+    a_ = O_pipe.highpass(S.make_clip(clip, seconds).astype(np.float64))
+    a_ = np.pad(a_, (16000 * geo[0], 16000 * geo[0]), mode="reflect").astype(np.float32)
+    seed = stable_seed(rcfg, a_, seed, f0_min, f0_max, pitch)
     hsd, rsd, ssd = (S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.rmvpe_state(rcfg, seed)),
                      S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])))
     tgt_sr = scfg[-1]
