@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- real-time factor of the rvc/infer hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+Workload (BASELINE.json configs[1]): one 30 s 16 kHz mono clip per step per GPU, RVC v2 48 kHz voice
+model, rmvpe+ F0, contentvec-shaped HuBERT-base, index_rate 0, fp32, chunk geometry (1,6,38,41);
+synthetic clip + synthetic weights in the real checkpoint layouts (no real weights exist offline).
+A step = VC.pipeline on one clip with the PCM already resident in HBM (device in, device int16 out).
+Weak scaling: every rank converts its own clip per step; value = all ranks' audio seconds / max-rank wall.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import polgen_rvc_amd  # noqa: E402
+from polgen_rvc_amd import _lib, dist as D, synthetic as S, weights as W  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
+CLIP_SECONDS = 30.0
+CPU_SAMPLE_SECONDS = 8.0
+
+
+def load_models(ctx, zero=False):
+    def z(state):
+        return {k: np.zeros_like(v) for k, v in state.items()} if zero else state
+    ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0)))
+    ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, 0)))
+    return ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, 0)))
+
+
+def make_params(seed=0):
+    p = _lib.Params()
+    p.pitch, p.f0_min, p.f0_max = 0.0, 50.0, 1100.0
+    p.index_rate, p.protect, p.volume_envelope = 0.0, 0.33, 1.0
+    p.sid = 0
+    p.x_pad, p.x_query, p.x_center, p.x_max = 1, 6, 38, 41
+    p.seed = seed
+    return p
+
+
+def cpu_baseline():
+    """The CPU oracle (oracle/pipeline.py, the pinned restatement of the reference path) timed on the host
+    cores on a bounded sample of the same workload.  Reported beside the GPU number; never the product."""
+    from oracle import pipeline as OP
+    models = OP.Models(S.to_torch(S.hubert_state(S.HUBERT_CFG_BASE, 0)), S.HUBERT_CFG_BASE,
+                       S.to_torch(S.rmvpe_state(S.RMVPE_CFG_FULL, 0)), S.RMVPE_CFG_FULL,
+                       S.to_torch(S.synth_state(S.SYNTH_CFG_48K, 0)), S.SYNTH_CFG_48K)
+    audio = S.make_clip(0, CPU_SAMPLE_SECONDS)
+    geo = OP.Geometry(48000, 1, 6, 38, 41)
+    t0 = time.perf_counter()
+    OP.pipeline(models, geo, audio, 0.0, 0, None, 0.0, 1.0, 0.33, 50, 1100, seed=0)
+    dt = time.perf_counter() - t0
+    return {"value": CPU_SAMPLE_SECONDS / dt, "unit": "x real-time", "cores": torch.get_num_threads(),
+            "kind": "port", "seconds": dt,
+            "sample": f"one {CPU_SAMPLE_SECONDS:.0f} s clip of the same workload (oracle/pipeline.py, torch-CPU fp32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-out", default="")
+    a = ap.parse_args()
+
+    rank, local, world = D.init("nccl")
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ctx = _lib.Context(local)
+
+    # rank 0 parses/folds/packs the checkpoints; the folded slab goes to the other GPUs over RCCL/xGMI
+    t0 = time.perf_counter()
+    mid = load_models(ctx, zero=(rank != 0))
+    t_load = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nbytes = D.broadcast_weights(ctx, local, 0)
+    t_bcast = time.perf_counter() - t0
+
+    params = make_params()
+    clip = S.make_clip(rank, CLIP_SECONDS)
+    n = clip.shape[0]
+    wav = torch.from_numpy(clip).to(dev)
+    cap = ctx.out_capacity(mid, n, params)
+    out = torch.empty(cap, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return ctx.convert_batch_raw(mid, [wav.data_ptr()], [n], params, [out.data_ptr()])[0]
+
+    for _ in range(a.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    ms_per_step = dt / a.steps * 1e3
+    rtf = world * a.steps * CLIP_SECONDS / dt
+
+    # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv): one extra, untimed step with a
+    # HIP event pair around every conv launch on the library's stream
+    stage = ctx.last_timing()
+    ctx.flop_counter(reset=True)
+    ctx.conv_profile_begin()
+    step()
+    prof = ctx.conv_profile_end()
+    total_flops = ctx.flop_counter()
+    prof.sort(key=lambda r: -r["ms"])
+    dom = prof[0]
+    conv_ms = sum(r["ms"] for r in prof)
+    conv_flops = sum(r["flops"] for r in prof)
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": f"conv_mfma_kernel<{dom['tile']}>", "achieved": achieved,
+                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                "flops_per_launch": dom["flops"] / dom["launches"],
+                "family": {"ms": conv_ms, "tflops": conv_flops / (conv_ms * 1e-3) / 1e12,
+                           "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                           "share_of_step": conv_ms / ms_per_step},
+                "whole_path_tflops": total_flops / (ms_per_step * 1e-3) / 1e12}
+
+    if rank == 0:
+        res = {"metric": "real-time-factor (audio-sec/wall-sec) per GPU, 30s@16kHz RMVPE->48kHz",
+               "value": rtf, "unit": "x real-time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "single 30 s 16 kHz clip per GPU per step, RVC v2 48k, f0_method=rmvpe+, "
+                                      "HuBERT-base, index_rate=0, geometry (1,6,38,41), PCM resident in HBM",
+                          "out_samples": got, "weights_bcast_bytes": nbytes, "weights_bcast_s": t_bcast,
+                          "load_s": t_load},
+               "stage_ms": stage, "roofline": roofline, "conv_tiles": prof}
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        else:
+            res["cpu_baseline"] = None
+        if a.profile_out:
+            with open(a.profile_out, "w") as f:
+                json.dump(res, f, indent=1)
+        print(json.dumps(res))
+    ctx.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,12 @@ int rvcx_get_f0(rvcx_ctx*, const float* wav16k_hd, int64_t n, const rvcx_params*
 /* per-stage GPU milliseconds (HIP events on the library's stream) of the last
  * rvcx_convert_batch: {highpass, rmvpe, hubert, index, enc_p, flow, decoder, post, total} */
 int rvcx_last_timing(rvcx_ctx*, float* ms9);
+/* HIP-event profile of the MFMA conv kernel family: begin=1 starts recording an event pair around
+ * every conv launch on the library stream; begin=0 stops and returns, per tile configuration
+ * (<= 8 entries), the launch count, algorithmic FLOPs (2*M*N*K of the unpadded problem) and the
+ * summed kernel milliseconds, plus the tile shape (bm x bn). */
+int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
+                      int32_t* bn, int cap);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */
 double rvcx_flop_counter(rvcx_ctx*, int reset);
 void* rvcx_stream(rvcx_ctx*); /* hipStream_t the library launches on */

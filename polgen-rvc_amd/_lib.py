@@ -62,7 +62,7 @@ SYMBOLS = [
     "rvcx_weights_blob", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_noise_len", "rvcx_get_f0", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -368,6 +368,36 @@ class Context:
         if want_f32:
             return pcm, [o[:out_n[i]].copy() for i, o in enumerate(f32s)]
         return pcm
+
+    def convert_batch_raw(self, model_id, wav_ptrs, ns, params, out_ptrs, f32_ptrs=None, noise_ptrs=None):
+        """Same as convert_batch but with raw (host or device) addresses: nothing is staged through numpy.
+        Returns the list of produced sample counts."""
+        B = len(wav_ptrs)
+        wp = (C.c_void_p * B)(*wav_ptrs)
+        op = (C.c_void_p * B)(*out_ptrs)
+        fp = None if f32_ptrs is None else (C.c_void_p * B)(*f32_ptrs)
+        npp = None if noise_ptrs is None else (C.c_void_p * B)(*noise_ptrs)
+        nn = (C.c_int64 * B)(*ns)
+        out_n = (C.c_int64 * B)()
+        self._ck(lib().rvcx_convert_batch(self._h, model_id, B, wp, nn, C.byref(params), npp, op, fp, out_n),
+                 "convert_batch")
+        return [int(v) for v in out_n]
+
+    def weights_blob(self):
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._ck(lib().rvcx_weights_blob(self._h, C.byref(ptr), C.byref(n)), "weights_blob")
+        return ptr.value, n.value
+
+    def conv_profile_begin(self):
+        z = (C.c_int64 * 8)()
+        self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, 0), "conv_profile")
+
+    def conv_profile_end(self):
+        la, fl, ms = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+        bm, bn = (C.c_int32 * 8)(), (C.c_int32 * 8)()
+        self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, 8), "conv_profile")
+        return [dict(tile=f"{bm[i]}x{bn[i]}", launches=int(la[i]), flops=float(fl[i]), ms=float(ms[i]))
+                for i in range(8) if la[i] > 0]
 
     def last_timing(self):
         ms = (C.c_float * 9)()

@@ -560,6 +560,25 @@ int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params
   API_END
 }
 
+int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
+                      int32_t* bn, int cap) {
+  API_BEGIN(ctx)
+  if (begin) {
+    conv_profile_begin();
+  } else {
+    ConvProfile p;
+    conv_profile_end(&p);
+    for (int t = 0; t < cap && t < ConvProfile::kMaxTiles; ++t) {
+      launches[t] = p.launches[t];
+      flops[t] = p.flops[t];
+      ms[t] = p.ms[t];
+      bm[t] = p.bm[t];
+      bn[t] = p.bn[t];
+    }
+  }
+  API_END
+}
+
 int rvcx_last_timing(rvcx_ctx* ctx, float* ms9) {
   if (!ctx) return -1;
   for (int k = 0; k < 9; ++k) ms9[k] = ctx->c.timing[k];

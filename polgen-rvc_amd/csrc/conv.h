@@ -55,6 +55,15 @@ inline int conv_tap_off(const ConvArgs& a, int kk) {
   return (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad;
 }
 
+struct ConvProfile {
+  static constexpr int kMaxTiles = 8;
+  long launches[kMaxTiles] = {0};
+  double flops[kMaxTiles] = {0};
+  double ms[kMaxTiles] = {0};
+  int bm[kMaxTiles] = {0}, bn[kMaxTiles] = {0};
+};
+void conv_profile_begin();                          // start recording one event pair per conv launch
+void conv_profile_end(ConvProfile* out);            // sync, accumulate, stop
 void conv_init();                                   // raise dynamic-LDS limits once
 void launch_conv(ConvArgs a, hipStream_t stream);   // picks tile + LDS chunking, launches
 double conv_flops(const ConvArgs& a);               // 2*M*N*K of the *real* (unpadded) problem

@@ -222,6 +222,40 @@ static bool plan_lds(ConvArgs& a, int bm, int bn) {
   return true;
 }
 
+namespace {
+struct ProfRec {
+  hipEvent_t a, b;
+  int tile;
+  double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+void conv_profile_begin() {
+  g_prof.clear();
+  g_prof_on = true;
+}
+
+void conv_profile_end(ConvProfile* out) {
+  g_prof_on = false;
+  for (int t = 0; t < kNumTiles; ++t) {
+    out->bm[t] = kTiles[t].bm;
+    out->bn[t] = kTiles[t].bn;
+  }
+  for (auto& r : g_prof) {
+    RVCX_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    RVCX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    out->launches[r.tile] += 1;
+    out->flops[r.tile] += r.flops;
+    out->ms[r.tile] += ms;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+}
+
 void launch_conv(ConvArgs a, hipStream_t stream) {
   RVCX_CHECK(a.Cin_gp % 2 == 0 && a.Cout_gp % 32 == 0, "conv: unpadded weights");
   RVCX_CHECK(a.Nout > 0 && a.B > 0, "conv: empty problem");
@@ -245,7 +279,19 @@ void launch_conv(ConvArgs a, hipStream_t stream) {
   const TileCfg& T = kTiles[best];
   dim3 grid(cdiv(a.Nout, T.bn), cdiv(a.Cout_gp, T.bm) * a.groups, a.B);
   size_t lds = (size_t)(best_a.kk_chunk * best_a.ci_chunk * T.bm + best_a.ci_chunk * best_a.wrow) * sizeof(float);
+  ProfRec rec;
+  if (g_prof_on) {
+    RVCX_HIP(hipEventCreate(&rec.a));
+    RVCX_HIP(hipEventCreate(&rec.b));
+    rec.tile = best;
+    rec.flops = conv_flops(a);
+    RVCX_HIP(hipEventRecord(rec.a, stream));
+  }
   hipLaunchKernelGGL(T.kern, grid, dim3(256), lds, stream, best_a);
+  if (g_prof_on) {
+    RVCX_HIP(hipEventRecord(rec.b, stream));
+    g_prof.push_back(rec);
+  }
   RVCX_HIP(hipGetLastError());
 }
 

@@ -27,7 +27,7 @@ struct SynthModel {
   Flow flows[4];
   // GeneratorNSF (rvc/lib/algorithm/nsf.py:43-144)
   ConvW conv_pre, cond, conv_post;
-  float lin_w = 1.f, lin_b = 0.f;
+  const float* lin_wb = nullptr;   // device {weight, bias} of m_source.l_linear (1 -> 1)
   struct Stage {
     ConvT1dW up;
     ConvW noise;
@@ -63,7 +63,7 @@ struct RmvpeModel {
   rvcx_rmvpe_cfg cfg{};
   ConvW stft;        // (1026, 1, 1024) Hann-windowed Fourier basis, stride 160
   ConvW melfb;       // (128, 513) as a 1x1 conv
-  float bn0_scale = 1.f, bn0_shift = 0.f;
+  const float* bn0 = nullptr;      // device {scale, shift} of the folded encoder.bn
   struct Block {
     ConvW c1, c2, sc;   // 3x3 + folded BN (x2), optional 1x1 shortcut
     bool has_sc = false;

@@ -48,7 +48,7 @@ void launch_mask(float* x, int B, int C, int T, const int* lens, hipStream_t s);
 void launch_add_channel_bias(float* x, const float* g, int B, int C, int T, hipStream_t s);
 // NSF harmonic source: f0 (B,T) -> har (B,T*upp) = tanh(w*(sine*uv + namp*noise) + b)  [generators.py:117-156, nsf.py:36-40]
 void launch_sine_source(const float* f0, const float* noise, float* har, int B, int T, int upp, float sr,
-                        float lin_w, float lin_b, const int* lens, double* scratch, hipStream_t s);
+                        const float* lin_wb, const int* lens, double* scratch, hipStream_t s);
 // standard normal noise, Philox4x32-10 + Box-Muller
 void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 // tanh(conv_post) is done in the conv epilogue; final leaky_relu(0.01) is its prologue.
@@ -59,7 +59,7 @@ void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs
 // |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F)
 void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s);
 // log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp
-void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, float bn_scale, float bn_shift,
+void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, const float* bn,
                      hipStream_t s);
 // 2x2 average pool on row-padded maps: (B*C, H, Wp) -> (B*C, H/2, W/2+2)
 void launch_avgpool2(const float* x, float* y, int planes, int H, int Wp, long x_ps, long y_ps, hipStream_t s);

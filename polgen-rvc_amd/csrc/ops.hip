@@ -271,9 +271,10 @@ __global__ void sine_prefix_kernel(const float* f0, double* P, float* rad_out, i
 }
 
 __global__ void sine_source_kernel(const float* f0, const double* P, const float* rad, const float* noise,
-                                   float* har, int T, int upp, float lin_w, float lin_b, const int* lens,
+                                   float* har, int T, int upp, const float* lin_wb, const int* lens,
                                    long total) {
   const long per = (long)T * upp;
+  const float lin_w = lin_wb[0], lin_b = lin_wb[1];
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long b = idx / per;
     const long j = idx - b * per;
@@ -292,12 +293,12 @@ __global__ void sine_source_kernel(const float* f0, const double* P, const float
 }
 
 void launch_sine_source(const float* f0, const float* noise, float* har, int B, int T, int upp, float sr,
-                        float lin_w, float lin_b, const int* lens, double* scratch, hipStream_t s) {
+                        const float* lin_wb, const int* lens, double* scratch, hipStream_t s) {
   double* P = scratch;
   float* rad = reinterpret_cast<float*>(scratch + (size_t)B * T);
   hipLaunchKernelGGL(sine_prefix_kernel, dim3(B), dim3(64), 0, s, f0, P, rad, T, upp, sr);
   long n = (long)B * T * upp;
-  hipLaunchKernelGGL(sine_source_kernel, EW_GRID(n), 0, s, f0, P, rad, noise, har, T, upp, lin_w, lin_b, lens, n);
+  hipLaunchKernelGGL(sine_source_kernel, EW_GRID(n), 0, s, f0, P, rad, noise, har, T, upp, lin_wb, lens, n);
 }
 
 // ------------------------------------------------------------------ Philox4x32-10 normal noise
@@ -365,9 +366,10 @@ void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStre
   hipLaunchKernelGGL(magnitude_kernel, EW_GRID(tot), 0, s, ft, mag, nb, F, tot);
 }
 
-__global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, int Tp, float sc, float sh,
+__global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, int Tp, const float* bn,
                                 long total) {
   const int Wp = nmel + 2;
+  const float sc = bn[0], sh = bn[1];
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int col = idx % Wp;
     const long bt = idx / Wp;
@@ -382,10 +384,10 @@ __global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, i
     out[idx] = v;
   }
 }
-void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, float bn_scale, float bn_shift,
+void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, const float* bn,
                      hipStream_t s) {
   long tot = (long)B * Tp * (nmel + 2);
-  hipLaunchKernelGGL(mel_post_kernel, EW_GRID(tot), 0, s, mel, out, nmel, F, Tp, bn_scale, bn_shift, tot);
+  hipLaunchKernelGGL(mel_post_kernel, EW_GRID(tot), 0, s, mel, out, nmel, F, Tp, bn, tot);
 }
 
 __global__ void avgpool2_kernel(const float* x, float* y, int H, int Wp, long x_ps, long y_ps, long total) {

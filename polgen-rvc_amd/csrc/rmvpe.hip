@@ -115,8 +115,8 @@ std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const 
   }
   {
     BnFold f = bn_fold(t, "unet.encoder.bn");
-    M->bn0_scale = f.scale[0];
-    M->bn0_shift = f.shift[0];
+    std::vector<float> ss = {f.scale[0], f.shift[0]};
+    M->bn0 = c.slab.upload(ss);
   }
   for (int l = 0; l < cfg.en_de_layers; ++l) {
     std::vector<RmvpeModel::Block> blocks;
@@ -277,7 +277,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   float* w2 = A.alloc<float>(big);
   float* w3 = A.alloc<float>(big);
   Map2 x{w0, (long)Hs[0] * Ws[0], 1, Hs[0], Ws[0]};
-  launch_mel_post(mel, x.p, B, N_MELS, F, Tp, m.bn0_scale, m.bn0_shift, s);
+  launch_mel_post(mel, x.p, B, N_MELS, F, Tp, m.bn0, s);
   for (int l = 0; l < nenc; ++l) {
     const int nblk = (int)m.enc[l].size();
     for (int b = 0; b < nblk; ++b) {

@@ -104,8 +104,8 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
   {
     auto lw = t.f32("dec.m_source.l_linear.weight");
     auto lb = t.f32("dec.m_source.l_linear.bias");
-    M->lin_w = lw[0];
-    M->lin_b = lb[0];
+    std::vector<float> wb = {lw[0], lb[0]};
+    M->lin_wb = c.slab.upload(wb);
   }
   M->conv_pre = load_conv(c, t, "dec.conv_pre");
   M->cond = load_conv(c, t, "dec.cond");
@@ -306,7 +306,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
   float* har = A.alloc<float>((size_t)B * Tupp);
   {
     double* sc = A.alloc<double>((size_t)B * T * 2);
-    launch_sine_source(io.pitchf, io.src_noise, har, B, T, m.upp, (float)cf.sr, m.lin_w, m.lin_b, lens, sc, s);
+    launch_sine_source(io.pitchf, io.src_noise, har, B, T, m.upp, (float)cf.sr, m.lin_wb, lens, sc, s);
   }
   const int C0 = cf.up_initial_channel;
   float* cur = A.alloc<float>((size_t)B * C0 * T);
