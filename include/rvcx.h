@@ -157,6 +157,10 @@ int rvcx_op_conv1d(rvcx_ctx*, const float* x, const float* w, const float* bias,
                    float* y, int B, int Cin, int Tin, int Cout, int K, int stride, int dil,
                    int pad_left, int Tout, int groups, int pre_lrelu, float pre_slope, int act,
                    float act_slope, const int32_t* lens_in, const int32_t* lens_out);
+/* micro-benchmark of the conv kernel on device-resident random data: `iters` back-to-back launches of
+ * y = conv1d(lrelu(x)) + bias + res, average milliseconds per launch (HIP events on the library stream) */
+int rvcx_bench_conv1d(rvcx_ctx*, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
+                      int iters, float* ms_per_launch);
 /* ConvTranspose1d: w (Cin,Cout,K), padding p; Tout = (Tin-1)*s - 2p + K */
 int rvcx_op_convtranspose1d(rvcx_ctx*, const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int Tin, int Cout, int K, int stride, int pad,

@@ -62,7 +62,7 @@ SYMBOLS = [
     "rvcx_weights_blob", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_noise_len", "rvcx_get_f0", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -169,6 +169,15 @@ class Context:
                                       C.c_float(0.0 if pre_lrelu is None else pre_lrelu), act,
                                       C.c_float(act_slope), _p(li, C.c_int32), _p(lo, C.c_int32)), "op_conv1d")
         return y
+
+    def bench_conv1d(self, B, Cin, Tin, Cout, K, stride=1, dil=1, groups=1, iters=10):
+        ms = C.c_float(0)
+        self._ck(lib().rvcx_bench_conv1d(self._h, B, Cin, Tin, Cout, K, stride, dil, groups, iters, C.byref(ms)),
+                 "bench_conv1d")
+        pad = (K * dil - dil) // 2
+        Tout = (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        flops = 2.0 * B * Cout * Tout * K * (Cin // groups)
+        return ms.value, flops / (ms.value * 1e-3) / 1e12
 
     def convtranspose1d(self, x, w, bias=None, stride=1, pad=0, pre_lrelu=None):
         x, w = f32(x), f32(w)

@@ -137,6 +137,44 @@ int rvcx_op_conv1d(rvcx_ctx* ctx, const float* x, const float* w, const float* b
   API_END
 }
 
+int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
+                      int iters, float* ms_per_launch) {
+  API_BEGIN(ctx)
+  ensure_slab(*C);
+  const int pad = (K * dil - dil) / 2;
+  const int Tout = (Tin + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tout;
+  C->arena.reserve((nx + 2 * ny) * 4 + (64 << 20));
+  C->arena.reset();
+  std::vector<float> w((size_t)Cout * (Cin / groups) * K), bias((size_t)Cout, 0.1f);
+  for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+  ConvW L = make_conv(*C, w.data(), bias.data(), Cout, Cin / groups, K, groups);
+  float* dx = C->arena.alloc<float>(nx);
+  float* dy = C->arena.alloc<float>(ny);
+  float* dr = C->arena.alloc<float>(ny);
+  launch_randn(dx, nx, 1, 0, C->stream);
+  launch_randn(dr, ny, 2, 0, C->stream);
+  ConvArgs a = conv1d_args(L, dx, dy, B, Tin, Tout, stride, dil, pad);
+  conv_set_res(a, dr, Cout, Tout);
+  a.pre_act = ACT_LRELU;
+  a.pre_slope = 0.1f;
+  C->conv(a);
+  hipEvent_t e0, e1;
+  RVCX_HIP(hipEventCreate(&e0));
+  RVCX_HIP(hipEventCreate(&e1));
+  RVCX_HIP(hipEventRecord(e0, C->stream));
+  for (int i = 0; i < iters; ++i) C->conv(a);
+  RVCX_HIP(hipEventRecord(e1, C->stream));
+  RVCX_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RVCX_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_op_convtranspose1d(rvcx_ctx* ctx, const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int Tin, int Cout, int K, int stride, int pad,
                             int pre_lrelu, float pre_slope) {
@@ -543,7 +581,7 @@ int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params
   C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, 1, n_pad) + (size_t)n_pad * 48 + (64 << 20));
   C->arena.reset();
   float* dw = any_to_dev(*C, wav16k, (size_t)n);
-  double* ext = C->arena.alloc<double>((size_t)n + 64);
+  double* ext = C->arena.alloc<double>(highpass_ext_doubles(n));
   float* a32 = C->arena.alloc<float>((size_t)n);
   launch_highpass(dw, nullptr, ext, nullptr, a32, n, C->stream);
   float* apad = C->arena.alloc<float>((size_t)n_pad);
@@ -591,7 +629,7 @@ int rvcx_op_highpass(rvcx_ctx* ctx, const double* x, double* y, int64_t n) {
   C->arena.reset();
   double* dx = C->arena.alloc<double>((size_t)n);
   RVCX_HIP(hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, C->stream));
-  double* ext = C->arena.alloc<double>((size_t)n + 64);
+  double* ext = C->arena.alloc<double>(highpass_ext_doubles(n));
   double* dy = C->arena.alloc<double>((size_t)n);
   launch_highpass(nullptr, dx, ext, dy, nullptr, n, C->stream);
   RVCX_HIP(hipMemcpyAsync(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost, C->stream));

@@ -17,6 +17,7 @@ std::vector<Chunk> plan_chunks(long n, const std::vector<long>& opt_ts, const Ge
 long out_capacity(const SynthModel& m, long n, const rvcx_params& p);
 long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params& p);
 
+size_t highpass_ext_doubles(long n);   // scratch the caller provides as `ext`
 void launch_highpass(const float* x32, const double* x64, double* ext, double* y64, float* y32, long n,
                      hipStream_t s);
 

@@ -1,0 +1,105 @@
+"""CPU: the oracle (oracle/*.py) against the vectors captured from the reference's own modules
+(tests/golden/*.npz, produced by tools/gen_golden.py in the build container).  This is what pins the
+oracle; HuBERT is pinned against the transformers twin only (fairseq absent -> parity unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rms
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _S():
+    import polgen_rvc_amd  # noqa: F401
+    from polgen_rvc_amd import synthetic
+    return synthetic
+
+
+@pytest.mark.parametrize("tag", ["tiny", "48k_T24"])
+def test_synth_oracle_vs_reference(tag):
+    from oracle import synth as O
+    S = _S()
+    d = np.load(os.path.join(GOLD, f"synth_{tag}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    sd = S.to_torch(S.synth_state(cfg, int(d["seed"])))
+    T = d["phone"].shape[1]
+    out, parts = O.synthesizer_infer(sd, cfg, torch.from_numpy(d["phone"]), torch.tensor([T]),
+                                     torch.from_numpy(d["pitch"]), torch.from_numpy(d["f0"]), torch.tensor([0]),
+                                     torch.from_numpy(d["z_noise"]), torch.from_numpy(d["src_noise"]),
+                                     return_parts=True)
+    assert rms(parts["m_p"].numpy() - d["m_p"]) < 1e-6
+    assert rms(parts["z"].numpy() - d["z"]) < 1e-5
+    assert rms(out.numpy() - d["audio"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full_1s"])
+def test_rmvpe_oracle_vs_reference(tag):
+    from oracle import rmvpe as O
+    S = _S()
+    d = np.load(os.path.join(GOLD, f"rmvpe_{tag}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    sd = S.to_torch(S.rmvpe_state(cfg, int(d["seed"])))
+    f0, hid, mel = O.infer_f0(sd, cfg, d["audio"].astype(np.float64), return_hidden=True)
+    st = int(d["stride"])
+    assert rms(hid[::st] - d["hidden"]) / rms(d["hidden"]) < 1e-4
+    assert np.abs(f0 - d["f0"]).max() < 1e-2
+    assert len(O.unstable_frames(hid)) == 0          # the golden instance is well-conditioned
+
+
+@pytest.mark.parametrize("tag", ["tiny", "base_1s"])
+def test_hubert_oracle_vs_hf_twin(tag):
+    from oracle import hubert as O
+    S = _S()
+    d = np.load(os.path.join(GOLD, f"hubert_{tag}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    sd = S.to_torch(S.hubert_state(cfg, int(d["seed"])))
+    out = O.extract_features(sd, cfg, torch.from_numpy(d["wav"]), cfg["layers"]).numpy()
+    assert rms(out - d["out"]) / rms(d["out"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked"])
+def test_pipeline_oracle_vs_reference(tag):
+    from oracle import pipeline as OP
+    S = _S()
+    d = np.load(os.path.join(GOLD, f"pipeline_{tag}.npz"))
+    hcfg, rcfg, scfg = json.loads(str(d["cfgs"]))
+    seed = int(d["seed"])
+    models = OP.Models(S.to_torch(S.hubert_state(hcfg, seed)), hcfg, S.to_torch(S.rmvpe_state(rcfg, seed)), rcfg,
+                       S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])), scfg)
+    noises = [(torch.from_numpy(d[f"z_noise_{i}"]), torch.from_numpy(d[f"src_noise_{i}"]))
+              for i in range(int(d["n_chunks"]))]
+    audio = S.make_clip(int(d["clip"]), float(d["seconds"]))
+    pcm, parts = OP.pipeline(models, OP.Geometry(scfg[-1], *[int(v) for v in d["geo"]]), audio, float(d["pitch"]),
+                             0, None, 0.0, float(d["volume_envelope"]), float(d["protect"]), float(d["f0_min"]),
+                             float(d["f0_max"]), noises=noises, return_parts=True)
+    assert len(parts["plan"]) == int(d["n_chunks"])
+    assert pcm.shape == d["pcm"].shape
+    assert np.abs(pcm.astype(np.int32) - d["pcm"].astype(np.int32)).max() <= 2
+    assert (parts["coarse"] == d["coarse"]).all()
+    assert rms(np.concatenate(parts["raw"]) - d["raw"]) < 1e-4
+
+
+def test_layout_contracts():
+    """Synthetic checkpoints carry exactly the key/shape set of the reference modules (layouts.json was
+    dumped from Synthesizer / E2E state_dicts)."""
+    S = _S()
+    with open(os.path.join(GOLD, "layouts.json")) as f:
+        L = json.load(f)
+    for name, state in (("synth_48k", S.synth_state(S.SYNTH_CFG_48K)), ("rmvpe", S.rmvpe_state(S.RMVPE_CFG_FULL))):
+        assert set(state) == set(L[name])
+        for k, v in state.items():
+            assert list(v.shape) == L[name][k], k
+
+
+def test_index_blend_oracle_properties():
+    from oracle import pipeline as OP
+    S = _S()
+    big = S.make_index(512, 32, 0)
+    q = big[[3, 77, 200]] + 1e-3
+    out, ids, dist = OP.index_blend(q.astype(np.float32), big, 1.0)
+    assert (ids[:, 0] == [3, 77, 200]).all() and (np.diff(dist, axis=1) >= 0).all()
+    assert rms(out - big[[3, 77, 200]]) < 1e-2          # (1/d)^2 weights are dominated by the exact neighbour

@@ -237,9 +237,13 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
     net = ref_synth(scfg, ssd)
     draws = []
     orig = torch.randn_like
+    # the two Gaussian draws come from a PRIVATE generator (seeded with `seed`) so that a test can
+    # regenerate them without depending on what else consumed torch's global RNG (the HF HuBERT twin
+    # calls torch.rand([]) per layer for layerdrop even in eval mode)
+    gen = torch.Generator().manual_seed(int(seed))
 
     def cap(x, **kw):
-        d = orig(x, **kw)
+        d = torch.randn(x.shape, generator=gen, dtype=x.dtype)
         draws.append(d.clone())
         return d
     raw = []
