@@ -65,7 +65,9 @@ struct ConvProfile {
 void conv_profile_begin();                          // start recording one event pair per conv launch
 void conv_profile_end(ConvProfile* out);            // sync, accumulate, stop
 void conv_init();                                   // raise dynamic-LDS limits once
-void launch_conv(ConvArgs a, hipStream_t stream);   // picks tile + LDS chunking, launches
+void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + tile, launches
+bool launch_conv_fast(ConvArgs& a, hipStream_t stream);   // stride-1 compile-time-tiled family; false = not applicable
+void conv_fast_init();
 double conv_flops(const ConvArgs& a);               // 2*M*N*K of the *real* (unpadded) problem
 
 // ---------------- host-side weight packing ------------------------------------------------

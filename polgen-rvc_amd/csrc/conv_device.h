@@ -1,0 +1,76 @@
+// Device-side pieces shared by the conv kernels: activation and the fused epilogue.
+#pragma once
+#include "conv.h"
+
+namespace rvcx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case ACT_LRELU: return v > 0.f ? v : v * slope;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+
+// one output element: bias -> activation -> residual -> length mask -> store (by output mode)
+__device__ __forceinline__ void store_elem(const ConvArgs& a, int b, int cg, int nn, float v, int len_out) {
+  if (a.bias) v += a.bias[cg];
+  v = apply_act(v, a.act, a.act_slope);
+  if (a.out_mode == OUT_NORMAL) {
+    if (a.res) v += a.res[(long)b * a.res_bs + (long)cg * a.res_cs + nn];
+    if (nn >= len_out) v = 0.f;
+    if (a.zero_wp > 0) {
+      const int col = nn % a.zero_wp;
+      if (col == 0 || col == a.zero_wp - 1) v = 0.f;
+    }
+    if (a.y) a.y[(long)b * a.y_bs + (long)cg * a.y_cs + nn] = v;
+    if (a.acc2_mode != ACC2_NONE) {
+      float* p2 = a.y2 + (long)b * a.y2_bs + (long)cg * a.y2_cs + nn;
+      if (a.acc2_mode == ACC2_SET) *p2 = v;
+      else if (a.acc2_mode == ACC2_ADD) *p2 = *p2 + v;
+      else *p2 = (*p2 + v) / a.acc2_div;
+    }
+  } else if (a.out_mode == OUT_SHUF1D) {
+    const int ph = cg / a.sh_cout, c = cg - ph * a.sh_cout;
+    const int t = nn * a.sh_s + ph - a.sh_pad;
+    if (t >= 0 && t < a.sh_tout) {
+      if (a.res) v += a.res[(long)b * a.res_bs + (long)c * a.res_cs + t];
+      if (t >= len_out) v = 0.f;
+      a.y[(long)b * a.y_bs + (long)c * a.y_cs + t] = v;
+    }
+  } else if (a.out_mode == OUT_SHUF2D) {
+    const int ph = cg / a.sh_cout, c = cg - ph * a.sh_cout;
+    const int pa = ph >> 1, pb = ph & 1;
+    const int irow = nn / a.wp_in, jj = nn - irow * a.wp_in;
+    if (jj != 0 && jj != a.wp_in - 1) {
+      const long rowbase = (long)b * a.y_bs + (long)c * a.y_cs + (long)(2 * irow + pa) * a.wp_out;
+      a.y[rowbase + 2 * (jj - 1) + pb + 1] = v;
+      if (jj == 1 && pb == 0) a.y[rowbase] = 0.f;
+      if (jj == a.wp_in - 2 && pb == 1) a.y[rowbase + a.wp_out - 1] = 0.f;
+    }
+  } else {  // OUT_TRANSPOSED: y[b][n][c]
+    if (a.res) v += a.res[(long)b * a.res_bs + (long)nn * a.res_cs + cg];
+    if (nn >= len_out) v = 0.f;
+    a.y[(long)b * a.y_bs + (long)nn * a.y_cs + cg] = v;
+  }
+}
+
+// one 32x32 accumulator tile.  C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5);
+// co_base already includes the 4*(lane>>5) term.
+__device__ __forceinline__ void store_tile(const ConvArgs& a, int b, int g, int co_base, int nn, const f32x16& t,
+                                           int len_out) {
+  if (nn >= a.Nout) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co_base + (r & 3) + 8 * (r >> 2);
+    if (co < a.Cout_g) store_elem(a, b, g * a.Cout_g + co, nn, t[r], len_out);
+  }
+}
+
+}  // namespace rvcx

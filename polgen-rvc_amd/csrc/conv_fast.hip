@@ -1,0 +1,196 @@
+// Stride-1 implicit-GEMM conv with compile-time tiling -- the kernel that carries the NSF-HiFi-GAN
+// decoder, the flow, the TextEncoder, the RMVPE U-Net and every Linear of the hot path.
+//
+// Differences from the generic kernel in conv.hip: the K-chunk shape (KKT taps x CIC channels), the LDS
+// row pitch (BN + HALO) and every loop bound are template constants, so the k-loop is fully unrolled
+// with immediate-offset ds_reads feeding back-to-back v_mfma_f32_32x32x2_f32, and the staging code is a
+// handful of coalesced loads (weights: exactly A_FLOATS/1024 float4 per thread; input: CIC/4 rows per
+// wave, 64 consecutive floats per wave-instruction, zero-filled at the sequence edges).
+//
+//   for ci0 in Cin step CIC:            stage X[ci0:ci0+CIC][n0+off_min : +BN+halo]      -> Bs[CIC][WROW]
+//     for kk0 in ksize step KKT:        stage Wp[kk0:kk0+KKT][ci0:ci0+CIC][co0:co0+BM]   -> As[KKT][CIC][BM]
+//       for kkl, cp (unrolled):         A frag As[kkl][2cp+h][wm+i], B frag Bs[2cp+h][wn+i+tap(kk)] -> MFMA
+#include "conv.h"
+#include "conv_device.h"
+
+namespace rvcx {
+
+template <int BM, int BN, int WR, int WC, int KKT, int CIC, int HALO>
+__global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
+  constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
+  constexpr int WROW = BN + HALO;
+  constexpr int A_FLOATS = KKT * CIC * BM;
+  constexpr int NA4 = A_FLOATS / 1024;
+  constexpr int NBJ = (WROW + 63) / 64;
+  static_assert(WR * WC == 4 && A_FLOATS % 1024 == 0 && CIC % 4 == 0, "bad tile");
+  __shared__ float As[A_FLOATS];
+  __shared__ float Bs[CIC * WROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int co0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
+  const float* xg = a.x + (long)b * a.x_bs;
+  const int in_base = n0 + a.off_min;
+  const int wuse = BN + a.wrow;          // a.wrow = off_max - off_min for this family
+  const int pre_act = a.pre_act;
+  const float pre_slope = a.pre_slope;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // chunk-invariant weight-tile addressing: float4 #j of this thread is row (kkl, cil), columns c4*4..+3
+  int a_goff[NA4], a_kkl[NA4];
+#pragma unroll
+  for (int j = 0; j < NA4; ++j) {
+    const int idx = tid + j * 256;
+    const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+    const int kkl = row / CIC, cil = row % CIC;
+    a_kkl[j] = (co0 + c4 * 4 < a.Cout_gp) ? kkl : (1 << 20);
+    a_goff[j] = (kkl * a.Cin_gp + cil) * a.Cout_gp + co0 + c4 * 4;
+  }
+  const float* Ap = As + h * BM + wr * (WM * 32) + i;
+  const float* Bp = Bs + h * WROW + wc * (WN * 32) + i;
+
+  for (int ci0 = 0; ci0 < a.Cin_gp; ci0 += CIC) {
+    __syncthreads();
+    // ---- input tile: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction
+#pragma unroll
+    for (int rr = 0; rr < CIC / 4; ++rr) {
+      const int r = wave + 4 * rr;
+      const int ci = ci0 + r;
+      const bool cvalid = ci < a.Cin_g;
+      const float* xr = xg + (long)ci * a.x_cs + in_base;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) {
+        const int p = lane + 64 * j;
+        const int pos = in_base + p;
+        float v = 0.f;
+        if (cvalid && p < wuse && pos >= 0 && pos < len_in) v = xr[p];
+        if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
+        if (p < WROW) Bs[r * WROW + p] = v;
+      }
+    }
+    for (int kk0 = 0; kk0 < a.ksize; kk0 += KKT) {
+      if (kk0 > 0) __syncthreads();
+      const float* wbase = a.w + ((long)kk0 * a.Cin_gp + ci0) * a.Cout_gp;
+#pragma unroll
+      for (int j = 0; j < NA4; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_kkl[j] + kk0 < a.ksize) v = *reinterpret_cast<const float4*>(wbase + a_goff[j]);
+        *reinterpret_cast<float4*>(As + (tid + j * 256) * 4) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kkl = 0; kkl < KKT; ++kkl) {
+        const int kk = kk0 + kkl;
+        if (kk < a.ksize) {
+          const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
+          const float* Bt = Bp + tp;
+#pragma unroll
+          for (int cp = 0; cp < CIC / 2; ++cp) {
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) av[m] = Ap[(kkl * CIC + 2 * cp) * BM + m * 32];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bv[n] = Bt[2 * cp * WROW + n * 32];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+              for (int n = 0; n < WN; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
+  const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+  store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
+  if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
+  if constexpr (WM > 1) {
+    store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
+    if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
+  }
+}
+
+namespace {
+
+struct FastCfg {
+  int bm, bn, halo, cic;   // cic = 32 marks the k=1 (Linear) variants
+  float eff;
+  void (*kern)(const ConvArgs);
+};
+
+const FastCfg kFast[] = {
+    // 1-D convs (halo <= 64 covers k=11 d=5)
+    {128, 128, 64, 16, 1.00f, conv_fast_kernel<128, 128, 2, 2, 2, 16, 64>},
+    {128, 64, 64, 16, 0.85f, conv_fast_kernel<128, 64, 4, 1, 2, 16, 64>},
+    {64, 256, 64, 16, 1.00f, conv_fast_kernel<64, 256, 1, 4, 4, 16, 64>},
+    {64, 128, 64, 16, 0.85f, conv_fast_kernel<64, 128, 2, 2, 4, 16, 64>},
+    {64, 64, 64, 16, 0.70f, conv_fast_kernel<64, 64, 2, 2, 4, 16, 64>},
+    {32, 256, 64, 16, 0.90f, conv_fast_kernel<32, 256, 1, 4, 4, 16, 64>},
+    // 3x3 convs on row-padded maps (halo = 2*Wp + 2 <= 262)
+    {128, 128, 288, 16, 1.00f, conv_fast_kernel<128, 128, 2, 2, 2, 16, 288>},
+    {64, 128, 288, 16, 0.85f, conv_fast_kernel<64, 128, 2, 2, 4, 16, 288>},
+    {32, 128, 288, 16, 0.70f, conv_fast_kernel<32, 128, 1, 4, 4, 16, 288>},
+    // Linear layers (k = 1)
+    {128, 128, 0, 32, 1.00f, conv_fast_kernel<128, 128, 2, 2, 1, 32, 0>},
+    {128, 64, 0, 32, 0.85f, conv_fast_kernel<128, 64, 4, 1, 1, 32, 0>},
+    {64, 64, 0, 32, 0.70f, conv_fast_kernel<64, 64, 2, 2, 1, 32, 0>},
+};
+constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
+
+}  // namespace
+
+void conv_fast_init() {}
+
+bool launch_conv_fast(ConvArgs& a, hipStream_t stream) {
+  if (a.stride != 1 || a.groups != 1 || a.Cin_gp % 16 != 0) return false;
+  int off_min = 1 << 30, off_max = -(1 << 30);
+  for (int kk = 0; kk < a.ksize; ++kk) {
+    const int o = conv_tap_off(a, kk);
+    off_min = std::min(off_min, o);
+    off_max = std::max(off_max, o);
+  }
+  const int halo = off_max - off_min;
+  int best = -1;
+  double best_t = 1e300;
+  for (int t = 0; t < kNumFast; ++t) {
+    const FastCfg& F = kFast[t];
+    if (F.cic == 32) {
+      if (a.ksize != 1 || a.Cin_gp % 32 != 0) continue;
+    } else if (a.ksize == 1 && a.Cin_gp % 32 == 0) {
+      continue;   // Linear layers go to the k=1 variants
+    }
+    if (halo > F.halo) continue;
+    if (F.halo == 288 && halo <= 64) continue;
+    const long mt = cdiv(a.Cout_gp, F.bm), nt = cdiv(a.Nout, F.bn);
+    const long blocks = mt * nt * a.B;
+    const long rounds = (blocks + 767) / 768;   // 256 CUs x ~3 resident blocks
+    const double tm = (double)rounds * F.bm * F.bn / F.eff;
+    if (tm < best_t) {
+      best_t = tm;
+      best = t;
+    }
+  }
+  if (best < 0) return false;
+  const FastCfg& F = kFast[best];
+  a.off_min = off_min;
+  a.wrow = halo;
+  dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B);
+  hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
+  RVCX_HIP(hipGetLastError());
+  return true;
+}
+
+}  // namespace rvcx
