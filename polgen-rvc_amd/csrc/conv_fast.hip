@@ -48,78 +48,101 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   // chunk-invariant weight-tile addressing: float4 #j of this thread is row (kkl, cil), columns c4*4..+3
-  int a_goff[NA4], a_kkl[NA4];
+  int a_kkl[NA4], a_col[NA4];
+  bool a_cok[NA4];
 #pragma unroll
   for (int j = 0; j < NA4; ++j) {
     const int idx = tid + j * 256;
     const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-    const int kkl = row / CIC, cil = row % CIC;
-    a_kkl[j] = (co0 + c4 * 4 < a.Cout_gp) ? kkl : (1 << 20);
-    a_goff[j] = (kkl * a.Cin_gp + cil) * a.Cout_gp + co0 + c4 * 4;
+    a_kkl[j] = row / CIC;
+    a_cok[j] = co0 + c4 * 4 < a.Cout_gp;
+    a_col[j] = (row % CIC) * a.Cout_gp + min(co0 + c4 * 4, a.Cout_gp - 4);
   }
   const float* Ap = As + h * BM + wr * (WM * 32) + i;
   const float* Bp = Bs + h * WROW + wc * (WN * 32) + i;
+  const int nkk = (a.ksize + KKT - 1) / KKT;
+  const int nst = (a.Cin_gp / CIC) * nkk;
+  const int len_m1 = max(len_in - 1, 0);
 
-  for (int ci0 = 0; ci0 < a.Cin_gp; ci0 += CIC) {
+  // one flat loop over (ci chunk, tap chunk) stages; all staging loads are unconditional (clamped
+  // addresses + select), so the loop body is straight-line code and the accumulators stay in AGPRs
+  int ci0 = 0, kk0 = 0;
+  for (int st = 0; st < nst; ++st) {
     __syncthreads();
-    // ---- input tile: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction
+    if (kk0 == 0) {
+      // ---- input tile: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction
 #pragma unroll
-    for (int rr = 0; rr < CIC / 4; ++rr) {
-      const int r = wave + 4 * rr;
-      const int ci = ci0 + r;
-      const bool cvalid = ci < a.Cin_g;
-      const float* xr = xg + (long)ci * a.x_cs + in_base;
+      for (int rr = 0; rr < CIC / 4; ++rr) {
+        const int r = wave + 4 * rr;
+        const int ci = ci0 + r;
+        const bool cvalid = ci < a.Cin_g;
+        const float* xr = xg + (long)min(ci, a.Cin_g - 1) * a.x_cs;
 #pragma unroll
-      for (int j = 0; j < NBJ; ++j) {
-        const int p = lane + 64 * j;
-        const int pos = in_base + p;
-        float v = 0.f;
-        if (cvalid && p < wuse && pos >= 0 && pos < len_in) v = xr[p];
-        if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
-        if (p < WROW) Bs[r * WROW + p] = v;
-      }
-    }
-    for (int kk0 = 0; kk0 < a.ksize; kk0 += KKT) {
-      if (kk0 > 0) __syncthreads();
-      const float* wbase = a.w + ((long)kk0 * a.Cin_gp + ci0) * a.Cout_gp;
-#pragma unroll
-      for (int j = 0; j < NA4; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_kkl[j] + kk0 < a.ksize) v = *reinterpret_cast<const float4*>(wbase + a_goff[j]);
-        *reinterpret_cast<float4*>(As + (tid + j * 256) * 4) = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int kkl = 0; kkl < KKT; ++kkl) {
-        const int kk = kk0 + kkl;
-        if (kk < a.ksize) {
-          const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
-          const float* Bt = Bp + tp;
-#pragma unroll
-          for (int cp = 0; cp < CIC / 2; ++cp) {
-            float av[WM], bv[WN];
-#pragma unroll
-            for (int m = 0; m < WM; ++m) av[m] = Ap[(kkl * CIC + 2 * cp) * BM + m * 32];
-#pragma unroll
-            for (int n = 0; n < WN; ++n) bv[n] = Bt[2 * cp * WROW + n * 32];
-#pragma unroll
-            for (int m = 0; m < WM; ++m)
-#pragma unroll
-              for (int n = 0; n < WN; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-          }
+        for (int j = 0; j < NBJ; ++j) {
+          const int p = lane + 64 * j;
+          const int pos = in_base + p;
+          float v = xr[min(max(pos, 0), len_m1)];
+          v = (cvalid && p < wuse && pos >= 0 && pos < len_in) ? v : 0.f;
+          if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
+          if (NBJ * 64 == WROW || p < WROW) Bs[r * WROW + p] = v;
         }
       }
+    }
+    {
+      const float* wbase = a.w + (long)ci0 * a.Cout_gp;
+#pragma unroll
+      for (int j = 0; j < NA4; ++j) {
+        const int kk = kk0 + a_kkl[j];
+        float4 v = *reinterpret_cast<const float4*>(wbase + (long)min(kk, a.ksize - 1) * a.Cin_gp * a.Cout_gp + a_col[j]);
+        if (!(a_cok[j] && kk < a.ksize)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(As + (tid + j * 256) * 4) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kkl = 0; kkl < KKT; ++kkl) {
+      const int kk = kk0 + kkl;
+      if (KKT == 1 || kk < a.ksize) {
+        const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
+        const float* Bt = Bp + tp;
+#pragma unroll
+        for (int cp = 0; cp < CIC / 2; ++cp) {
+          float av[WM], bv[WN];
+#pragma unroll
+          for (int m = 0; m < WM; ++m) av[m] = Ap[(kkl * CIC + 2 * cp) * BM + m * 32];
+#pragma unroll
+          for (int n = 0; n < WN; ++n) bv[n] = Bt[2 * cp * WROW + n * 32];
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+    kk0 += KKT;
+    if (kk0 >= a.ksize) {
+      kk0 = 0;
+      ci0 += CIC;
     }
   }
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
-  store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
-  if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
-  if constexpr (WM > 1) {
-    store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
-    if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
+  if (fast_epilogue_ok(a)) {
+    store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
+    if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
+    if constexpr (WM > 1) {
+      store_tile_fast(a, b, co_w + 32, nn_w, acc[1][0], len_out);
+      if constexpr (WN > 1) store_tile_fast(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
+    }
+  } else {
+    store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
+    if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
+    if constexpr (WM > 1) {
+      store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
+      if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
+    }
   }
 }
 
