@@ -59,6 +59,8 @@ int rvcx_create(int device, rvcx_ctx** out) {
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     conv_init();
+    RVCX_HIP(hipMalloc(&h->c.dev_err, sizeof(int)));
+    RVCX_HIP(hipMemset(h->c.dev_err, 0, sizeof(int)));
     h->c.arena.reserve((size_t)256 << 20);
     *out = h;
     return 0;
@@ -429,6 +431,7 @@ int rvcx_rmvpe_f0(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float thr
   RVCX_HIP(hipMemcpyAsync(f0, df0, (size_t)B * F * 4, hipMemcpyDefault, C->stream));
   if (hidden) RVCX_HIP(hipMemcpyAsync(hidden, dh, (size_t)B * F * 360 * 4, hipMemcpyDefault, C->stream));
   RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->check_dev_err();
   C->arena.reset();
   API_END
 }
@@ -489,10 +492,12 @@ int rvcx_op_bigru(rvcx_ctx* ctx, const float* x, const float* w_ih, const float*
   a.y_cs = 2 * H3;
   C->conv(a);
   float* gy = C->arena.alloc<float>((size_t)B * 2 * H * T);
-  launch_bigru(gi, dwhh, dbhh, gy, B, T, H, C->stream);
+  void* gscr = C->arena.alloc<unsigned long long>(bigru_scratch_bytes(B) / 8);
+  launch_bigru(gi, dwhh, dbhh, gy, B, T, H, gscr, C->dev_err, C->stream);
   float* gyt = C->arena.alloc<float>((size_t)B * 2 * H * T);
   launch_transpose(gy, gyt, B, 2 * H, T, C->stream);  // (B,2H,T) -> (B,T,2H)
   to_host(*C, y, gyt, (size_t)B * T * 2 * H);
+  C->check_dev_err();
   C->arena.reset();
   API_END
 }
@@ -566,6 +571,7 @@ int rvcx_convert_batch(rvcx_ctx* ctx, int model_id, int B, const float* const* w
     RVCX_HIP(hipMemcpyAsync(out[i], dpcm, (size_t)got * sizeof(short), hipMemcpyDefault, C->stream));
     if (df32) RVCX_HIP(hipMemcpyAsync(out_f32[i], df32, (size_t)got * sizeof(float), hipMemcpyDefault, C->stream));
     RVCX_HIP(hipStreamSynchronize(C->stream));
+    C->check_dev_err();
     if (out_n) out_n[i] = got;
   }
   for (int k = 0; k < 9; ++k) C->timing[k] = tsum[k];
@@ -589,10 +595,11 @@ int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params
   const long pl = n_pad / 160;
   int* dc = C->arena.alloc<int>((size_t)pl + 8);
   float* df = C->arena.alloc<float>((size_t)pl + 8);
-  get_f0_device(*C, apad, n_pad, *p, dc, df);
+  get_f0_device(*C, apad, n_pad, *p, dc, df, C->stream);
   RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)pl * 4, hipMemcpyDefault, C->stream));
   RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)pl * 4, hipMemcpyDefault, C->stream));
   RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->check_dev_err();
   *p_len = pl;
   C->arena.reset();
   API_END

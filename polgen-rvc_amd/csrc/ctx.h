@@ -60,6 +60,8 @@ struct Ctx {
   WeightSlab slab;
   std::string last_error;
   double flops = 0.0;
+  int* dev_err = nullptr;         // device flag: a kernel gave up waiting (checked after each API call)
+  void check_dev_err();
   float timing[9] = {0};
   StageTimer timer;
   std::unique_ptr<HubertModel> hubert;

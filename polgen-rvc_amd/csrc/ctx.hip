@@ -51,6 +51,16 @@ std::vector<float> TensorTable::f32(const std::string& name) const {
 
 Ctx::Ctx() {}
 
+void Ctx::check_dev_err() {
+  if (!dev_err) return;
+  int v = 0;
+  RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (v) {
+    RVCX_HIP(hipMemset(dev_err, 0, sizeof(int)));
+    fail("device-side timeout: a GRU cluster workgroup lost its partner");
+  }
+}
+
 Ctx::~Ctx() {
   hubert.reset();
   rmvpe.reset();
@@ -58,6 +68,7 @@ Ctx::~Ctx() {
   index.reset();
   if (timer.made)
     for (auto& e : timer.ev) (void)hipEventDestroy(e);
+  if (dev_err) (void)hipFree(dev_err);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
   if (stream2) (void)hipStreamDestroy(stream2);

@@ -1,11 +1,18 @@
 // Bidirectional GRU recurrence (RMVPE BiGRU(384 -> 2x256), rvc/lib/predictors/RMVPE.py:125-137).
 // The input projections W_ih x + b_ih for every frame are one MFMA GEMM done by the conv kernel
-// (transposed store, (B,T,6H)); what is left is the serial part h_t = f(gi_t, W_hh h_{t-1}).
+// (transposed store, (B,T,6H)); what is left is the serial part h_t = f(gi_t, W_hh h_{t-1}), T = 3232
+// dependent steps for a 30 s clip.  Gate order r, z, n (torch.nn.GRU).
 //
-// One workgroup per (direction, batch item): 3H threads, thread j owns gate row j.  W_hh is
-// stored transposed (H x 3H) so the per-step read of column block k is coalesced across the
-// threads; it streams from L2 every step (786 KB fp32 does not fit one CU's registers + LDS).
-// Gate order r, z, n (torch.nn.GRU).
+// Two kernels:
+//  * bigru_cluster_kernel: NC workgroups (= CUs) per (direction, batch item).  W_hh (786 KB fp32) does
+//    not fit one CU, so each workgroup keeps the 3*H/NC gate rows of its H/NC hidden units in REGISTERS
+//    for the whole sequence and the workgroups exchange their slice of h_t every step through
+//    data-tagged 8-byte granules ({value, step} written by one write-through store, polled with
+//    relaxed agent-scope loads -- no fences, placement independent; guide G16 "R2").  Per-step cost is
+//    one 128-FMA register dot product + one inter-CU hand-off (~1.5 us) instead of streaming W_hh from
+//    L2 (~7 us).
+//  * bigru_kernel: one workgroup per (direction, item), W_hh streamed from L2 every step.  Used when
+//    the cluster grid would not be co-resident (large batches) -- the cluster kernel spins.
 #include "ops.h"
 
 namespace rvcx {
@@ -50,10 +57,123 @@ __global__ __launch_bounds__(3 * H) void bigru_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+constexpr int GRU_H = 256;
+constexpr int GRU_NC = 4;                 // workgroups per (direction, item)
+constexpr int GRU_U = GRU_H / GRU_NC;     // hidden units owned by a workgroup (64)
+constexpr int GRU_ROWS = 3 * GRU_U;       // gate rows owned (192)
+constexpr int GRU_THREADS = 2 * GRU_ROWS; // thread = (row, column half): 128 weights in registers
+constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;   // ~seconds: a lost partner ends the kernel instead of hanging the GPU
+
+union Granule {
+  unsigned long long u;
+  struct {
+    float v;
+    int tag;
+  } s;
+};
+
+__global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float* __restrict__ gi,
+                                                                    const float* __restrict__ whh_t,  // (2,H,3H)
+                                                                    const float* __restrict__ bhh,
+                                                                    float* __restrict__ y,
+                                                                    unsigned long long* xbuf,  // (B,2,2,H) granules
+                                                                    int* err, int T) {
+  constexpr int H = GRU_H;
+  __shared__ __attribute__((aligned(16))) float hs[H];
+  __shared__ float part[2][GRU_ROWS];
+  __shared__ int sfail;
+  const int c = blockIdx.x, dir = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int row = tid % GRU_ROWS, half = tid / GRU_ROWS;
+  const int gate = row / GRU_U, ul = row % GRU_U;
+  const int grow = gate * H + c * GRU_U + ul;          // row of W_hh (3H x H)
+  const float* W = whh_t + (long)dir * H * 3 * H;
+  // this thread's 128 weights: W_hh[grow][half*128 .. +128)  (whh_t is (H, 3H): column-major rows)
+  float w[H / 2];
+#pragma unroll
+  for (int k = 0; k < H / 2; ++k) w[k] = W[(long)(half * (H / 2) + k) * 3 * H + grow];
+  const float* gib = gi + (long)b * T * 6 * H + dir * 3 * H;
+  float* yb = y + ((long)b * 2 + dir) * H * T;
+  unsigned long long* xb = xbuf + ((long)b * 2 + dir) * 2 * H;
+  const int ju = c * GRU_U + tid;                      // unit handled in the gate phase (tid < GRU_U)
+  float bh_r = 0.f, bh_z = 0.f, bh_n = 0.f;
+  if (tid < GRU_U) {
+    bh_r = bhh[dir * 3 * H + ju];
+    bh_z = bhh[dir * 3 * H + H + ju];
+    bh_n = bhh[dir * 3 * H + 2 * H + ju];
+  }
+  for (int k = tid; k < H; k += GRU_THREADS) hs[k] = 0.f;
+  if (tid == 0) sfail = 0;
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    // ---- partial dot product over this thread's 128 columns (h broadcast from LDS, 16 B at a time)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float4* h4 = reinterpret_cast<const float4*>(hs + half * (H / 2));
+#pragma unroll
+    for (int k = 0; k < H / 8; ++k) {
+      const float4 hv = h4[k];
+      a0 = fmaf(w[4 * k + 0], hv.x, a0);
+      a1 = fmaf(w[4 * k + 1], hv.y, a1);
+      a2 = fmaf(w[4 * k + 2], hv.z, a2);
+      a3 = fmaf(w[4 * k + 3], hv.w, a3);
+    }
+    part[half][row] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    // ---- gates for the owned units, publish h_t[ju] as a {value, step+1} granule
+    if (tid < GRU_U) {
+      const float* g = gib + (long)t * 6 * H;
+      const float ghr = part[0][tid] + part[1][tid] + bh_r;
+      const float ghz = part[0][GRU_U + tid] + part[1][GRU_U + tid] + bh_z;
+      const float ghn = part[0][2 * GRU_U + tid] + part[1][2 * GRU_U + tid] + bh_n;
+      const float r = 1.f / (1.f + expf(-(g[ju] + ghr)));
+      const float z = 1.f / (1.f + expf(-(g[H + ju] + ghz)));
+      const float n = tanhf(g[2 * H + ju] + r * ghn);
+      const float hn = (1.f - z) * n + z * hs[ju];
+      Granule gr;
+      gr.s.v = hn;
+      gr.s.tag = step + 1;
+      __hip_atomic_store(xb + (step & 1) * H + ju, gr.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      yb[(long)ju * T + t] = hn;
+      hs[ju] = hn;   // own slice: no other thread reads hs[ju] before the barrier below
+    } else if (tid < GRU_U + (H - GRU_U)) {
+      // ---- gather the other workgroups' units of h_t
+      int k = tid - GRU_U;                     // 0 .. H-U-1 over the foreign units
+      if (k >= c * GRU_U) k += GRU_U;          // skip the own slice
+      Granule gr;
+      unsigned spins = 0;
+      do {
+        gr.u = __hip_atomic_load(xb + (step & 1) * H + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gr.s.tag == step + 1) break;
+        if (++spins > GRU_SPIN_LIMIT) {
+          sfail = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      } while (true);
+      hs[k] = gr.s.v;
+    }
+    __syncthreads();
+    if (sfail) break;     // block-uniform: every thread sees the flag after the barrier
+  }
+  if (tid == 0 && sfail) atomicExch(err, 1);
+}
+
+size_t bigru_scratch_bytes(int B) { return (size_t)B * 2 * 2 * GRU_H * sizeof(unsigned long long); }
+
 void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* y, int B, int T, int H,
-                  hipStream_t stream) {
-  RVCX_CHECK(H == 256, "bigru: hidden size must be 256 (RMVPE)");
-  hipLaunchKernelGGL(bigru_kernel<256>, dim3(2, B), dim3(768), 0, stream, gi, whh_t, bhh, y, T);
+                  void* scratch, int* err, hipStream_t stream) {
+  RVCX_CHECK(H == GRU_H, "bigru: hidden size must be 256 (RMVPE)");
+  // the cluster kernel needs all 2*B*NC workgroups co-resident (they spin on each other)
+  if (scratch && err && 2 * B * GRU_NC <= 128) {
+    unsigned long long* xbuf = static_cast<unsigned long long*>(scratch);
+    RVCX_HIP(hipMemsetAsync(scratch, 0, bigru_scratch_bytes(B), stream));
+    hipLaunchKernelGGL(bigru_cluster_kernel, dim3(GRU_NC, 2, B), dim3(GRU_THREADS), 0, stream, gi, whh_t, bhh, y, xbuf,
+                       err, T);
+  } else {
+    hipLaunchKernelGGL(bigru_kernel<GRU_H>, dim3(2, B), dim3(3 * GRU_H), 0, stream, gi, whh_t, bhh, y, T);
+  }
   RVCX_HIP(hipGetLastError());
 }
 

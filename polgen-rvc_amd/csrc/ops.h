@@ -14,8 +14,11 @@ double attention_flops(int B, int H, int D, int T);
 // ---- gru.hip
 // gi: (B, T, 2*3H) input projections (+b_ih) for [fwd | rev]; whh_t: (2, H, 3H); bhh: (2, 3H);
 // y: (B, 2H, T) channel-first (feeds the classifier conv directly)
+// scratch: bigru_scratch_bytes(B) of device memory for the inter-CU exchange; err: device flag set to 1 if
+// the cluster kernel timed out waiting for a partner workgroup (null scratch/err -> single-CU kernel)
+size_t bigru_scratch_bytes(int B);
 void launch_bigru(const float* gi, const float* whh, const float* bhh, float* y, int B, int T, int H,
-                  hipStream_t stream);
+                  void* scratch, int* err, hipStream_t stream);
 
 // ---- ops.hip
 // LayerNorm over channels of (B,C,T): y = (x-mean)/sqrt(var+eps)*gamma+beta  [normalization.py:13-16]

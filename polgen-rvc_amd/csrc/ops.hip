@@ -15,46 +15,64 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 // ------------------------------------------------------------------ LayerNorm over channels
-// block = 64 time steps x 4 channel slices; two-pass moments (mean, then centred variance)
+// block = 16 time steps x 16 channel slices (T is only a few thousand frames: small column groups keep
+// every CU busy); each thread caches its <= LN_MAXC/16 channel values in registers: one global read.
+constexpr int LN_TX = 16, LN_PARTS = 16, LN_MAXC = 1024, LN_RPT = LN_MAXC / LN_PARTS;
 __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           int C, int T, float eps, const int* lens) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  __shared__ float red[LN_PARTS][LN_TX];
+  const int tx = threadIdx.x % LN_TX, part = threadIdx.x / LN_TX;
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 64 + tx;
+  const int t = blockIdx.x * LN_TX + tx;
   const bool valid = t < T;
   const float* xb = x + (long)b * C * T;
   float* yb = y + (long)b * C * T;
+  float v[LN_RPT];
   float s = 0.f;
-  if (valid)
-    for (int c = part; c < C; c += 4) s += xb[(long)c * T + t];
+#pragma unroll
+  for (int k = 0; k < LN_RPT; ++k) {
+    const int c = part + k * LN_PARTS;
+    v[k] = (valid && c < C) ? xb[(long)c * T + t] : 0.f;
+    s += v[k];
+  }
   red[part][tx] = s;
   __syncthreads();
-  const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+  float tot = 0.f;
+#pragma unroll
+  for (int p = 0; p < LN_PARTS; ++p) tot += red[p][tx];
+  const float mean = tot / (float)C;
   __syncthreads();
-  float v = 0.f;
-  if (valid)
-    for (int c = part; c < C; c += 4) {
-      const float d = xb[(long)c * T + t] - mean;
-      v += d * d;
-    }
-  red[part][tx] = v;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_RPT; ++k) {
+    const int c = part + k * LN_PARTS;
+    const float d = (c < C) ? v[k] - mean : 0.f;
+    q += d * d;
+  }
+  red[part][tx] = q;
   __syncthreads();
-  const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
-  const float rstd = 1.f / sqrtf(var + eps);
+  float vt = 0.f;
+#pragma unroll
+  for (int p = 0; p < LN_PARTS; ++p) vt += red[p][tx];
+  const float rstd = 1.f / sqrtf(vt / (float)C + eps);
   if (!valid) return;
   const bool live = !lens || t < lens[b];
-  for (int c = part; c < C; c += 4) {
-    const float o = (xb[(long)c * T + t] - mean) * rstd * gamma[c] + beta[c];
-    yb[(long)c * T + t] = live ? o : 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_RPT; ++k) {
+    const int c = part + k * LN_PARTS;
+    if (c < C) {
+      const float o = (v[k] - mean) * rstd * gamma[c] + beta[c];
+      yb[(long)c * T + t] = live ? o : 0.f;
+    }
   }
 }
 
 void launch_layernorm_c(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                         float eps, const int* lens, hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, 64), B), dim3(256), 0, s, x, gamma, beta, y, C, T, eps, lens);
+  RVCX_CHECK(C <= LN_MAXC, "layernorm: too many channels");
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TX), B), dim3(256), 0, s, x, gamma, beta, y, C, T, eps, lens);
 }
 
 // ------------------------------------------------------------------ GroupNorm(C,C) + GELU

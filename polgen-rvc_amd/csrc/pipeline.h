@@ -28,6 +28,7 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
 size_t convert_arena_bytes(Ctx& c, int model_id, long n, const rvcx_params& p);
 
 // VC.get_f0 on device for one utterance: coarse/f0 device arrays of p_len frames
-long get_f0_device(Ctx& c, const float* wav, long n, const rvcx_params& p, int* coarse, float* f0);
+long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
+                   hipStream_t s);
 
 }  // namespace rvcx

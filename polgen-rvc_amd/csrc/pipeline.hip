@@ -363,12 +363,13 @@ long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params&
   return cap_frames * (long)(m.cfg.inter_channels + m.upp);
 }
 
-long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0) {
+long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
+                   hipStream_t s) {
   // VC.get_f0 (pipeline.py:132-201) on the already reflect-padded signal
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
   float* f0raw = c.arena.alloc<float>((size_t)F);
-  rmvpe_forward(c, *c.rmvpe, 1, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, c.stream);
-  launch_f0_coarse(f0raw, f0, coarse, (int)p_len, p.pitch, p.f0_min, p.f0_max, c.stream);
+  rmvpe_forward(c, *c.rmvpe, 1, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s);
+  launch_f0_coarse(f0raw, f0, coarse, (int)p_len, p.pitch, p.f0_min, p.f0_max, s);
   return p_len;
 }
 
@@ -400,11 +401,15 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
   const long p_len = n_pad / 160;
   int* coarse = A.alloc<int>((size_t)p_len + 8);
   float* f0 = A.alloc<float>((size_t)p_len + 8);
-  {
-    const size_t mk = A.mark();
-    get_f0_device(c, apad, n_pad, p, coarse, f0);
-    A.reset(mk);
-  }
+  // F0 runs on the second stream beside HuBERT (they only share the padded signal); its arena region
+  // stays allocated until the streams join, so nothing on the main stream can recycle it underneath
+  RVCX_HIP(hipEventRecord(c.ev_fork, s));
+  RVCX_HIP(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
+  const int r0 = clk.mark(c.stream2);
+  get_f0_device(c, apad, n_pad, p, coarse, f0, c.stream2);
+  const int r1 = clk.mark(c.stream2);
+  RVCX_HIP(hipEventRecord(c.ev_join, c.stream2));
+  bool joined = false;
   const int e2 = clk.mark(s);
   // ---- 4. per-chunk vc() (pipeline.py:203-287)
   const long cap = out_capacity(M, n, p);
@@ -443,6 +448,10 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
       A.reset(mk2);
     }
     const int h2 = clk.mark(s);
+    if (!joined) {   // first consumer of f0 / coarse
+      RVCX_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
+      joined = true;
+    }
     float* phone = A.alloc<float>((size_t)E * T);
     launch_upsample_protect(blended, feats0, f0 + ch.f0_off, phone, E, Th, T, p.protect, use_protect ? 1 : 0, s);
     // noise (parity: packed [z (inter*T) | src (T*upp)] per chunk in draw order; else Philox)
@@ -510,7 +519,7 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
   if (stage_ms) {
     RVCX_HIP(hipStreamSynchronize(s));
     stage_ms[0] = clk.between(e0, e1);
-    stage_ms[1] = clk.between(e1, e2);
+    stage_ms[1] = clk.between(r0, r1);   // on stream2, overlapped with the HuBERT stage
     stage_ms[2] = t_hub;
     stage_ms[3] = t_idx;
     stage_ms[4] = t_syn[0];

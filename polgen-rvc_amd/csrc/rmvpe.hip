@@ -346,7 +346,8 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
     c.conv_on(a, s);
   }
   float* gy = A.alloc<float>((size_t)B * 2 * H * Tp);
-  launch_bigru(gi, m.whh_t, m.bhh, gy, B, Tp, H, s);
+  void* gscr = A.alloc<unsigned long long>(bigru_scratch_bytes(B) / 8);
+  launch_bigru(gi, m.whh_t, m.bhh, gy, B, Tp, H, gscr, c.dev_err, s);
   float* sal = A.alloc<float>((size_t)B * Tp * 360);
   {
     ConvArgs a = conv1d_args(m.fc, gy, sal, B, Tp, Tp);
