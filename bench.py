@@ -120,6 +120,9 @@ def main():
     ctx.conv_profile_begin()
     step()
     prof = ctx.conv_profile_end()
+    if a.profile_out and rank == 0:
+        with open(a.profile_out.replace('.json', '') + '_conv_launches.csv', 'w') as f:
+            f.write(ctx.conv_profile_csv())
     total_flops = ctx.flop_counter()
     prof.sort(key=lambda r: -r["ms"])
     dom = prof[0]

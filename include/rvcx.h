@@ -147,6 +147,8 @@ int rvcx_last_timing(rvcx_ctx*, float* ms9);
  * summed kernel milliseconds, plus the tile shape (bm x bn). */
 int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
                       int32_t* bn, int cap);
+/* per-launch table (CSV text: tile,B,cin,cout,k,stride,nout,gflop,ms,tflops) of the last profile */
+const char* rvcx_conv_profile_csv(rvcx_ctx*);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */
 double rvcx_flop_counter(rvcx_ctx*, int reset);
 void* rvcx_stream(rvcx_ctx*); /* hipStream_t the library launches on */

@@ -62,7 +62,7 @@ SYMBOLS = [
     "rvcx_weights_blob", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_noise_len", "rvcx_get_f0", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         _lib.rvcx_version.restype = C.c_char_p
         _lib.rvcx_flop_counter.restype = C.c_double
         _lib.rvcx_stream.restype = C.c_void_p
+        _lib.rvcx_conv_profile_csv.restype = C.c_char_p
         _lib.rvcx_out_len.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
     return _lib
@@ -407,6 +408,9 @@ class Context:
         self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, 8), "conv_profile")
         return [dict(tile=f"{bm[i]}x{bn[i]}", launches=int(la[i]), flops=float(fl[i]), ms=float(ms[i]))
                 for i in range(8) if la[i] > 0]
+
+    def conv_profile_csv(self) -> str:
+        return (lib().rvcx_conv_profile_csv(self._h) or b"").decode()
 
     def last_timing(self):
         ms = (C.c_float * 9)()

@@ -624,6 +624,8 @@ int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops
   API_END
 }
 
+const char* rvcx_conv_profile_csv(rvcx_ctx*) { return conv_profile_csv(); }
+
 int rvcx_last_timing(rvcx_ctx* ctx, float* ms9) {
   if (!ctx) return -1;
   for (int k = 0; k < 9; ++k) ms9[k] = ctx->c.timing[k];

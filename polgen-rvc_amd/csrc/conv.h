@@ -46,8 +46,12 @@ struct ConvArgs {
   int zero_wp = 0;               // >0: force the pad columns of a row-padded 2-D map to 0
   int acc2_mode = ACC2_NONE;
   float acc2_div = 1.f;
+  // split-K scratch offered by the caller (per stream); the launcher decides whether to use it
+  float* part = nullptr;
+  long part_cap = 0;             // floats
   // filled by the launcher
   int ci_chunk = 0, kk_chunk = 0, wrow = 0, off_min = 0;
+  int splitk = 1;
 };
 
 // tap offset of kernel element kk relative to n*stride (before subtracting off_min)
@@ -64,6 +68,7 @@ struct ConvProfile {
 };
 void conv_profile_begin();                          // start recording one event pair per conv launch
 void conv_profile_end(ConvProfile* out);            // sync, accumulate, stop
+const char* conv_profile_csv();                     // per-launch table of the last profile (CSV text)
 void conv_init();                                   // raise dynamic-LDS limits once
 void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + tile, launches
 bool launch_conv_fast(ConvArgs& a, hipStream_t stream);   // stride-1 compile-time-tiled family; false = not applicable

@@ -169,6 +169,7 @@ struct ProfRec {
   hipEvent_t a, b;
   int tile;
   double flops;
+  int cin, cout, k, nout, stride, B;
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -179,8 +180,12 @@ void conv_profile_begin() {
   g_prof_on = true;
 }
 
+static std::string g_prof_csv;
+const char* conv_profile_csv() { return g_prof_csv.c_str(); }
+
 void conv_profile_end(ConvProfile* out) {
   g_prof_on = false;
+  g_prof_csv = "tile,B,cin,cout,k,stride,nout,gflop,ms,tflops\n";
   for (int t = 0; t < kNumTiles; ++t) {
     out->bm[t] = kTiles[t].bm;
     out->bn[t] = kTiles[t].bn;
@@ -192,6 +197,10 @@ void conv_profile_end(ConvProfile* out) {
     out->launches[r.tile] += 1;
     out->flops[r.tile] += r.flops;
     out->ms[r.tile] += ms;
+    char line[256];
+    snprintf(line, sizeof line, "%d,%d,%d,%d,%d,%d,%d,%.3f,%.4f,%.1f\n", r.tile, r.B, r.cin, r.cout, r.k, r.stride,
+             r.nout, r.flops / 1e9, ms, r.flops / (ms * 1e-3) / 1e12);
+    g_prof_csv += line;
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
@@ -207,6 +216,8 @@ void launch_conv(ConvArgs a, hipStream_t stream) {
     RVCX_HIP(hipEventCreate(&rec.b));
     rec.tile = ConvProfile::kMaxTiles - 1;
     rec.flops = conv_flops(a);
+    rec.cin = a.Cin_g * a.groups; rec.cout = a.Cout_g * a.groups; rec.k = a.ksize; rec.nout = a.Nout;
+    rec.stride = a.stride; rec.B = a.B;
     RVCX_HIP(hipEventRecord(rec.a, stream));
     if (launch_conv_fast(a, stream)) {
       RVCX_HIP(hipEventRecord(rec.b, stream));
@@ -244,6 +255,8 @@ void launch_conv(ConvArgs a, hipStream_t stream) {
     RVCX_HIP(hipEventCreate(&rec.b));
     rec.tile = best;
     rec.flops = conv_flops(a);
+    rec.cin = a.Cin_g * a.groups; rec.cout = a.Cout_g * a.groups; rec.k = a.ksize; rec.nout = a.Nout;
+    rec.stride = a.stride; rec.B = a.B;
     RVCX_HIP(hipEventRecord(rec.a, stream));
   }
   hipLaunchKernelGGL(T.kern, grid, dim3(256), lds, stream, best_a);

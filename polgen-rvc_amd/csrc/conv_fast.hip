@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int i = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / a.splitk, ks = blockIdx.z - b * a.splitk;
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
@@ -61,12 +61,14 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
   const float* Ap = As + h * BM + wr * (WM * 32) + i;
   const float* Bp = Bs + h * WROW + wc * (WN * 32) + i;
   const int nkk = (a.ksize + KKT - 1) / KKT;
-  const int nst = (a.Cin_gp / CIC) * nkk;
+  const int nci = a.Cin_gp / CIC;
+  const int cb0 = ks * nci / a.splitk, cb1 = (ks + 1) * nci / a.splitk;   // this split's ci chunks
+  const int nst = (cb1 - cb0) * nkk;
   const int len_m1 = max(len_in - 1, 0);
 
   // one flat loop over (ci chunk, tap chunk) stages; all staging loads are unconditional (clamped
   // addresses + select), so the loop body is straight-line code and the accumulators stay in AGPRs
-  int ci0 = 0, kk0 = 0;
+  int ci0 = cb0 * CIC, kk0 = 0;
   for (int st = 0; st < nst; ++st) {
     __syncthreads();
     if (kk0 == 0) {
@@ -129,6 +131,24 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+  if (a.splitk > 1) {
+    // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
+    float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int nn = nn_w + n * 32;
+        if (nn < a.Nout) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_w + m * 32 + (r & 3) + 8 * (r >> 2);
+            if (co < a.Cout_g) pb[(long)co * a.Nout + nn] = acc[m][n][r];
+          }
+        }
+      }
+    return;
+  }
   if (fast_epilogue_ok(a)) {
     store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
     if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
@@ -143,6 +163,20 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
       store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
       if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
     }
+  }
+}
+
+// sum the split-K partial slabs in a fixed order (deterministic) and run the fused epilogue
+__global__ void conv_splitk_finish_kernel(const ConvArgs a) {
+  const long per = (long)a.Cout_g * a.Nout, total = per * a.B;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int b = idx / per;
+    const long r = idx - (long)b * per;
+    const int co = r / a.Nout, nn = r - (long)co * a.Nout;
+    float v = 0.f;
+    for (int s = 0; s < a.splitk; ++s) v += a.part[((long)s * a.B + b) * per + r];
+    const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
+    store_elem(a, b, co, nn, v, len_out);
   }
 }
 
@@ -210,8 +244,22 @@ bool launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   const FastCfg& F = kFast[best];
   a.off_min = off_min;
   a.wrow = halo;
-  dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B);
+  // split-K when the output grid cannot fill the chip but K is long (small-N transformer / deep U-Net layers)
+  const long blocks = (long)cdiv(a.Nout, F.bn) * cdiv(a.Cout_gp, F.bm) * a.B;
+  const int nci = a.Cin_gp / F.cic;
+  int S = 1;
+  if (blocks < 384 && a.part) {
+    while (S < 8 && blocks * S * 2 <= 1024 && nci / (S * 2) >= 2) S *= 2;
+    if ((long)S * a.B * a.Cout_g * a.Nout > a.part_cap) S = 1;
+  }
+  a.splitk = S;
+  dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
   hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
+  if (S > 1) {
+    const long total = (long)a.B * a.Cout_g * a.Nout;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)std::min<long>(cdiv64(total, 256), 4096)), dim3(256), 0,
+                       stream, a);
+  }
   RVCX_HIP(hipGetLastError());
   return true;
 }

@@ -70,12 +70,16 @@ struct Ctx {
   std::unique_ptr<IndexData> index;
   Ctx();
   ~Ctx();
-  void conv(const ConvArgs& a) {
+  // split-K partial-sum scratch, one per stream (RMVPE and HuBERT run concurrently)
+  float* splitk_buf[2] = {nullptr, nullptr};
+  static constexpr long kSplitKFloats = 32L << 20;   // 128 MiB each
+  void conv(const ConvArgs& a) { conv_on(a, stream); }
+  void conv_on(ConvArgs a, hipStream_t s) {
     flops += conv_flops(a);
-    launch_conv(a, stream);
-  }
-  void conv_on(const ConvArgs& a, hipStream_t s) {
-    flops += conv_flops(a);
+    const int si = (s == stream2) ? 1 : 0;
+    if (!splitk_buf[si]) RVCX_HIP(hipMalloc(&splitk_buf[si], kSplitKFloats * sizeof(float)));
+    a.part = splitk_buf[si];
+    a.part_cap = kSplitKFloats;
     launch_conv(a, s);
   }
 };

@@ -69,6 +69,8 @@ Ctx::~Ctx() {
   if (timer.made)
     for (auto& e : timer.ev) (void)hipEventDestroy(e);
   if (dev_err) (void)hipFree(dev_err);
+  for (auto* p : splitk_buf)
+    if (p) (void)hipFree(p);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
   if (stream2) (void)hipStreamDestroy(stream2);
