@@ -56,6 +56,8 @@ int rvcx_create(int device, rvcx_ctx** out) {
     h->c.device = device;
     RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking));
     RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream2, hipStreamNonBlocking));
+    for (auto& s : h->c.aux) RVCX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (auto& e : h->c.ev_aux) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     conv_init();

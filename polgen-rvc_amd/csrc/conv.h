@@ -52,6 +52,7 @@ struct ConvArgs {
   // filled by the launcher
   int ci_chunk = 0, kk_chunk = 0, wrow = 0, off_min = 0;
   int splitk = 1;
+  int dbg = 0;                   // timing ablations only (RVCX_CONV_DBG): 1 skip weight staging, 2 skip input staging, 4 skip MFMAs
 };
 
 // tap offset of kernel element kk relative to n*stride (before subtracting off_min)

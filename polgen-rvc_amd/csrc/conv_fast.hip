@@ -10,6 +10,8 @@
 //   for ci0 in Cin step CIC:            stage X[ci0:ci0+CIC][n0+off_min : +BN+halo]      -> Bs[CIC][WROW]
 //     for kk0 in ksize step KKT:        stage Wp[kk0:kk0+KKT][ci0:ci0+CIC][co0:co0+BM]   -> As[KKT][CIC][BM]
 //       for kkl, cp (unrolled):         A frag As[kkl][2cp+h][wm+i], B frag Bs[2cp+h][wn+i+tap(kk)] -> MFMA
+#include <cstdlib>
+
 #include "conv.h"
 #include "conv_device.h"
 
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
   int ci0 = cb0 * CIC, kk0 = 0;
   for (int st = 0; st < nst; ++st) {
     __syncthreads();
-    if (kk0 == 0) {
+    if (kk0 == 0 && !((a.dbg & 2) && st > 0)) {
       // ---- input tile: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction
 #pragma unroll
       for (int rr = 0; rr < CIC / 4; ++rr) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
         }
       }
     }
-    {
+    if (!((a.dbg & 1) && st > 0)) {
       const float* wbase = a.w + (long)ci0 * a.Cout_gp;
 #pragma unroll
       for (int j = 0; j < NA4; ++j) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
 #pragma unroll
     for (int kkl = 0; kkl < KKT; ++kkl) {
       const int kk = kk0 + kkl;
-      if (KKT == 1 || kk < a.ksize) {
+      if ((KKT == 1 || kk < a.ksize) && !(a.dbg & 4)) {
         const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
         const float* Bt = Bp + tp;
 #pragma unroll
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+  if (a.dbg & 8) return;
   if (a.splitk > 1) {
     // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
     float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
@@ -253,6 +256,11 @@ bool launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     if ((long)S * a.B * a.Cout_g * a.Nout > a.part_cap) S = 1;
   }
   a.splitk = S;
+  {
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("RVCX_CONV_DBG") ? atoi(getenv("RVCX_CONV_DBG")) : 0;
+    a.dbg = dbg;
+  }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
   hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) {

@@ -55,6 +55,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second stream: RMVPE runs beside HuBERT
+  hipStream_t aux[2] = {nullptr, nullptr};   // the three ResBlocks of an NSF stage run side by side
+  hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Arena arena;
   WeightSlab slab;
@@ -71,12 +73,12 @@ struct Ctx {
   Ctx();
   ~Ctx();
   // split-K partial-sum scratch, one per stream (RMVPE and HuBERT run concurrently)
-  float* splitk_buf[2] = {nullptr, nullptr};
+  float* splitk_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   static constexpr long kSplitKFloats = 32L << 20;   // 128 MiB each
   void conv(const ConvArgs& a) { conv_on(a, stream); }
   void conv_on(ConvArgs a, hipStream_t s) {
     flops += conv_flops(a);
-    const int si = (s == stream2) ? 1 : 0;
+    const int si = (s == stream2) ? 1 : (s == aux[0] ? 2 : (s == aux[1] ? 3 : 0));
     if (!splitk_buf[si]) RVCX_HIP(hipMalloc(&splitk_buf[si], kSplitKFloats * sizeof(float)));
     a.part = splitk_buf[si];
     a.part_cap = kSplitKFloats;

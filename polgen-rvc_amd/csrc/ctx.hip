@@ -73,6 +73,10 @@ Ctx::~Ctx() {
     if (p) (void)hipFree(p);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
+  for (auto e : ev_aux)
+    if (e) (void)hipEventDestroy(e);
+  for (auto s : aux)
+    if (s) (void)hipStreamDestroy(s);
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }

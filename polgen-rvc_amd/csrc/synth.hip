@@ -151,7 +151,7 @@ size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
     mx = std::max(mx, n);
     sum += n + 1024;
   }
-  return (enc + dec + sum + 3 * mx) * sizeof(float) + ((size_t)64 << 20);
+  return (enc + dec + sum + 9 * mx) * sizeof(float) + ((size_t)64 << 20);
 }
 
 namespace {
@@ -327,8 +327,13 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
     float* xs = A.alloc<float>(n);      // survives the stage (next stage's input)
     const size_t stage_mark = A.mark();
     float* xu = A.alloc<float>(n);
-    float* xc = A.alloc<float>(n);
-    float* xt = A.alloc<float>(n);
+    const int nk = cf.n_resblocks;
+    float* xcb[4];
+    float* xtb[4];
+    for (int j = 0; j < nk; ++j) {
+      xcb[j] = A.alloc<float>(n);
+      xtb[j] = A.alloc<float>(n);
+    }
     const int* lin = lens_stage[i];
     const int* lout = lens_stage[i + 1];
     ConvArgs a = convT1d_args(S.up, cur, xu, B, (int)Tin, (int)Tout);
@@ -343,11 +348,19 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
     a.lens_in = lens_stage[m.stages.size()];
     a.lens_out = lout;
     c.conv(a);
-    // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53)
-    const int nk = cf.n_resblocks;
+    // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
+    // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases
+    // interleave on the CUs instead of marching in lockstep.  Only the running sum xs is ordered
+    // (SET -> ADD -> ADD_DIV) through events.
+    hipStream_t rs[4] = {s, c.aux[0], c.aux[1], s};
+    RVCX_HIP(hipEventRecord(c.ev_aux[0], s));
+    for (int j = 1; j < nk && j < 3; ++j) RVCX_HIP(hipStreamWaitEvent(rs[j], c.ev_aux[0], 0));
     for (int j = 0; j < nk; ++j) {
+      hipStream_t sj = rs[j];
       const int k = cf.res_kernels[j];
       const float* xin = xu;
+      float* xc = xcb[j];
+      float* xt = xtb[j];
       for (int mi = 0; mi < 3; ++mi) {
         const int d = cf.res_dilations[j][mi];
         a = conv1d_args(S.c1[j][mi], xin, xt, B, (int)Tout, (int)Tout, 1, d, (k * d - d) / 2);
@@ -357,7 +370,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
         a.act_slope = 0.1f;
         a.lens_in = lout;
         a.lens_out = lout;
-        c.conv(a);
+        c.conv_on(a, sj);
         a = conv1d_args(S.c2[j][mi], xt, xc, B, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
         conv_set_res(a, xin, S.ch, (int)Tout);
         a.lens_in = lout;
@@ -370,11 +383,14 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
           a.acc2_mode = j == 0 ? ACC2_SET : (j == nk - 1 ? ACC2_ADD_DIV : ACC2_ADD);
           a.acc2_div = (float)nk;
           if (nk == 1) a.acc2_mode = ACC2_SET;
+          if (j > 0) RVCX_HIP(hipStreamWaitEvent(sj, c.ev_aux[j], 0));   // xs of block j-1 is complete
         }
-        c.conv(a);
+        c.conv_on(a, sj);
+        if (mi == 2) RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
         xin = xc;
       }
     }
+    if (rs[nk - 1] != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_aux[nk], 0));   // join before the next stage
     cur = xs;
     Tin = Tout;
     A.reset(stage_mark);
