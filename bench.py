@@ -65,6 +65,25 @@ def cpu_baseline():
             "sample": f"one {CPU_SAMPLE_SECONDS:.0f} s clip of the same workload (oracle/pipeline.py, torch-CPU fp32)"}
 
 
+def pmc_traffic(tile_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE are separate profiler runs of this same command; bench.py cannot collect them itself)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
+    if not os.path.exists(path):
+        return None, None
+    m = re.match(r"conv_fast_(sb|db)<(\d+),(\d+),(halo(\d+)|linear)>", tile_name)
+    if not m:
+        return None, None
+    fn = "conv_fast_sb_kernel" if m.group(1) == "sb" else "conv_fast_kernel"
+    want = f"{fn}<{m.group(2)}, {m.group(3)},"
+    tail = ", 32, 0>" if m.group(4) == "linear" else f", 16, {m.group(5)}>"
+    for k, v in json.load(open(path))["kernels"].items():
+        if want in k and tail in k:
+            return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,8 +148,10 @@ def main():
     conv_ms = sum(r["ms"] for r in prof)
     conv_flops = sum(r["flops"] for r in prof)
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": f"conv_mfma_kernel<{dom['tile']}>", "achieved": achieved,
-                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+    traffic, traffic_src = pmc_traffic(dom["tile"])
+    roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
+                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                 "flops_per_launch": dom["flops"] / dom["launches"],
                 "family": {"ms": conv_ms, "tflops": conv_flops / (conv_ms * 1e-3) / 1e12,

@@ -143,10 +143,11 @@ int rvcx_get_f0(rvcx_ctx*, const float* wav16k_hd, int64_t n, const rvcx_params*
 int rvcx_last_timing(rvcx_ctx*, float* ms9);
 /* HIP-event profile of the MFMA conv kernel family: begin=1 starts recording an event pair around
  * every conv launch on the library stream; begin=0 stops and returns, per tile configuration
- * (<= 8 entries), the launch count, algorithmic FLOPs (2*M*N*K of the unpadded problem) and the
+ * (<= 40 entries; kind: -1 generic strided kernel, halo*10+{0 single-buffered, 1 LDS-DMA} for the stride-1
+ * family, 100000/100001 its Linear variants), the launch count, algorithmic FLOPs (2*M*N*K of the unpadded problem) and the
  * summed kernel milliseconds, plus the tile shape (bm x bn). */
 int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
-                      int32_t* bn, int cap);
+                      int32_t* bn, int32_t* kind, int cap);
 /* per-launch table (CSV text: tile,B,cin,cout,k,stride,nout,gflop,ms,tflops) of the last profile */
 const char* rvcx_conv_profile_csv(rvcx_ctx*);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */

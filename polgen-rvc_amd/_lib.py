@@ -399,15 +399,23 @@ class Context:
         return ptr.value, n.value
 
     def conv_profile_begin(self):
-        z = (C.c_int64 * 8)()
-        self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, 0), "conv_profile")
+        z = (C.c_int64 * 40)()
+        self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, None, 0), "conv_profile")
 
     def conv_profile_end(self):
-        la, fl, ms = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
-        bm, bn = (C.c_int32 * 8)(), (C.c_int32 * 8)()
-        self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, 8), "conv_profile")
-        return [dict(tile=f"{bm[i]}x{bn[i]}", launches=int(la[i]), flops=float(fl[i]), ms=float(ms[i]))
-                for i in range(8) if la[i] > 0]
+        N = 40
+        la, fl, ms = (C.c_int64 * N)(), (C.c_double * N)(), (C.c_double * N)()
+        bm, bn, kd = (C.c_int32 * N)(), (C.c_int32 * N)(), (C.c_int32 * N)()
+        self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, kd, N), "conv_profile")
+
+        def name(i):
+            if kd[i] < 0:
+                return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
+            if kd[i] >= 100000:
+                return f"conv_fast{'_db' if kd[i] % 10 else '_sb'}<{bm[i]},{bn[i]},linear>"
+            return f"conv_fast{'_db' if kd[i] % 10 else '_sb'}<{bm[i]},{bn[i]},halo{kd[i] // 10}>"
+        return [dict(tile=name(i), launches=int(la[i]), flops=float(fl[i]), ms=float(ms[i]))
+                for i in range(N) if la[i] > 0]
 
     def conv_profile_csv(self) -> str:
         return (lib().rvcx_conv_profile_csv(self._h) or b"").decode()

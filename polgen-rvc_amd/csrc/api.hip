@@ -1,6 +1,8 @@
 // C ABI of librvcx.so (include/rvcx.h).  Nothing throws across this boundary.
 #include "../../include/rvcx.h"
 
+#include <cstdlib>
+
 #include "ctx.h"
 #include "layers.h"
 #include "models.h"
@@ -61,6 +63,7 @@ int rvcx_create(int device, rvcx_ctx** out) {
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     conv_init();
+    h->c.resblock_streams = getenv("RVCX_RESBLOCK_STREAMS") && atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
     RVCX_HIP(hipMalloc(&h->c.dev_err, sizeof(int)));
     RVCX_HIP(hipMemset(h->c.dev_err, 0, sizeof(int)));
     h->c.arena.reserve((size_t)256 << 20);
@@ -608,8 +611,9 @@ int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params
 }
 
 int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
-                      int32_t* bn, int cap) {
+                      int32_t* bn, int32_t* kind, int cap) {
   API_BEGIN(ctx)
+  C->serial = begin != 0;
   if (begin) {
     conv_profile_begin();
   } else {
@@ -621,6 +625,7 @@ int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops
       ms[t] = p.ms[t];
       bm[t] = p.bm[t];
       bn[t] = p.bn[t];
+      kind[t] = p.halo[t];
     }
   }
   API_END

@@ -61,18 +61,19 @@ inline int conv_tap_off(const ConvArgs& a, int kk) {
 }
 
 struct ConvProfile {
-  static constexpr int kMaxTiles = 8;
+  static constexpr int kMaxTiles = 40;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
   long launches[kMaxTiles] = {0};
   double flops[kMaxTiles] = {0};
   double ms[kMaxTiles] = {0};
-  int bm[kMaxTiles] = {0}, bn[kMaxTiles] = {0};
+  int bm[kMaxTiles] = {0}, bn[kMaxTiles] = {0}, halo[kMaxTiles] = {0};
 };
 void conv_profile_begin();                          // start recording one event pair per conv launch
 void conv_profile_end(ConvProfile* out);            // sync, accumulate, stop
 const char* conv_profile_csv();                     // per-launch table of the last profile (CSV text)
 void conv_init();                                   // raise dynamic-LDS limits once
 void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + tile, launches
-bool launch_conv_fast(ConvArgs& a, hipStream_t stream);   // stride-1 compile-time-tiled family; false = not applicable
+int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-time-tiled family; profile slot or -1
+void conv_fast_describe(ConvProfile* p);
 void conv_fast_init();
 double conv_flops(const ConvArgs& a);               // 2*M*N*K of the *real* (unpadded) problem
 

@@ -189,7 +189,9 @@ void conv_profile_end(ConvProfile* out) {
   for (int t = 0; t < kNumTiles; ++t) {
     out->bm[t] = kTiles[t].bm;
     out->bn[t] = kTiles[t].bn;
+    out->halo[t] = -1;
   }
+  conv_fast_describe(out);
   for (auto& r : g_prof) {
     RVCX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -214,19 +216,21 @@ void launch_conv(ConvArgs a, hipStream_t stream) {
     ProfRec rec;
     RVCX_HIP(hipEventCreate(&rec.a));
     RVCX_HIP(hipEventCreate(&rec.b));
-    rec.tile = ConvProfile::kMaxTiles - 1;
+    rec.tile = 0;
     rec.flops = conv_flops(a);
     rec.cin = a.Cin_g * a.groups; rec.cout = a.Cout_g * a.groups; rec.k = a.ksize; rec.nout = a.Nout;
     rec.stride = a.stride; rec.B = a.B;
     RVCX_HIP(hipEventRecord(rec.a, stream));
-    if (launch_conv_fast(a, stream)) {
+    const int slot = launch_conv_fast(a, stream);
+    if (slot >= 0) {
+      rec.tile = slot;
       RVCX_HIP(hipEventRecord(rec.b, stream));
       g_prof.push_back(rec);
       return;
     }
     (void)hipEventDestroy(rec.a);
     (void)hipEventDestroy(rec.b);
-  } else if (launch_conv_fast(a, stream)) {
+  } else if (launch_conv_fast(a, stream) >= 0) {
     return;
   }
   int best = -1;

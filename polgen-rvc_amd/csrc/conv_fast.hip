@@ -427,8 +427,18 @@ constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
 void conv_fast_init() {}
 
-bool launch_conv_fast(ConvArgs& a, hipStream_t stream) {
-  if (a.stride != 1 || a.groups != 1 || a.Cin_gp % 16 != 0) return false;
+void conv_fast_describe(ConvProfile* p) {
+  for (int t = 0; t < kNumFast; ++t)
+    for (int v = 0; v < 2; ++v) {
+      const int s = 8 + 16 * v + t;
+      p->bm[s] = kFast[t].bm;
+      p->bn[s] = kFast[t].bn;
+      p->halo[s] = kFast[t].cic == 32 ? 100000 + v : kFast[t].halo * 10 + v;
+    }
+}
+
+int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
+  if (a.stride != 1 || a.groups != 1 || a.Cin_gp % 16 != 0) return -1;
   int off_min = 1 << 30, off_max = -(1 << 30);
   for (int kk = 0; kk < a.ksize; ++kk) {
     const int o = conv_tap_off(a, kk);
@@ -456,7 +466,7 @@ bool launch_conv_fast(ConvArgs& a, hipStream_t stream) {
       best = t;
     }
   }
-  if (best < 0) return false;
+  if (best < 0) return -1;
   const FastCfg& F = kFast[best];
   a.off_min = off_min;
   a.wrow = halo;
@@ -484,7 +494,7 @@ bool launch_conv_fast(ConvArgs& a, hipStream_t stream) {
                        stream, a);
   }
   RVCX_HIP(hipGetLastError());
-  return true;
+  return 8 + (use_db ? 16 : 0) + best;
 }
 
 }  // namespace rvcx

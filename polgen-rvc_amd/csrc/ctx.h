@@ -62,6 +62,8 @@ struct Ctx {
   WeightSlab slab;
   std::string last_error;
   double flops = 0.0;
+  bool resblock_streams = false;  // run the ResBlocks of an NSF stage on 3 streams
+  bool serial = false;            // profiling: keep every launch on the main stream (true per-kernel times)
   int* dev_err = nullptr;         // device flag: a kernel gave up waiting (checked after each API call)
   void check_dev_err();
   float timing[9] = {0};

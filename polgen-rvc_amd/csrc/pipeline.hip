@@ -403,12 +403,13 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
   float* f0 = A.alloc<float>((size_t)p_len + 8);
   // F0 runs on the second stream beside HuBERT (they only share the padded signal); its arena region
   // stays allocated until the streams join, so nothing on the main stream can recycle it underneath
+  hipStream_t sf = c.serial ? s : c.stream2;
   RVCX_HIP(hipEventRecord(c.ev_fork, s));
-  RVCX_HIP(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
-  const int r0 = clk.mark(c.stream2);
-  get_f0_device(c, apad, n_pad, p, coarse, f0, c.stream2);
-  const int r1 = clk.mark(c.stream2);
-  RVCX_HIP(hipEventRecord(c.ev_join, c.stream2));
+  RVCX_HIP(hipStreamWaitEvent(sf, c.ev_fork, 0));
+  const int r0 = clk.mark(sf);
+  get_f0_device(c, apad, n_pad, p, coarse, f0, sf);
+  const int r1 = clk.mark(sf);
+  RVCX_HIP(hipEventRecord(c.ev_join, sf));
   bool joined = false;
   const int e2 = clk.mark(s);
   // ---- 4. per-chunk vc() (pipeline.py:203-287)
