@@ -375,7 +375,7 @@ int rvcx_op_attention(rvcx_ctx* ctx, const float* q, const float* k, const float
                       const int32_t* lens) {
   API_BEGIN(ctx)
   const size_t n = (size_t)B * H * D * T;
-  C->arena.reserve(n * 16 + attention_scratch_floats(B, H, T, window) * 4 + (64 << 20));
+  C->arena.reserve(n * 16 + (attention_scratch_floats(B, H, T, window) + attention_split_floats(B, H, T)) * 4 + (64 << 20));
   C->arena.reset();
   float *dq = to_dev(*C, q, n), *dk = to_dev(*C, k, n), *dv = to_dev(*C, v, n);
   float* dout = C->arena.alloc<float>(n);
@@ -386,7 +386,7 @@ int rvcx_op_attention(rvcx_ctx* ctx, const float* q, const float* k, const float
     scratch = C->arena.alloc<float>(attention_scratch_floats(B, H, T, window));
   }
   launch_attention(dq, dk, dv, dout, B, H, D, T, T, (long)H * D * T, (long)H * D * T, scale, ek, ev, window,
-                   to_dev_i(*C, lens, B), scratch, C->stream);
+                   to_dev_i(*C, lens, B), scratch, C->arena.alloc<float>(attention_split_floats(B, H, T)), C->stream);
   to_host(*C, out, dout, n);
   C->arena.reset();
   API_END

@@ -22,13 +22,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
                                                    float* __restrict__ m_out, float* __restrict__ l_out,
                                                    const float* __restrict__ relq, int H, int D, int T,
                                                    int ld, long in_bs, long out_bs, float scale, int window,
-                                                   const int* lens) {
+                                                   const int* lens, int nsplit, float* opart) {
   __shared__ float Ks[32 * DT * KT];
   __shared__ float Vs[32 * DT * VROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qblk = blockIdx.x / nsplit, split = blockIdx.x - qblk * nsplit;
+  const int q0 = qblk * 128 + wave * 32;
   const int len = lens ? lens[b] : T;
   const long base = (long)b * in_bs + (long)hd * D * ld;
   const long obase = (long)b * out_bs + (long)hd * D * ld;
@@ -56,7 +57,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
   const int nrel = 2 * window + 1;
   const float* relrow = relq ? relq + (((long)b * H + hd) * T + min(qi, T - 1)) * nrel : nullptr;
 
-  for (int k0 = 0; k0 < len; k0 += KT) {
+  // split-KV: this workgroup covers keys [klo, khi) (whole 32-key tiles); partial (O, m, l) are merged later
+  const int tiles = (len + KT - 1) / KT;
+  const int klo = (int)((long)tiles * split / nsplit) * KT;
+  const int khi = min(len, (int)((long)tiles * (split + 1) / nsplit) * KT);
+  for (int k0 = klo; k0 < khi; k0 += KT) {
     __syncthreads();
     // ---- stage K [D][32] and V [D][33] tiles (zero beyond D / len)
     for (int idx = tid; idx < 32 * DT * KT; idx += 256) {
@@ -125,6 +130,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
     }
   }
   // ---- normalise and store (coalesced along queries)
+  if (nsplit > 1) {
+    // partial results: opart[((b*H+hd)*nsplit + split)][DP+2][T]  (rows 0..D-1: unnormalised O, then m, l)
+    if (qi < T) {
+      const int DP = 32 * DT;
+      float* pb = opart + (((long)b * H + hd) * nsplit + split) * (DP + 2) * T;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          pb[(long)d * T + qi] = acc_o[dt][r];
+        }
+      if (h == 0) {
+        pb[(long)DP * T + qi] = m_run;
+        pb[(long)(DP + 1) * T + qi] = l_run;
+      }
+    }
+    return;
+  }
   if (qi < T) {
     const float inv = 1.f / l_run;
     float* ob = out + obase;
@@ -139,6 +163,37 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
       m_out[((long)b * H + hd) * T + qi] = m_run;
       l_out[((long)b * H + hd) * T + qi] = l_run;
     }
+  }
+}
+
+// merge the split-KV partials: out = sum_s e^(m_s - m) O_s / sum_s e^(m_s - m) l_s
+__global__ void attn_merge_kernel(const float* __restrict__ opart, float* __restrict__ out, float* m_out,
+                                  float* l_out, int H, int D, int DP, int T, int ld, long out_bs, int nsplit,
+                                  const int* lens) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* pb = opart + (((long)b * H + hd) * nsplit) * (DP + 2) * T;
+  const long ss = (long)(DP + 2) * T;
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pb[s * ss + (long)DP * T + t]);
+  float w[8], l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float ms = pb[s * ss + (long)DP * T + t];
+    w[s] = (ms == -INFINITY) ? 0.f : expf(ms - m);
+    l += w[s] * pb[s * ss + (long)(DP + 1) * T + t];
+  }
+  const int len = lens ? lens[b] : T;
+  const float inv = 1.f / l;
+  float* ob = out + (long)b * out_bs + (long)hd * D * ld;
+  for (int d = part; d < D; d += 4) {
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += w[s] * pb[s * ss + (long)d * T + t];
+    ob[(long)d * ld + t] = t < len ? acc * inv : 0.f;
+  }
+  if (m_out && part == 0) {
+    m_out[((long)b * H + hd) * T + t] = m;
+    l_out[((long)b * H + hd) * T + t] = l;
   }
 }
 
@@ -214,7 +269,7 @@ __global__ __launch_bounds__(256) void rel_values_kernel(const float* __restrict
 
 void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
                       int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
-                      const int* lens, float* scratch, hipStream_t stream) {
+                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream) {
   RVCX_CHECK(D % 2 == 0 && D <= 96, "attention: head dim must be even and <= 96");
   const int nrel = 2 * window + 1;
   float *relq = nullptr, *mb = nullptr, *lb = nullptr;
@@ -226,17 +281,31 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
     hipLaunchKernelGGL(rel_logits_kernel, dim3(cdiv(T, 128), H, B), dim3(128), nrel * D * sizeof(float), stream,
                        q, emb_rel_k, relq, H, D, T, ld, in_bs, scale, nrel);
   }
-  dim3 grid(cdiv(T, 128), H, B);
   const int DT = cdiv(D, 32);
+  // split the key range over several workgroups when the (query block, head, batch) grid is too small
+  const long blocks = (long)cdiv(T, 128) * H * B;
+  int nsplit = 1;
+  while (nsplit < 8 && blocks * nsplit < 384 && T / (nsplit * 2) >= 256) nsplit *= 2;
+  float* opart = nullptr;
+  if (nsplit > 1) {
+    if (split_scratch) opart = split_scratch;
+    else nsplit = 1;
+  }
+  float* mo = nsplit > 1 ? nullptr : mb;
+  float* lo = nsplit > 1 ? nullptr : lb;
+  dim3 grid(cdiv(T, 128) * nsplit, H, B);
   if (DT == 1)
-    hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mb, lb, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens);
+    hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens, nsplit, opart);
   else if (DT == 2)
-    hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mb, lb, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens);
+    hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens, nsplit, opart);
   else
-    hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mb, lb, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens);
+    hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens, nsplit, opart);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(T, 64), H, B), dim3(256), 0, stream, opart, out, mb, lb, H, D,
+                       32 * DT, T, ld, out_bs, nsplit, lens);
   if (emb_rel_v) {
     size_t lds = ((size_t)nrel * D + 64 * (nrel + 1)) * sizeof(float);
     hipLaunchKernelGGL(rel_values_kernel, dim3(cdiv(T, 64), H, B), dim3(256), lds, stream, q, k, relq, mb, lb,
@@ -248,6 +317,9 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
 size_t attention_scratch_floats(int B, int H, int T, int window) {
   return (size_t)B * H * T * (2 * window + 1) + 2 * (size_t)B * H * T;
 }
+
+// scratch for the split-KV partials (worst case 8 splits, head dim padded to 96, + m and l rows)
+size_t attention_split_floats(int B, int H, int T) { return (size_t)B * H * 8 * 98 * T; }
 
 double attention_flops(int B, int H, int D, int T) { return 4.0 * B * H * (double)T * T * D; }
 

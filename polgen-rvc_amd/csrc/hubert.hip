@@ -76,7 +76,7 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
   const int64_t t0 = (n - m.cfg.conv_kernels[0]) / m.cfg.conv_strides[0] + 1;
   const int T = hubert_frames(m, n);
   size_t conv = 2 * (size_t)m.cfg.conv_dim * t0;
-  size_t enc = (size_t)T * (size_t)(6 * m.cfg.embed_dim + m.cfg.ffn_dim + 64);
+  size_t enc = (size_t)T * (size_t)(6 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + 8 * 98 * m.cfg.heads);
   return (size_t)B * (conv + enc) * sizeof(float) + ((size_t)64 << 20);
 }
 
@@ -127,6 +127,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
   float* qkv = A.alloc<float>((size_t)B * 3 * E * T);
   float* att = A.alloc<float>((size_t)B * E * T);
   float* ff = A.alloc<float>((size_t)B * cf.ffn_dim * T);
+  float* asplit = A.alloc<float>(attention_split_floats(B, cf.heads, T));
   const int hd = E / cf.heads;
   const float scale = 1.f / std::sqrt((float)hd);
   const int nl = std::min(output_layer, cf.layers);
@@ -135,7 +136,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     ConvArgs a = conv1d_args(L.qkv, h, qkv, B, T, T);
     c.conv_on(a, s);
     launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T,
-                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, s);
+                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s);
     c.flops += attention_flops(B, cf.heads, hd, T);
     a = conv1d_args(L.o, att, h2, B, T, T);
     conv_set_res(a, h, E, T);

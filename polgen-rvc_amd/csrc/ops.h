@@ -7,8 +7,9 @@ namespace rvcx {
 // ---- attention.hip
 void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
                       int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
-                      const int* lens, float* scratch, hipStream_t stream);
+                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream);
 size_t attention_scratch_floats(int B, int H, int T, int window);
+size_t attention_split_floats(int B, int H, int T);
 double attention_flops(int B, int H, int D, int T);
 
 // ---- gru.hip

@@ -141,7 +141,7 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
 size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
   const auto& cf = m.cfg;
   size_t enc = (size_t)B * T * (size_t)(cf.input_dim + 8 * cf.hidden_channels + 2 * cf.filter_channels +
-                                        4 * cf.inter_channels + 64);
+                                        4 * cf.inter_channels + 64 + 8 * 98 * cf.n_heads);
   size_t dec = (size_t)B * T * m.upp * 3;  // har, noise, out
   size_t mx = 0, sum = (size_t)B * T * cf.up_initial_channel;
   long tt = T;
@@ -221,12 +221,13 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
   float* tmp = A.alloc<float>((size_t)B * hid * T);
   float* hbuf = A.alloc<float>((size_t)B * filt * T);
   float* scratch = A.alloc<float>(attention_scratch_floats(B, heads, T, 10));
+  float* asplit = A.alloc<float>(attention_split_floats(B, heads, T));
   const float scale = 1.f / std::sqrt((float)kc);
   for (const auto& L : m.enc) {
     ConvArgs a = conv1d_args(L.qkv, x, qkv, B, T, T);
     c.conv(a);
     launch_attention(qkv, qkv + (size_t)hid * T, qkv + (size_t)2 * hid * T, att, B, heads, kc, T, T,
-                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, s);
+                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, asplit, s);
     c.flops += attention_flops(B, heads, kc, T);
     a = conv1d_args(L.o, att, tmp, B, T, T);
     conv_set_res(a, x, hid, T);
