@@ -86,7 +86,7 @@ __device__ __forceinline__ void store_tile_fast(const ConvArgs& a, int b, int co
   const float slope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : a.act_slope);
   const bool live = nn < len_out;
   float* yb = a.y ? a.y + (long)b * a.y_bs + nn : nullptr;
-  const float* rb = (a.res && !(a.dbg & 16)) ? a.res + (long)b * a.res_bs + nn : nullptr;
+  const float* rb = a.res ? a.res + (long)b * a.res_bs + nn : nullptr;
   float* y2b = a.acc2_mode != ACC2_NONE ? a.y2 + (long)b * a.y2_bs + nn : nullptr;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {

@@ -15,6 +15,14 @@
 #include "conv.h"
 #include "conv_device.h"
 
+// timing ablations (RVCX_CONV_DBG=<mask>) are compiled in only with -DRVCX_ABLATION: even uniform
+// branches in the unrolled k-loop cost the small-channel layers ~15 %
+#ifdef RVCX_ABLATION
+#define RVCX_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define RVCX_DBG(a, bit) 0
+#endif
+
 namespace rvcx {
 
 // LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base) + lane*SIZE.
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
 #pragma unroll
     for (int kkl = 0; kkl < KKT; ++kkl) {
       const int kk = kk0 + kkl;
-      if ((KKT == 1 || kk < a.ksize) && !(a.dbg & 4)) {
+      if ((KKT == 1 || kk < a.ksize) && !RVCX_DBG(a, 4)) {
         const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
         const float* Bt = Bp + tp;
 #pragma unroll
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
-  if (a.dbg & 8) return;
+  if (RVCX_DBG(a, 8)) return;
   if (a.splitk > 1) {
     // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
     float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
   int ci0 = cb0 * CIC, kk0 = 0;
   for (int st = 0; st < nst; ++st) {
     __syncthreads();
-    if (kk0 == 0 && !((a.dbg & 2) && st > 0)) {
+    if (kk0 == 0 && !(RVCX_DBG(a, 2) && st > 0)) {
       // ---- input tile: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction
 #pragma unroll
       for (int rr = 0; rr < CIC / 4; ++rr) {
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
         }
       }
     }
-    if (!((a.dbg & 1) && st > 0)) {
+    if (!(RVCX_DBG(a, 1) && st > 0)) {
       const float* wbase = a.w + (long)ci0 * a.Cout_gp;
 #pragma unroll
       for (int j = 0; j < NA4; ++j) {
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
 #pragma unroll
     for (int kkl = 0; kkl < KKT; ++kkl) {
       const int kk = kk0 + kkl;
-      if ((KKT == 1 || kk < a.ksize) && !(a.dbg & 4)) {
+      if ((KKT == 1 || kk < a.ksize) && !RVCX_DBG(a, 4)) {
         const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
         const float* Bt = Bp + tp;
 #pragma unroll
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
-  if (a.dbg & 8) return;
+  if (RVCX_DBG(a, 8)) return;
   if (a.splitk > 1) {
     // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
     float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
