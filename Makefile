@@ -7,7 +7,7 @@ OUT   := polgen-rvc_amd/librvcx.so
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 HDRS  := $(wildcard $(CSRC)/*.h) include/rvcx.h
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-result
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-result $(EXTRA)
 
 all: $(OUT)
 

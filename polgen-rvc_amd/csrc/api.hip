@@ -166,6 +166,13 @@ int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, i
   a.pre_act = ACT_LRELU;
   a.pre_slope = 0.1f;
   C->conv(a);
+  long long* dtrace = nullptr;
+  const long ntrace = 1L << 16;
+  if (getenv("RVCX_TRACE")) {
+    RVCX_HIP(hipMalloc(&dtrace, ntrace * 6 * sizeof(long long)));
+    RVCX_HIP(hipMemset(dtrace, 0, ntrace * 6 * sizeof(long long)));
+    a.trace = dtrace;
+  }
   hipEvent_t e0, e1;
   RVCX_HIP(hipEventCreate(&e0));
   RVCX_HIP(hipEventCreate(&e1));
@@ -176,6 +183,15 @@ int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, i
   float ms = 0.f;
   RVCX_HIP(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = ms / iters;
+  if (dtrace) {
+    std::vector<long long> ht((size_t)ntrace * 6);
+    RVCX_HIP(hipMemcpy(ht.data(), dtrace, ht.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    FILE* f = fopen(getenv("RVCX_TRACE"), "w");
+    for (long i = 0; i < ntrace; ++i)
+      if (ht[i * 6 + 5]) fprintf(f, "%ld,%lld,%lld,%lld,%lld,%lld,%lld\n", i, ht[i*6], ht[i*6+1], ht[i*6+2], ht[i*6+3], ht[i*6+4], ht[i*6+5]);
+    fclose(f);
+    (void)hipFree(dtrace);
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   C->arena.reset();

@@ -45,7 +45,7 @@ __device__ __forceinline__ void wait_all_memory() {
 }
 
 template <int BM, int BN, int WR, int WC, int KKT, int CIC, int HALO>
-__global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_fast_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
   constexpr int WROW = BN + HALO;
   constexpr int A_FLOATS = KKT * CIC * BM;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvArgs a) {
 // resident workgroups): better for the long-sequence NSF layers where 3-5 co-resident blocks already
 // hide the staging latency.
 template <int BM, int BN, int WR, int WC, int KKT, int CIC, int HALO>
-__global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
   constexpr int WROW = BN + HALO;
   constexpr int A_FLOATS = KKT * CIC * BM;
@@ -252,6 +252,10 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
   const int wr = wave / WC, wc = wave % WC;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z / a.splitk, ks = blockIdx.z - b * a.splitk;
+#ifdef RVCX_ABLATION
+  long long tr0 = 0, tr1 = 0, tr2 = 0;
+  if (a.trace && tid == 0) tr0 = wall_clock64();
+#endif
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
@@ -323,6 +327,9 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
       }
     }
     __syncthreads();
+#ifdef RVCX_ABLATION
+    if (a.trace && tid == 0 && st == 0) tr1 = wall_clock64();
+#endif
 #pragma unroll
     for (int kkl = 0; kkl < KKT; ++kkl) {
       const int kk = kk0 + kkl;
@@ -353,6 +360,9 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+#ifdef RVCX_ABLATION
+  if (a.trace && tid == 0) tr2 = wall_clock64();
+#endif
   if (RVCX_DBG(a, 8)) return;
   if (a.splitk > 1) {
     // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
@@ -379,6 +389,19 @@ __global__ __launch_bounds__(256) void conv_fast_sb_kernel(const ConvArgs a) {
       store_tile_fast(a, b, co_w + 32, nn_w, acc[1][0], len_out);
       if constexpr (WN > 1) store_tile_fast(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
     }
+#ifdef RVCX_ABLATION
+    if (a.trace && tid == 0) {
+      __builtin_amdgcn_s_waitcnt(0);
+      const long lin = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+      long long* tp = a.trace + lin * 6;
+      tp[0] = __builtin_amdgcn_s_getreg(63492);               // HW_REG_HW_ID
+      tp[1] = __builtin_amdgcn_s_getreg((20) | (31 << 11));   // HW_REG_XCC_ID
+      tp[2] = tr0;
+      tp[3] = tr1;
+      tp[4] = tr2;
+      tp[5] = wall_clock64();
+    }
+#endif
   } else {
     store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
     if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
