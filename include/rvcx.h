@@ -164,6 +164,10 @@ int rvcx_op_conv1d(rvcx_ctx*, const float* x, const float* w, const float* bias,
  * y = conv1d(lrelu(x)) + bias + res, average milliseconds per launch (HIP events on the library stream) */
 int rvcx_bench_conv1d(rvcx_ctx*, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
                       int iters, float* ms_per_launch);
+/* tuning hook for the tile-selection sweep (tools/sweep_conv.py): force the conv_fast tile index, the
+ * staging variant (0 register-staged, 1 LDS-DMA double-buffered) and the split-K factor; -1 = heuristic.
+ * Process-wide; never set by the product path. */
+int rvcx_conv_override(int tile, int variant, int splitk);
 /* ConvTranspose1d: w (Cin,Cout,K), padding p; Tout = (Tin-1)*s - 2p + K */
 int rvcx_op_convtranspose1d(rvcx_ctx*, const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int Tin, int Cout, int K, int stride, int pad,

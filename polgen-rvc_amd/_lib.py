@@ -62,7 +62,7 @@ SYMBOLS = [
     "rvcx_weights_blob", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_noise_len", "rvcx_get_f0", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -170,6 +170,10 @@ class Context:
                                       C.c_float(0.0 if pre_lrelu is None else pre_lrelu), act,
                                       C.c_float(act_slope), _p(li, C.c_int32), _p(lo, C.c_int32)), "op_conv1d")
         return y
+
+    @staticmethod
+    def conv_override(tile=-1, variant=-1, splitk=-1):
+        lib().rvcx_conv_override(tile, variant, splitk)
 
     def bench_conv1d(self, B, Cin, Tin, Cout, K, stride=1, dil=1, groups=1, iters=10):
         ms = C.c_float(0)

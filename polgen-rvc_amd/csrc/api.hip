@@ -63,7 +63,7 @@ int rvcx_create(int device, rvcx_ctx** out) {
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     conv_init();
-    h->c.resblock_streams = getenv("RVCX_RESBLOCK_STREAMS") && atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
+    h->c.resblock_streams = !getenv("RVCX_RESBLOCK_STREAMS") || atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
     RVCX_HIP(hipMalloc(&h->c.dev_err, sizeof(int)));
     RVCX_HIP(hipMemset(h->c.dev_err, 0, sizeof(int)));
     h->c.arena.reserve((size_t)256 << 20);
@@ -142,6 +142,13 @@ int rvcx_op_conv1d(rvcx_ctx* ctx, const float* x, const float* w, const float* b
   to_host(*C, y, dy, ny);
   C->arena.reset();
   API_END
+}
+
+int rvcx_conv_override(int tile, int variant, int splitk) {
+  rvcx::g_conv_override.tile = tile;
+  rvcx::g_conv_override.variant = variant;
+  rvcx::g_conv_override.splitk = splitk;
+  return 0;
 }
 
 int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,

@@ -76,6 +76,8 @@ void conv_init();                                   // raise dynamic-LDS limits 
 void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + tile, launches
 int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-time-tiled family; profile slot or -1
 void conv_fast_describe(ConvProfile* p);
+struct ConvOverride { int tile = -1, variant = -1, splitk = -1; };
+extern ConvOverride g_conv_override;   // tuning sweeps only (rvcx_conv_override)
 void conv_fast_init();
 double conv_flops(const ConvArgs& a);               // 2*M*N*K of the *real* (unpadded) problem
 

@@ -456,6 +456,8 @@ constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
 }  // namespace
 
+ConvOverride g_conv_override;
+
 void conv_fast_init() {}
 
 void conv_fast_describe(ConvProfile* p) {
@@ -477,38 +479,43 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     off_max = std::max(off_max, o);
   }
   const int halo = off_max - off_min;
-  int best = -1;
+  // joint (tile, split-K) choice from a small cost model calibrated on tools/sweep_conv.py (MI355X):
+  // a CU sustains ~477 GFLOP/s of fp32 MFMA with >= 4 co-resident blocks; every block pays a fixed
+  // prologue + epilogue worth ~150 K-steps; fewer than 1024 blocks in flight do not finish sooner than a
+  // full wave would; split-K adds the finish pass (S + 1 slabs through HBM at ~3 TB/s + one launch).
+  static const float kEff[12] = {0.97f, 1.0f, 0.99f, 1.0f, 0.93f, 0.95f, 0.97f, 1.0f, 0.93f, 0.97f, 1.0f, 0.95f};
+  int best = -1, S = 1;
   double best_t = 1e300;
+  const bool lin = a.ksize == 1 && a.Cin_gp % 32 == 0;
+  const double kdepth = (double)a.ksize * a.Cin_gp;
   for (int t = 0; t < kNumFast; ++t) {
     const FastCfg& F = kFast[t];
-    if (F.cic == 32) {
-      if (a.ksize != 1 || a.Cin_gp % 32 != 0) continue;
-    } else if (a.ksize == 1 && a.Cin_gp % 32 == 0) {
-      continue;   // Linear layers go to the k=1 variants
-    }
+    if ((F.cic == 32) != lin) continue;   // Linear layers go to the k=1 variants
     if (halo > F.halo) continue;
     if (F.halo == 320 && halo <= 64) continue;
-    const long mt = cdiv(a.Cout_gp, F.bm), nt = cdiv(a.Nout, F.bn);
-    const long blocks = mt * nt * a.B;
-    const long rounds = (blocks + 767) / 768;   // 256 CUs x ~3 resident blocks
-    const double tm = (double)rounds * F.bm * F.bn / F.eff;
-    if (tm < best_t) {
-      best_t = tm;
-      best = t;
+    if (g_conv_override.tile >= 0 && g_conv_override.tile != t) continue;
+    const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * a.B;
+    const int nci = a.Cin_gp / F.cic;
+    for (int s = 1; s <= 8; s *= 2) {
+      if (s > 1 && (!a.part || nci / s < 1 || kdepth / s < 128.0 ||
+                    (long)s * a.B * a.Cout_g * a.Nout > a.part_cap))
+        break;
+      if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
+      const double waves = std::max(1.0, (double)blocks * s / 1024.0);
+      double us = waves * 4.0 * F.bm * F.bn * 2.0 * (kdepth / s + 150.0) / 477e3 / kEff[t];
+      if (s > 1) us += 3.0 + (double)(s + 1) * a.B * a.Cout_g * a.Nout * 4.0 / 3e6;
+      if (us < best_t) {
+        best_t = us;
+        best = t;
+        S = s;
+      }
     }
   }
   if (best < 0) return -1;
   const FastCfg& F = kFast[best];
   a.off_min = off_min;
   a.wrow = halo;
-  // split-K when the output grid cannot fill the chip but K is long (small-N transformer / deep U-Net layers)
   const long blocks = (long)cdiv(a.Nout, F.bn) * cdiv(a.Cout_gp, F.bm) * a.B;
-  const int nci = a.Cin_gp / F.cic;
-  int S = 1;
-  if (blocks < 384 && a.part) {
-    while (S < 8 && blocks * S * 2 <= 1024 && nci / (S * 2) >= 2) S *= 2;
-    if ((long)S * a.B * a.Cout_g * a.Nout > a.part_cap) S = 1;
-  }
   a.splitk = S;
   {
     static int dbg = -1;
@@ -516,8 +523,10 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     a.dbg = dbg;
   }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
-  // few blocks per CU -> latency-bound -> the DMA-pipelined variant; many -> the small-footprint one
-  const bool use_db = blocks * S <= 2048 || F.cic == 32;
+  // a nearly empty chip is latency-bound -> the DMA-pipelined variant; otherwise the small-footprint one
+  // (more co-resident blocks) wins on every shape of the sweep
+  bool use_db = blocks * S <= 320;
+  if (g_conv_override.variant >= 0) use_db = g_conv_override.variant != 0;
   hipLaunchKernelGGL(use_db ? F.kern_db : F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) {
     const long total = (long)a.B * a.Cout_g * a.Nout;
