@@ -415,6 +415,8 @@ class Context:
         def name(i):
             if kd[i] < 0:
                 return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
+            if kd[i] >= 200000:
+                return f"conv_fast_sb<{bm[i]},{bn[i]},stride2>"
             if kd[i] >= 100000:
                 return f"conv_fast{'_db' if kd[i] % 10 else '_sb'}<{bm[i]},{bn[i]},linear>"
             return f"conv_fast{'_db' if kd[i] % 10 else '_sb'}<{bm[i]},{bn[i]},halo{kd[i] // 10}>"

@@ -57,7 +57,13 @@ int rvcx_create(int device, rvcx_ctx** out) {
     auto* h = new rvcx_ctx();
     h->c.device = device;
     RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking));
-    RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream2, hipStreamNonBlocking));
+    {
+      // RMVPE ends in a latency-bound serial GRU: give its stream dispatch priority over HuBERT's wide kernels
+      int lo = 0, hi = 0;
+      RVCX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const bool prio = !getenv("RVCX_F0_PRIORITY") || atoi(getenv("RVCX_F0_PRIORITY")) != 0;
+      RVCX_HIP(hipStreamCreateWithPriority(&h->c.stream2, hipStreamNonBlocking, prio ? hi : lo));
+    }
     for (auto& s : h->c.aux) RVCX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     for (auto& e : h->c.ev_aux) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));

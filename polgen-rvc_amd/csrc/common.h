@@ -61,6 +61,12 @@ class Arena {
   }
   size_t mark() const { return off_; }
   void reset(size_t m = 0) { off_ = m; }
+  void swap(Arena& o) {
+    std::swap(base_, o.base_);
+    std::swap(cap_, o.cap_);
+    std::swap(off_, o.off_);
+    std::swap(peak_, o.peak_);
+  }
   size_t capacity() const { return cap_; }
   size_t peak() const { return peak_; }
 

@@ -237,10 +237,12 @@ __global__ __launch_bounds__(256, 3) void conv_fast_kernel(const ConvArgs a) {
 // ---- single-buffered variant (register staging, 2 barriers per stage, small LDS footprint -> more
 // resident workgroups): better for the long-sequence NSF layers where 3-5 co-resident blocks already
 // hide the staging latency.
-template <int BM, int BN, int WR, int WC, int KKT, int CIC, int HALO>
+// STRIDE = 2 (HuBERT extractor): the input tile is staged at full input resolution and the MFMA B
+// fragments read it with a stride-2 LDS pattern (2-way bank conflict, the LDS is far from its limit).
+template <int BM, int BN, int WR, int WC, int KKT, int CIC, int HALO, int STRIDE = 1>
 __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
-  constexpr int WROW = BN + HALO;
+  constexpr int WROW = BN * STRIDE + HALO;
   constexpr int A_FLOATS = KKT * CIC * BM;
   constexpr int NA4 = A_FLOATS / 1024;
   constexpr int NBJ = (WROW + 63) / 64;
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
   const float* xg = a.x + (long)b * a.x_bs;
-  const int in_base = n0 + a.off_min;
-  const int wuse = BN + a.wrow;          // a.wrow = off_max - off_min for this family
+  const int in_base = n0 * STRIDE + a.off_min;
+  const int wuse = BN * STRIDE + a.wrow;          // a.wrow = off_max - off_min for this family
   const int pre_act = a.pre_act;
   const float pre_slope = a.pre_slope;
 
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
     a_col[j] = (row % CIC) * a.Cout_gp + min(co0 + c4 * 4, a.Cout_gp - 4);
   }
   const float* Ap = As + h * BM + wr * (WM * 32) + i;
-  const float* Bp = Bs + h * WROW + wc * (WN * 32) + i;
+  const float* Bp = Bs + h * WROW + (wc * (WN * 32) + i) * STRIDE;
   const int nkk = (a.ksize + KKT - 1) / KKT;
   const int nci = a.Cin_gp / CIC;
   const int cb0 = ks * nci / a.splitk, cb1 = (ks + 1) * nci / a.splitk;   // this split's ci chunks
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
 #pragma unroll
           for (int m = 0; m < WM; ++m) av[m] = Ap[(kkl * CIC + 2 * cp) * BM + m * 32];
 #pragma unroll
-          for (int n = 0; n < WN; ++n) bv[n] = Bt[2 * cp * WROW + n * 32];
+          for (int n = 0; n < WN; ++n) bv[n] = Bt[2 * cp * WROW + n * 32 * STRIDE];
 #pragma unroll
           for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -429,7 +431,7 @@ __global__ void conv_splitk_finish_kernel(const ConvArgs a) {
 namespace {
 
 struct FastCfg {
-  int bm, bn, halo, cic;   // cic = 32 marks the k=1 (Linear) variants
+  int bm, bn, halo, cic;   // cic = 32 marks the k=1 (Linear) variants; halo < 0: stride-2 variant (halo = -halo)
   float eff;
   void (*kern)(const ConvArgs);      // long-N launches
   void (*kern_db)(const ConvArgs);   // LDS-DMA double-buffered variant (latency-bound small-N launches)
@@ -451,6 +453,10 @@ const FastCfg kFast[] = {
     {128, 128, 0, 32, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 1, 32, 0>, conv_fast_kernel<128, 128, 2, 2, 1, 32, 0>},
     {128, 64, 0, 32, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 1, 32, 0>, conv_fast_kernel<128, 64, 4, 1, 1, 32, 0>},
     {64, 64, 0, 32, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 1, 32, 0>, conv_fast_kernel<64, 64, 2, 2, 1, 32, 0>},
+    // stride-2 1-D convs (HuBERT feature extractor k=3 / k=2)
+    {128, 128, -64, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 64, 2>, nullptr},
+    {128, 64, -64, 16, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 2, 16, 64, 2>, nullptr},
+    {64, 64, -64, 16, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 4, 16, 64, 2>, nullptr},
 };
 constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
@@ -466,12 +472,12 @@ void conv_fast_describe(ConvProfile* p) {
       const int s = 8 + 16 * v + t;
       p->bm[s] = kFast[t].bm;
       p->bn[s] = kFast[t].bn;
-      p->halo[s] = kFast[t].cic == 32 ? 100000 + v : kFast[t].halo * 10 + v;
+      p->halo[s] = kFast[t].cic == 32 ? 100000 + v : (kFast[t].halo < 0 ? 200000 + v : kFast[t].halo * 10 + v);
     }
 }
 
 int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
-  if (a.stride != 1 || a.groups != 1 || a.Cin_gp % 16 != 0) return -1;
+  if ((a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) || a.groups != 1 || a.Cin_gp % 16 != 0) return -1;
   int off_min = 1 << 30, off_max = -(1 << 30);
   for (int kk = 0; kk < a.ksize; ++kk) {
     const int o = conv_tap_off(a, kk);
@@ -483,16 +489,22 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   // a CU sustains ~477 GFLOP/s of fp32 MFMA with >= 4 co-resident blocks; every block pays a fixed
   // prologue + epilogue worth ~150 K-steps; fewer than 1024 blocks in flight do not finish sooner than a
   // full wave would; split-K adds the finish pass (S + 1 slabs through HBM at ~3 TB/s + one launch).
-  static const float kEff[12] = {0.97f, 1.0f, 0.99f, 1.0f, 0.93f, 0.95f, 0.97f, 1.0f, 0.93f, 0.97f, 1.0f, 0.95f};
+  static const float kEff[15] = {0.97f, 1.0f, 0.99f, 1.0f, 0.93f, 0.95f, 0.97f, 1.0f, 0.93f, 0.97f, 1.0f, 0.95f,
+                                 0.97f, 1.0f, 0.93f};
   int best = -1, S = 1;
   double best_t = 1e300;
   const bool lin = a.ksize == 1 && a.Cin_gp % 32 == 0;
   const double kdepth = (double)a.ksize * a.Cin_gp;
   for (int t = 0; t < kNumFast; ++t) {
     const FastCfg& F = kFast[t];
-    if ((F.cic == 32) != lin) continue;   // Linear layers go to the k=1 variants
-    if (halo > F.halo) continue;
-    if (F.halo == 320 && halo <= 64) continue;
+    if ((F.halo < 0) != (a.stride == 2)) continue;
+    if (a.stride == 2) {
+      if (halo > -F.halo) continue;
+    } else {
+      if ((F.cic == 32) != lin) continue;   // Linear layers go to the k=1 variants
+      if (halo > F.halo) continue;
+      if (F.halo == 320 && halo <= 64) continue;
+    }
     if (g_conv_override.tile >= 0 && g_conv_override.tile != t) continue;
     const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * a.B;
     const int nci = a.Cin_gp / F.cic;
@@ -527,6 +539,7 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   // (more co-resident blocks) wins on every shape of the sweep
   bool use_db = blocks * S <= 320;
   if (g_conv_override.variant >= 0) use_db = g_conv_override.variant != 0;
+  if (!F.kern_db) use_db = false;
   hipLaunchKernelGGL(use_db ? F.kern_db : F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) {
     const long total = (long)a.B * a.Cout_g * a.Nout;

@@ -59,6 +59,7 @@ struct Ctx {
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Arena arena;
+  Arena arena_f0;                 // RMVPE workspace: lives on stream2 across the main stream's arena resets
   WeightSlab slab;
   std::string last_error;
   double flops = 0.0;

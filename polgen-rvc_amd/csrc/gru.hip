@@ -78,12 +78,25 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
                                                                     const float* __restrict__ bhh,
                                                                     float* __restrict__ y,
                                                                     unsigned long long* xbuf,  // (B,2,2,H) granules
-                                                                    int* err, int T) {
+                                                                    int* err, int T, int nq, int colocate) {
   constexpr int H = GRU_H;
   __shared__ __attribute__((aligned(16))) float hs[H];
   __shared__ float part[2][GRU_ROWS];
   __shared__ int sfail;
-  const int c = blockIdx.x, dir = blockIdx.y, b = blockIdx.z;
+  // workgroup -> (cluster q = dir + 2 b, member c).  Workgroups are dealt round-robin to the 8 XCDs, so with
+  // `colocate` the NC members of a cluster are the ids congruent mod 8: they share one XCD and its L2.
+  int c, q;
+  if (colocate) {
+    const int g = blockIdx.x, rest = g >> 3;
+    c = rest % GRU_NC;
+    q = (rest / GRU_NC) * 8 + (g & 7);
+  } else {
+    c = blockIdx.x % GRU_NC;
+    q = blockIdx.x / GRU_NC;
+  }
+  if (q >= nq) return;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound serial chain: issue ahead of co-resident conv waves
+  const int dir = q & 1, b = q >> 1;
   const int tid = threadIdx.x;
   const int row = tid % GRU_ROWS, half = tid / GRU_ROWS;
   const int gate = row / GRU_U, ul = row % GRU_U;
@@ -106,8 +119,23 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
   for (int k = tid; k < H; k += GRU_THREADS) hs[k] = 0.f;
   if (tid == 0) sfail = 0;
   __syncthreads();
+  // input-projection terms of the next step are fetched one step ahead (they do not depend on h)
+  float gr_n = 0.f, gz_n = 0.f, gn_n = 0.f;
+  if (tid < GRU_U && T > 0) {
+    const float* g = gib + (long)(dir == 0 ? 0 : T - 1) * 6 * H;
+    gr_n = g[ju];
+    gz_n = g[H + ju];
+    gn_n = g[2 * H + ju];
+  }
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
+    const float g_r = gr_n, g_z = gz_n, g_n = gn_n;
+    if (tid < GRU_U && step + 1 < T) {
+      const float* g = gib + (long)(dir == 0 ? t + 1 : t - 1) * 6 * H;
+      gr_n = g[ju];
+      gz_n = g[H + ju];
+      gn_n = g[2 * H + ju];
+    }
     // ---- partial dot product over this thread's 128 columns (h broadcast from LDS, 16 B at a time)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const float4* h4 = reinterpret_cast<const float4*>(hs + half * (H / 2));
@@ -123,13 +151,12 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
     __syncthreads();
     // ---- gates for the owned units, publish h_t[ju] as a {value, step+1} granule
     if (tid < GRU_U) {
-      const float* g = gib + (long)t * 6 * H;
       const float ghr = part[0][tid] + part[1][tid] + bh_r;
       const float ghz = part[0][GRU_U + tid] + part[1][GRU_U + tid] + bh_z;
       const float ghn = part[0][2 * GRU_U + tid] + part[1][2 * GRU_U + tid] + bh_n;
-      const float r = 1.f / (1.f + expf(-(g[ju] + ghr)));
-      const float z = 1.f / (1.f + expf(-(g[H + ju] + ghz)));
-      const float n = tanhf(g[2 * H + ju] + r * ghn);
+      const float r = 1.f / (1.f + expf(-(g_r + ghr)));
+      const float z = 1.f / (1.f + expf(-(g_z + ghz)));
+      const float n = tanhf(g_n + r * ghn);
       const float hn = (1.f - z) * n + z * hs[ju];
       Granule gr;
       gr.s.v = hn;
@@ -169,8 +196,12 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
   if (scratch && err && 2 * B * GRU_NC <= 128) {
     unsigned long long* xbuf = static_cast<unsigned long long*>(scratch);
     RVCX_HIP(hipMemsetAsync(scratch, 0, bigru_scratch_bytes(B), stream));
-    hipLaunchKernelGGL(bigru_cluster_kernel, dim3(GRU_NC, 2, B), dim3(GRU_THREADS), 0, stream, gi, whh_t, bhh, y, xbuf,
-                       err, T);
+    static int colocate = -1;
+    if (colocate < 0) colocate = getenv("RVCX_GRU_COLOCATE") ? atoi(getenv("RVCX_GRU_COLOCATE")) : 1;
+    const int nq = 2 * B;
+    const int grid = colocate ? 8 * GRU_NC * cdiv(nq, 8) : GRU_NC * nq;
+    hipLaunchKernelGGL(bigru_cluster_kernel, dim3(grid), dim3(GRU_THREADS), 0, stream, gi, whh_t, bhh, y, xbuf, err, T,
+                       nq, colocate);
   } else {
     hipLaunchKernelGGL(bigru_kernel<GRU_H>, dim3(2, B), dim3(3 * GRU_H), 0, stream, gi, whh_t, bhh, y, T);
   }

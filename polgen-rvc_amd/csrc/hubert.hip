@@ -81,7 +81,7 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
 }
 
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
-                    float* feats_ct, hipStream_t s) {
+                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor) {
   Arena& A = c.arena;
   const auto& cf = m.cfg;
   const int C = cf.conv_dim, E = cf.embed_dim;
@@ -109,6 +109,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     Tin = Tout;
   }
   const int T = (int)Tin;
+  if (after_extractor) (*after_extractor)();
   // ---- LayerNorm(C) -> proj -> x + gelu(pos_conv(x)) -> LayerNorm(E)
   float* ln = y;
   launch_layernorm_c(x, m.ln0_g, m.ln0_b, ln, B, C, T, 1e-5f, nullptr, s);

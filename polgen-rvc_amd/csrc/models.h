@@ -1,5 +1,7 @@
 // Model containers (weights folded + packed into the slab) and their forward passes.
 #pragma once
+#include <functional>
+
 #include "../../include/rvcx.h"
 #include "ctx.h"
 #include "layers.h"
@@ -105,8 +107,10 @@ std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, con
 int hubert_frames(const HubertModel& m, int64_t n);
 size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n);
 // wav: device (B,n).  feats_ct: device (B, embed, T') channel-first.
+// `after_extractor` (optional) runs on the host right after the conv feature extractor has been enqueued:
+// the pipeline uses it to enqueue RMVPE's ~330 small launches while those long convs keep the GPU busy.
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
-                    float* feats_ct, hipStream_t s);
+                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor = nullptr);
 
 // ------------------------------------------------------------------------------ retrieval index
 struct IndexData {

@@ -401,15 +401,32 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
   const long p_len = n_pad / 160;
   int* coarse = A.alloc<int>((size_t)p_len + 8);
   float* f0 = A.alloc<float>((size_t)p_len + 8);
-  // F0 runs on the second stream beside HuBERT (they only share the padded signal); its arena region
-  // stays allocated until the streams join, so nothing on the main stream can recycle it underneath
+  // F0 runs on the second stream beside HuBERT (they only share the padded signal) out of its own arena, so
+  // the main stream's arena resets cannot recycle its workspace.  One host thread feeds both streams: RMVPE's
+  // ~330 small launches are enqueued right after the first chunk's HuBERT conv extractor (7 long kernels),
+  // otherwise HuBERT would sit idle for the milliseconds the host needs to enqueue RMVPE.
   hipStream_t sf = c.serial ? s : c.stream2;
   RVCX_HIP(hipEventRecord(c.ev_fork, s));
-  RVCX_HIP(hipStreamWaitEvent(sf, c.ev_fork, 0));
-  const int r0 = clk.mark(sf);
-  get_f0_device(c, apad, n_pad, p, coarse, f0, sf);
-  const int r1 = clk.mark(sf);
-  RVCX_HIP(hipEventRecord(c.ev_join, sf));
+  c.arena_f0.reset();
+  c.arena_f0.reserve(rmvpe_arena_bytes(*c.rmvpe, 1, n_pad) + ((size_t)64 << 20));
+  int r0 = -1, r1 = -1;
+  bool f0_enqueued = false;
+  const std::function<void()> enqueue_f0 = [&]() {
+    if (f0_enqueued) return;
+    f0_enqueued = true;
+    RVCX_HIP(hipStreamWaitEvent(sf, c.ev_fork, 0));
+    r0 = clk.mark(sf);
+    c.arena.swap(c.arena_f0);
+    try {
+      get_f0_device(c, apad, n_pad, p, coarse, f0, sf);
+    } catch (...) {
+      c.arena.swap(c.arena_f0);
+      throw;
+    }
+    c.arena.swap(c.arena_f0);
+    r1 = clk.mark(sf);
+    RVCX_HIP(hipEventRecord(c.ev_join, sf));
+  };
   bool joined = false;
   const int e2 = clk.mark(s);
   // ---- 4. per-chunk vc() (pipeline.py:203-287)
@@ -431,7 +448,7 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
     float* feats = A.alloc<float>((size_t)E * Th);
     {
       const size_t mk2 = A.mark();
-      hubert_forward(c, *c.hubert, 1, apad + ch.s, ns, 12, feats, s);
+      hubert_forward(c, *c.hubert, 1, apad + ch.s, ns, 12, feats, s, &enqueue_f0);
       A.reset(mk2);
     }
     const int h1 = clk.mark(s);
@@ -520,7 +537,7 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
   if (stage_ms) {
     RVCX_HIP(hipStreamSynchronize(s));
     stage_ms[0] = clk.between(e0, e1);
-    stage_ms[1] = clk.between(r0, r1);   // on stream2, overlapped with the HuBERT stage
+    stage_ms[1] = r0 >= 0 ? clk.between(r0, r1) : 0.f;   // on stream2, overlapped with the HuBERT stage
     stage_ms[2] = t_hub;
     stage_ms[3] = t_idx;
     stage_ms[4] = t_syn[0];

@@ -29,6 +29,9 @@ CASES_1D = [
     (1, 1, 4000, 48, 10, 5, 1, 1),      # HuBERT conv0 shape (Cin=1, strided)
     (2, 48, 799, 48, 3, 2, 1, 1),
     (1, 48, 399, 48, 2, 2, 1, 1),
+    (1, 512, 1001, 512, 3, 2, 1, 1),    # HuBERT conv1-4 shape: stride-2 tile family
+    (2, 512, 300, 512, 2, 2, 1, 1),     # HuBERT conv5-6 shape
+    (1, 64, 4097, 200, 3, 2, 1, 1),
     (1, 1, 6000, 40, 24, 12, 1, 1),     # noise conv (Cin=1, k=2*stride)
     (1, 128, 70, 128, 128, 1, 1, 16),   # HuBERT pos_conv (grouped, k=128)
     (1, 24, 50, 288, 1, 1, 1, 1),       # odd channel counts -> padding guards
