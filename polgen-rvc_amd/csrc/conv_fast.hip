@@ -38,6 +38,37 @@ __device__ __forceinline__ void dma4(const float* g, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(g, lds_wave_base, 4, 0, 0);
 #endif
 }
+// Buffer loads through a 128-bit resource descriptor: 32-bit byte offsets and hardware range checking -- an
+// offset >= num_records returns 0, so the zero fill of the sequence edges / padded channels / padded taps is
+// a select on the OFFSET and every load is unconditional (the compiler turned `valid ? *p : 0` into
+// branches that serialised the staging loads one memory round trip after the other).
+struct BufRsrc {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+constexpr int kBufOob = 0x7ffffff0;
+__device__ __forceinline__ BufRsrc make_rsrc(const float* base, int bytes) {
+  BufRsrc b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+#endif
+  return b;
+}
+__device__ __forceinline__ float buf_load1(const BufRsrc& b, int byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, 0, 0));
+#else
+  return 0.f;
+#endif
+}
+__device__ __forceinline__ float4 buf_load4(const BufRsrc& b, int byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 0));
+#else
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
 __device__ __forceinline__ void wait_all_memory() {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_s_waitcnt(0);
@@ -246,6 +277,7 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   constexpr int A_FLOATS = KKT * CIC * BM;
   constexpr int NA4 = A_FLOATS / 1024;
   constexpr int NBJ = (WROW + 63) / 64;
+  constexpr int NBR = CIC / 4;
   static_assert(WR * WC == 4 && A_FLOATS % 1024 == 0 && CIC % 4 == 0, "bad tile");
   __shared__ float As[A_FLOATS];
   __shared__ float Bs[CIC * WROW];
@@ -261,11 +293,12 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
-  const float* xg = a.x + (long)b * a.x_bs;
   const int in_base = n0 * STRIDE + a.off_min;
   const int wuse = BN * STRIDE + a.wrow;          // a.wrow = off_max - off_min for this family
   const int pre_act = a.pre_act;
   const float pre_slope = a.pre_slope;
+  const BufRsrc xr = make_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
+  const BufRsrc wr_ = make_rsrc(a.w, a.ksize * a.Cin_gp * a.Cout_gp * 4);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -275,16 +308,21 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  // chunk-invariant weight-tile addressing: float4 #j of this thread is row (kkl, cil), columns c4*4..+3
-  int a_kkl[NA4], a_col[NA4];
-  bool a_cok[NA4];
+  // chunk-invariant addressing.  Weights: float4 #j of this thread is row (kkl, cil), columns c4*4..+3.
+  // Input: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction.
+  int a_kkl[NA4], a_off[NA4];
 #pragma unroll
   for (int j = 0; j < NA4; ++j) {
     const int idx = tid + j * 256;
     const int row = idx / (BM / 4), c4 = idx % (BM / 4);
     a_kkl[j] = row / CIC;
-    a_cok[j] = co0 + c4 * 4 < a.Cout_gp;
-    a_col[j] = (row % CIC) * a.Cout_gp + min(co0 + c4 * 4, a.Cout_gp - 4);
+    a_off[j] = co0 + c4 * 4 < a.Cout_gp ? ((row % CIC) * a.Cout_gp + co0 + c4 * 4) * 4 : kBufOob;
+  }
+  int b_off[NBJ];
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int p = lane + 64 * j, pos = in_base + p;
+    b_off[j] = (p < wuse && pos >= 0 && pos < len_in) ? pos * 4 : kBufOob;
   }
   const float* Ap = As + h * BM + wr * (WM * 32) + i;
   const float* Bp = Bs + h * WROW + (wc * (WN * 32) + i) * STRIDE;
@@ -292,43 +330,59 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   const int nci = a.Cin_gp / CIC;
   const int cb0 = ks * nci / a.splitk, cb1 = (ks + 1) * nci / a.splitk;   // this split's ci chunks
   const int nst = (cb1 - cb0) * nkk;
-  const int len_m1 = max(len_in - 1, 0);
+  const int kstride = a.Cin_gp * a.Cout_gp * 4;    // bytes between taps of the packed weights
+  const int xrow = a.x_cs * 4;
 
-  // one flat loop over (ci chunk, tap chunk) stages; all staging loads are unconditional (clamped
-  // addresses + select), so the loop body is straight-line code and the accumulators stay in AGPRs
-  int ci0 = cb0 * CIC, kk0 = 0;
-  for (int st = 0; st < nst; ++st) {
-    __syncthreads();
-    if (kk0 == 0 && !(RVCX_DBG(a, 2) && st > 0)) {
-      // ---- input tile: wave w stages rows w, w+4, ...; 64 consecutive positions per wave-instruction
+  // register-staged software pipeline: the loads of stage st+1 are in flight while stage st computes
+  float4 ra[NA4];
+  float rb[NBR][NBJ];
+  auto fetch = [&](int ci0, int kk0) {
+    if (kk0 == 0) {
 #pragma unroll
-      for (int rr = 0; rr < CIC / 4; ++rr) {
+      for (int rr = 0; rr < NBR; ++rr) {
+        const int ci = ci0 + wave + 4 * rr;
+        const int rowb = ci * xrow;   // rows >= Cin_g land beyond num_records and read as 0
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) rb[rr][j] = buf_load1(xr, b_off[j] == kBufOob ? kBufOob : rowb + b_off[j]);
+      }
+    }
+    const int wbase = ci0 * a.Cout_gp * 4;
+#pragma unroll
+    for (int j = 0; j < NA4; ++j) {
+      const int kk = kk0 + a_kkl[j];
+      ra[j] = buf_load4(wr_, (kk < a.ksize && a_off[j] != kBufOob) ? wbase + kk * kstride + a_off[j] : kBufOob);
+    }
+  };
+  auto commit = [&](int kk0) {
+    if (kk0 == 0) {
+#pragma unroll
+      for (int rr = 0; rr < NBR; ++rr) {
         const int r = wave + 4 * rr;
-        const int ci = ci0 + r;
-        const bool cvalid = ci < a.Cin_g;
-        const float* xr = xg + (long)min(ci, a.Cin_g - 1) * a.x_cs;
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
           const int p = lane + 64 * j;
-          const int pos = in_base + p;
-          float v = xr[min(max(pos, 0), len_m1)];
-          v = (cvalid && p < wuse && pos >= 0 && pos < len_in) ? v : 0.f;
+          float v = rb[rr][j];
           if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
           if (NBJ * 64 == WROW || p < WROW) Bs[r * WROW + p] = v;
         }
       }
     }
-    if (!(RVCX_DBG(a, 1) && st > 0)) {
-      const float* wbase = a.w + (long)ci0 * a.Cout_gp;
 #pragma unroll
-      for (int j = 0; j < NA4; ++j) {
-        const int kk = kk0 + a_kkl[j];
-        float4 v = *reinterpret_cast<const float4*>(wbase + (long)min(kk, a.ksize - 1) * a.Cin_gp * a.Cout_gp + a_col[j]);
-        if (!(a_cok[j] && kk < a.ksize)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(As + (tid + j * 256) * 4) = v;
-      }
-    }
+    for (int j = 0; j < NA4; ++j) *reinterpret_cast<float4*>(As + (tid + j * 256) * 4) = ra[j];
+  };
+
+  int ci0 = cb0 * CIC, kk0 = 0;
+  if (nst > 0) fetch(ci0, 0);
+  for (int st = 0; st < nst; ++st) {
+    __syncthreads();            // every wave is done reading the previous stage
+    commit(kk0);
     __syncthreads();
+    int kk1 = kk0 + KKT, ci1 = ci0;
+    if (kk1 >= a.ksize) {
+      kk1 = 0;
+      ci1 += CIC;
+    }
+    if (st + 1 < nst) fetch(ci1, kk1);
 #ifdef RVCX_ABLATION
     if (a.trace && tid == 0 && st == 0) tr1 = wall_clock64();
 #endif
@@ -353,11 +407,8 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
         }
       }
     }
-    kk0 += KKT;
-    if (kk0 >= a.ksize) {
-      kk0 = 0;
-      ci0 += CIC;
-    }
+    kk0 = kk1;
+    ci0 = ci1;
   }
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
@@ -478,6 +529,8 @@ void conv_fast_describe(ConvProfile* p) {
 
 int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   if ((a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) || a.groups != 1 || a.Cin_gp % 16 != 0) return -1;
+  // the staging loads address x (per batch item) and the packed weights through 32-bit buffer offsets
+  if ((long)a.Cin_gp * a.x_cs * 4 >= kBufOob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kBufOob) return -1;
   int off_min = 1 << 30, off_max = -(1 << 30);
   for (int kk = 0; kk < a.ksize; ++kk) {
     const int o = conv_tap_off(a, kk);
