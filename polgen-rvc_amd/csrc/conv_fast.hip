@@ -10,6 +10,7 @@
 //   for ci0 in Cin step CIC:            stage X[ci0:ci0+CIC][n0+off_min : +BN+halo]      -> Bs[CIC][WROW]
 //     for kk0 in ksize step KKT:        stage Wp[kk0:kk0+KKT][ci0:ci0+CIC][co0:co0+BM]   -> As[KKT][CIC][BM]
 //       for kkl, cp (unrolled):         A frag As[kkl][2cp+h][wm+i], B frag Bs[2cp+h][wn+i+tap(kk)] -> MFMA
+#include <cmath>
 #include <cstdlib>
 
 #include "conv.h"
@@ -538,12 +539,17 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     off_max = std::max(off_max, o);
   }
   const int halo = off_max - off_min;
-  // joint (tile, split-K) choice from a small cost model calibrated on tools/sweep_conv.py (MI355X):
-  // a CU sustains ~477 GFLOP/s of fp32 MFMA with >= 4 co-resident blocks; every block pays a fixed
-  // prologue + epilogue worth ~150 K-steps; fewer than 1024 blocks in flight do not finish sooner than a
-  // full wave would; split-K adds the finish pass (S + 1 slabs through HBM at ~3 TB/s + one launch).
-  static const float kEff[15] = {0.97f, 1.0f, 0.99f, 1.0f, 0.93f, 0.95f, 0.97f, 1.0f, 0.93f, 0.97f, 1.0f, 0.95f,
-                                 0.97f, 1.0f, 0.93f};
+  // joint (tile, split-K) choice from a small cost model fitted to tools/sweep_conv.py on MI355X:
+  //   block time = 2 bm bn (K/S + ovh_t) / (577 GFLOP/s x eff_t x f(c)),  c = blocks S / 256 blocks per CU,
+  // f(c) = MFMA utilisation of a CU with c co-resident blocks (0.45 alone .. 1.0 from four up), ovh_t = the
+  // prologue + epilogue of a block in K-steps, the busiest CU runs ceil(c) blocks; split-K adds the finish
+  // pass (S + 1 slabs through HBM at ~3 TB/s + one launch).
+  struct TileFit {
+    float eff, ovh;
+  };
+  static const TileFit kFit[15] = {{0.964f, 201.f}, {0.922f, 129.f}, {0.968f, 231.f}, {0.954f, 150.f}, {0.964f, 169.f},
+                                   {1.00f, 184.f},  {0.93f, 260.f},  {0.95f, 180.f},  {1.00f, 150.f},  {1.00f, 213.f},
+                                   {0.95f, 150.f},  {0.95f, 120.f},  {0.964f, 201.f}, {0.922f, 129.f}, {0.964f, 169.f}};
   int best = -1, S = 1;
   double best_t = 1e300;
   const bool lin = a.ksize == 1 && a.Cin_gp % 32 == 0;
@@ -566,8 +572,9 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
                     (long)s * a.B * a.Cout_g * a.Nout > a.part_cap))
         break;
       if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
-      const double waves = std::max(1.0, (double)blocks * s / 1024.0);
-      double us = waves * 4.0 * F.bm * F.bn * 2.0 * (kdepth / s + 150.0) / 477e3 / kEff[t];
+      const double c = (double)blocks * s / 256.0;
+      const double f = std::min(1.0, 0.45 + 0.55 * (std::max(c, 1.0) - 1.0) / 3.0);
+      double us = std::ceil(c) * 2.0 * F.bm * F.bn * (kdepth / s + kFit[t].ovh) / (577e3 * kFit[t].eff * f);
       if (s > 1) us += 3.0 + (double)(s + 1) * a.B * a.Cout_g * a.Nout * 4.0 / 3e6;
       if (us < best_t) {
         best_t = us;
@@ -588,9 +595,9 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     a.dbg = dbg;
   }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
-  // a nearly empty chip is latency-bound -> the DMA-pipelined variant; otherwise the small-footprint one
-  // (more co-resident blocks) wins on every shape of the sweep
-  bool use_db = blocks * S <= 320;
+  // the register-prefetch kernel wins on every shape of the sweep; the LDS-DMA double-buffered variant
+  // (conv_fast_kernel) stays reachable through rvcx_conv_override for A/B runs only
+  bool use_db = false;
   if (g_conv_override.variant >= 0) use_db = g_conv_override.variant != 0;
   if (!F.kern_db) use_db = false;
   hipLaunchKernelGGL(use_db ? F.kern_db : F.kern, grid, dim3(256), 0, stream, a);

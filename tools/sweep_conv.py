@@ -27,13 +27,14 @@ SHAPES = [
 TILES = {False: range(0, 6), True: range(9, 12)}
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 ctx = _lib.Context(0)
+ALL = []
 for name, cin, T, cout, k, dil in SHAPES:
     lin = k == 1 and cin % 32 == 0
     ctx.conv_override(-1, -1, -1)
     base, _ = ctx.bench_conv1d(1, cin, T, cout, k, 1, dil, 1, iters)
     res = []
     for tile in TILES[lin]:
-        for variant in (0, 1):
+        for variant in (0,):
             for sk in (1, 2, 4, 8):
                 if sk > 1 and T > 8000:
                     continue
@@ -44,5 +45,10 @@ for name, cin, T, cout, k, dil in SHAPES:
                     continue
                 res.append((ms, tile, variant, sk, tf))
     res.sort()
+    ALL.append(dict(name=name, cin=cin, T=T, cout=cout, k=k, dil=dil, heuristic_ms=base,
+                    results=[dict(ms=ms, tile=t, variant=v, splitk=sk) for ms, t, v, sk, tf in res]))
     top = "  ".join(f"[t{t} v{v} s{s} {ms:.3f}ms {tf:.0f}TF]" for ms, t, v, s, tf in res[:4])
     print(f"{name:26s} heuristic {base:.3f} ms | {top}", flush=True)
+import json
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(ALL, open("gpurun_out/sweep_conv.json", "w"))
