@@ -72,12 +72,14 @@ def pmc_traffic(tile_name):
     path = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
     if not os.path.exists(path):
         return None, None
-    m = re.match(r"conv_fast_(sb|db)<(\d+),(\d+),(halo(\d+)|linear)>", tile_name)
+    m = re.match(r"conv_fast_(sb|db)<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
     if not m:
         return None, None
     fn = "conv_fast_sb_kernel" if m.group(1) == "sb" else "conv_fast_kernel"
     want = f"{fn}<{m.group(2)}, {m.group(3)},"
-    tail = ", 32, 0>" if m.group(4) == "linear" else f", 16, {m.group(5)}>"
+    tail = {"linear": ", 32, 0", "stride2": ", 16, 64, 2>"}.get(m.group(4), f", 16, {m.group(5)}")
+    if m.group(1) == "sb" and m.group(4) != "stride2":
+        tail += ", 1>"   # trailing STRIDE template argument of conv_fast_sb_kernel
     for k, v in json.load(open(path))["kernels"].items():
         if want in k and tail in k:
             return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"

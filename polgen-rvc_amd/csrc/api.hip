@@ -600,7 +600,9 @@ int rvcx_convert_batch(rvcx_ctx* ctx, int model_id, int B, const float* const* w
     short* dpcm = C->arena.alloc<short>((size_t)cap);
     float* df32 = (out_f32 && out_f32[i]) ? C->arena.alloc<float>((size_t)cap) : nullptr;
     float ms[9];
-    const long got = convert_one(*C, model_id, dw, n[i], *p, dn, dpcm, df32, ms);
+    static const bool timing = !getenv("RVCX_STAGE_TIMING") || atoi(getenv("RVCX_STAGE_TIMING")) != 0;
+    for (float& v : ms) v = 0.f;
+    const long got = convert_one(*C, model_id, dw, n[i], *p, dn, dpcm, df32, timing ? ms : nullptr);
     for (int k = 0; k < 9; ++k) tsum[k] += ms[k];
     RVCX_HIP(hipMemcpyAsync(out[i], dpcm, (size_t)got * sizeof(short), hipMemcpyDefault, C->stream));
     if (df32) RVCX_HIP(hipMemcpyAsync(out_f32[i], df32, (size_t)got * sizeof(float), hipMemcpyDefault, C->stream));
