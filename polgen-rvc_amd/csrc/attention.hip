@@ -198,29 +198,35 @@ __global__ void attn_merge_kernel(const float* __restrict__ opart, float* __rest
 }
 
 // relq[b][h][t][r] = sum_d (q[d][t]*scale) * Ek[r][d]      (attentions.py:83-86)
-__global__ void rel_logits_kernel(const float* __restrict__ q, const float* __restrict__ ek,
-                                  float* __restrict__ relq, int H, int D, int T, int ld, long in_bs,
-                                  float scale, int nrel) {
+// block = 64 queries x 4 slices of the relative offsets (r = part, part+4, ...)
+__global__ __launch_bounds__(256) void rel_logits_kernel(const float* __restrict__ q, const float* __restrict__ ek,
+                                                         float* __restrict__ relq, int H, int D, int T, int ld,
+                                                         long in_bs, float scale, int nrel) {
   extern __shared__ float eks[];  // [nrel][D]
-  for (int idx = threadIdx.x; idx < nrel * D; idx += blockDim.x) eks[idx] = ek[idx];
+  for (int idx = threadIdx.x; idx < nrel * D; idx += 256) eks[idx] = ek[idx];
   __syncthreads();
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tq = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tq;
   const int hd = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   const float* qb = q + (long)b * in_bs + (long)hd * D * ld;
-  float acc[32];
+  float acc[8];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   for (int d = 0; d < D; ++d) {
     const float qv = qb[(long)d * ld + t] * scale;
 #pragma unroll
-    for (int r = 0; r < 32; ++r)
-      if (r < nrel) acc[r] = fmaf(qv, eks[r * D + d], acc[r]);
+    for (int i = 0; i < 8; ++i) {
+      const int r = part + 4 * i;
+      if (r < nrel) acc[i] = fmaf(qv, eks[r * D + d], acc[i]);
+    }
   }
   float* o = relq + (((long)b * H + hd) * T + t) * nrel;
 #pragma unroll
-  for (int r = 0; r < 32; ++r)
-    if (r < nrel) o[r] = acc[r];
+  for (int i = 0; i < 8; ++i) {
+    const int r = part + 4 * i;
+    if (r < nrel) o[r] = acc[i];
+  }
 }
 
 // out[d][t] += sum_r p[t][t+r-w] * Ev[r][d], p recomputed on the band from (m, l)
@@ -232,25 +238,40 @@ __global__ __launch_bounds__(256) void rel_values_kernel(const float* __restrict
                                                          const float* __restrict__ ev, float* __restrict__ out,
                                                          int H, int D, int T, int ld, long in_bs, long out_bs, float scale,
                                                          int window, const int* lens) {
-  extern __shared__ float sm[];  // evs [nrel][D] ; ps [64][nrel+1]
+  // block = 32 queries x 8 slices; the q tile and the k band (32 + 2*window keys) are staged in LDS once
+  extern __shared__ float sm[];  // evs [nrel][D] ; ps [32][nrel+1] ; qs [D][32] ; ks [D][KW]
   const int nrel = 2 * window + 1;
+  const int KW = 32 + 2 * window;
   float* evs = sm;
-  float* ps = sm + nrel * D;
-  const int tq = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float* ps = evs + nrel * D;
+  float* qs = ps + 32 * (nrel + 1);
+  float* ks = qs + D * 32;
+  const int tq = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
-  const int t = blockIdx.x * 64 + tq;
+  const int tb = blockIdx.x * 32;
+  const int t = tb + tq;
   const int len = lens ? lens[b] : T;
-  for (int idx = threadIdx.x; idx < nrel * D; idx += 256) evs[idx] = ev[idx];
   const long base = (long)b * in_bs + (long)hd * D * ld;
   const long obase = (long)b * out_bs + (long)hd * D * ld;
+  for (int idx = threadIdx.x; idx < nrel * D; idx += 256) evs[idx] = ev[idx];
+  for (int idx = threadIdx.x; idx < D * 32; idx += 256) {
+    const int d = idx >> 5, j = idx & 31;
+    qs[idx] = tb + j < T ? q[base + (long)d * ld + tb + j] * scale : 0.f;
+  }
+  for (int idx = threadIdx.x; idx < D * KW; idx += 256) {
+    const int d = idx / KW, j = idx - d * KW;
+    const int key = tb - window + j;
+    ks[idx] = (key >= 0 && key < T) ? k[base + (long)d * ld + key] : 0.f;
+  }
+  __syncthreads();
   if (t < T) {
     const float m = m_in[((long)b * H + hd) * T + t], l = l_in[((long)b * H + hd) * T + t];
-    for (int r = part; r < nrel; r += 4) {
+    for (int r = part; r < nrel; r += 8) {
       const int key = t + r - window;
       float p = 0.f;
       if (key >= 0 && key < len) {
         float s = 0.f;
-        for (int d = 0; d < D; ++d) s = fmaf(q[base + (long)d * ld + t] * scale, k[base + (long)d * ld + key], s);
+        for (int d = 0; d < D; ++d) s = fmaf(qs[d * 32 + tq], ks[d * KW + tq + r], s);
         s += relq[(((long)b * H + hd) * T + t) * nrel + r];
         p = expf(s - m) / l;
       }
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(256) void rel_values_kernel(const float* __restrict
   }
   __syncthreads();
   if (t < T && t < len) {
-    for (int d = part; d < D; d += 4) {
+    for (int d = part; d < D; d += 8) {
       float acc = 0.f;
       for (int r = 0; r < nrel; ++r) acc = fmaf(ps[tq * (nrel + 1) + r], evs[r * D + d], acc);
       out[obase + (long)d * ld + t] += acc;
@@ -278,7 +299,7 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
     relq = scratch;
     mb = relq + (size_t)B * H * T * nrel;
     lb = mb + (size_t)B * H * T;
-    hipLaunchKernelGGL(rel_logits_kernel, dim3(cdiv(T, 128), H, B), dim3(128), nrel * D * sizeof(float), stream,
+    hipLaunchKernelGGL(rel_logits_kernel, dim3(cdiv(T, 64), H, B), dim3(256), nrel * D * sizeof(float), stream,
                        q, emb_rel_k, relq, H, D, T, ld, in_bs, scale, nrel);
   }
   const int DT = cdiv(D, 32);
@@ -307,8 +328,8 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
     hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(T, 64), H, B), dim3(256), 0, stream, opart, out, mb, lb, H, D,
                        32 * DT, T, ld, out_bs, nsplit, lens);
   if (emb_rel_v) {
-    size_t lds = ((size_t)nrel * D + 64 * (nrel + 1)) * sizeof(float);
-    hipLaunchKernelGGL(rel_values_kernel, dim3(cdiv(T, 64), H, B), dim3(256), lds, stream, q, k, relq, mb, lb,
+    size_t lds = ((size_t)nrel * D + 32 * (nrel + 1) + (size_t)D * 32 + (size_t)D * (32 + 2 * window)) * sizeof(float);
+    hipLaunchKernelGGL(rel_values_kernel, dim3(cdiv(T, 32), H, B), dim3(256), lds, stream, q, k, relq, mb, lb,
                        emb_rel_v, out, H, D, T, ld, in_bs, out_bs, scale, window, lens);
   }
   RVCX_HIP(hipGetLastError());

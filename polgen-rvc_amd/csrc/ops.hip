@@ -275,16 +275,36 @@ void launch_add_channel_bias(float* x, const float* g, int B, int C, int T, hipS
 // phase prefix per frame (float64): P[t] = frac(sum_{t'<t} upp * rad[t']), rad = (f0/sr) % 1 in fp32.
 // sin(2*pi*cumsum) is invariant to the integer "cumsum_shift" of generators.py:140-146, so the
 // per-sample phase is P[t] + (jj+1)*rad[t] without ever materialising the 1.5M-sample cumsum.
-__global__ void sine_prefix_kernel(const float* f0, double* P, float* rad_out, int T, int upp, float sr) {
-  const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;
+// One wave per item: lane l owns a contiguous segment of frames (local wrapped sum, wave-level exclusive
+// scan of the 64 segment totals, second pass writes the prefixes).  Subtracting floor() only removes
+// integers, so the wrapped running sum equals the sequential one up to fp64 rounding (1e-16 of a cycle).
+__global__ __launch_bounds__(64) void sine_prefix_kernel(const float* f0, double* P, float* rad_out, int T, int upp,
+                                                         float sr) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int seg = (T + 63) / 64;
+  const int t0 = min(lane * seg, T), t1 = min(t0 + seg, T);
+  const float* f = f0 + (long)b * T;
   double acc = 0.0;
-  for (int t = 0; t < T; ++t) {
-    const float rad = fmodf(f0[(long)b * T + t] / sr, 1.0f);
-    P[(long)b * T + t] = acc;
-    rad_out[(long)b * T + t] = rad;
-    acc += (double)rad * upp;
+  for (int t = t0; t < t1; ++t) {
+    acc += (double)fmodf(f[t] / sr, 1.0f) * upp;
     acc -= floor(acc);
+  }
+  // inclusive scan over lanes, then shift to exclusive
+  double incl = acc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+    incl -= floor(incl);
+  }
+  double run = incl - acc;
+  run -= floor(run);
+  for (int t = t0; t < t1; ++t) {
+    const float rad = fmodf(f[t] / sr, 1.0f);
+    P[(long)b * T + t] = run;
+    rad_out[(long)b * T + t] = rad;
+    run += (double)rad * upp;
+    run -= floor(run);
   }
 }
 
