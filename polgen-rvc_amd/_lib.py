@@ -415,6 +415,8 @@ class Context:
         def name(i):
             if kd[i] < 0:
                 return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
+            if kd[i] >= 300000:
+                return "conv_cin1 (vector FMA, Cin=1)"
             if kd[i] >= 200000:
                 return f"conv_fast_sb<{bm[i]},{bn[i]},stride2>"
             if kd[i] >= 100000:

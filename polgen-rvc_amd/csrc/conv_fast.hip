@@ -480,6 +480,46 @@ __global__ void conv_splitk_finish_kernel(const ConvArgs a) {
   }
 }
 
+// Cin = 1 convolutions (NSF noise convs k = 2*stride, HuBERT conv0 k10 s5): an FIR per output channel,
+// bound by the output write -- plain vector FMAs, 16 output channels per thread, weights broadcast from LDS.
+constexpr int kCin1MaxK = 192;
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const ConvArgs a) {
+  __shared__ float ws[kCin1MaxK * 16];
+  const int co0 = blockIdx.y * 16, b = blockIdx.z;
+  const int K = a.ksize;
+  for (int idx = threadIdx.x; idx < K * 16; idx += 256) {
+    const int kk = idx >> 4, j = idx & 15;
+    ws[idx] = co0 + j < a.Cout_gp ? a.w[(long)kk * a.Cin_gp * a.Cout_gp + co0 + j] : 0.f;
+  }
+  __syncthreads();
+  const int nn = blockIdx.x * 256 + threadIdx.x;
+  if (nn >= a.Nout) return;
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
+  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
+  const float* xb = a.x + (long)b * a.x_bs;
+  const int p0 = nn * a.stride - a.pad;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int kk = 0; kk < K; ++kk) {
+    const int pos = p0 + kk * a.dil;
+    float xv = (pos >= 0 && pos < len_in) ? xb[pos] : 0.f;
+    if (a.pre_act == ACT_LRELU) xv = xv > 0.f ? xv : xv * a.pre_slope;
+    const float4* w4 = reinterpret_cast<const float4*>(ws + kk * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 w = w4[q];
+      acc[4 * q + 0] = fmaf(w.x, xv, acc[4 * q + 0]);
+      acc[4 * q + 1] = fmaf(w.y, xv, acc[4 * q + 1]);
+      acc[4 * q + 2] = fmaf(w.z, xv, acc[4 * q + 2]);
+      acc[4 * q + 3] = fmaf(w.w, xv, acc[4 * q + 3]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (co0 + j < a.Cout_g) store_elem(a, b, co0 + j, nn, acc[j], len_out);
+}
+
 namespace {
 
 struct FastCfg {
@@ -519,6 +559,9 @@ ConvOverride g_conv_override;
 void conv_fast_init() {}
 
 void conv_fast_describe(ConvProfile* p) {
+  p->bm[7] = 16;
+  p->bn[7] = 256;
+  p->halo[7] = 300000;   // slot 7: conv_cin1_kernel
   for (int t = 0; t < kNumFast; ++t)
     for (int v = 0; v < 2; ++v) {
       const int s = 8 + 16 * v + t;
@@ -529,6 +572,11 @@ void conv_fast_describe(ConvProfile* p) {
 }
 
 int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
+  if (a.Cin_g == 1 && a.groups == 1 && a.kw == a.ksize && a.ksize <= kCin1MaxK) {
+    hipLaunchKernelGGL(conv_cin1_kernel, dim3(cdiv(a.Nout, 256), cdiv(a.Cout_g, 16), a.B), dim3(256), 0, stream, a);
+    RVCX_HIP(hipGetLastError());
+    return 7;
+  }
   if ((a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) || a.groups != 1 || a.Cin_gp % 16 != 0) return -1;
   // the staging loads address x (per batch item) and the packed weights through 32-bit buffer offsets
   if ((long)a.Cin_gp * a.x_cs * 4 >= kBufOob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kBufOob) return -1;

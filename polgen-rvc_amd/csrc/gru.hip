@@ -65,6 +65,13 @@ constexpr int GRU_ROWS = 3 * GRU_U;       // gate rows owned (192)
 constexpr int GRU_THREADS = 2 * GRU_ROWS; // thread = (row, column half): 128 weights in registers
 constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;   // ~seconds: a lost partner ends the kernel instead of hanging the GPU
 
+__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+// tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): no cancellation near 0, saturates cleanly
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(-2.f * fabsf(x));
+  return copysignf(__fdividef(1.f - e, 1.f + e), x);
+}
+
 union Granule {
   unsigned long long u;
   struct {
@@ -154,9 +161,10 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
       const float ghr = part[0][tid] + part[1][tid] + bh_r;
       const float ghz = part[0][GRU_U + tid] + part[1][GRU_U + tid] + bh_z;
       const float ghn = part[0][2 * GRU_U + tid] + part[1][2 * GRU_U + tid] + bh_n;
-      const float r = 1.f / (1.f + expf(-(g_r + ghr)));
-      const float z = 1.f / (1.f + expf(-(g_z + ghz)));
-      const float n = tanhf(g_n + r * ghn);
+      // hardware exp2 / rcp (1-2 ulp): the gate chain is on the serial critical path of every step
+      const float r = fast_sigmoid(g_r + ghr);
+      const float z = fast_sigmoid(g_z + ghz);
+      const float n = fast_tanh(g_n + r * ghn);
       const float hn = (1.f - z) * n + z * hs[ju];
       Granule gr;
       gr.s.v = hn;
@@ -177,7 +185,6 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
           sfail = 1;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
       } while (true);
       hs[k] = gr.s.v;
     }

@@ -76,39 +76,64 @@ void launch_layernorm_c(const float* x, const float* gamma, const float* beta, f
 }
 
 // ------------------------------------------------------------------ GroupNorm(C,C) + GELU
-__global__ __launch_bounds__(256) void groupnorm_gelu_kernel(const float* __restrict__ x,
+// One block per (channel, item); two sweeps over the row (the second hits L2): fp64 sum / sum of squares in
+// one sweep (exact enough that var = E[x^2] - mean^2 matches the two-pass fp32 result to rounding), then apply.
+__global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
                                                              int C, int T, float eps) {
-  __shared__ float red[4];
+  __shared__ double red[2][8];
   const int c = blockIdx.x, b = blockIdx.y;
   const float* xr = x + ((long)b * C + c) * T;
   float* yr = y + ((long)b * C + c) * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float s = 0.f;
-  for (int t = tid; t < T; t += 256) s += xr[t];
-  s = wave_sum(s);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)T;
-  __syncthreads();
-  float v = 0.f;
-  for (int t = tid; t < T; t += 256) {
-    const float d = xr[t] - mean;
-    v += d * d;
+  double s = 0.0, q = 0.0;
+  int t = tid;
+  for (; t + 3 * 512 < T; t += 4 * 512) {
+    const float v0 = xr[t], v1 = xr[t + 512], v2 = xr[t + 1024], v3 = xr[t + 1536];
+    s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    q += ((double)v0 * v0 + (double)v1 * v1) + ((double)v2 * v2 + (double)v3 * v3);
   }
-  v = wave_sum(v);
-  if (lane == 0) red[wave] = v;
+  for (; t < T; t += 512) {
+    const float v = xr[t];
+    s += v;
+    q += (double)v * v;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    s += __shfl_xor(s, d, 64);
+    q += __shfl_xor(q, d, 64);
+  }
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
   __syncthreads();
-  const float var = (red[0] + red[1] + red[2] + red[3]) / (float)T;
+  double ts = 0.0, tq = 0.0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    ts += red[0][w];
+    tq += red[1][w];
+  }
+  const double meand = ts / T;
+  const float mean = (float)meand;
+  const float var = (float)fmax(tq / T - meand * meand, 0.0);
   const float rstd = 1.f / sqrtf(var + eps);
   const float g = gamma[c], bb = beta[c];
-  for (int t = tid; t < T; t += 256) yr[t] = gelu_erf((xr[t] - mean) * rstd * g + bb);
+  t = tid;
+  for (; t + 3 * 512 < T; t += 4 * 512) {
+    const float v0 = xr[t], v1 = xr[t + 512], v2 = xr[t + 1024], v3 = xr[t + 1536];
+    yr[t] = gelu_erf((v0 - mean) * rstd * g + bb);
+    yr[t + 512] = gelu_erf((v1 - mean) * rstd * g + bb);
+    yr[t + 1024] = gelu_erf((v2 - mean) * rstd * g + bb);
+    yr[t + 1536] = gelu_erf((v3 - mean) * rstd * g + bb);
+  }
+  for (; t < T; t += 512) yr[t] = gelu_erf((xr[t] - mean) * rstd * g + bb);
 }
 
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                            float eps, hipStream_t s) {
-  hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3(C, B), dim3(256), 0, s, x, gamma, beta, y, C, T, eps);
+  hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3(C, B), dim3(512), 0, s, x, gamma, beta, y, C, T, eps);
 }
 
 // ------------------------------------------------------------------ batched transpose
