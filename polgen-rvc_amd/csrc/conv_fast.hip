@@ -375,15 +375,17 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   int ci0 = cb0 * CIC, kk0 = 0;
   if (nst > 0) fetch(ci0, 0);
   for (int st = 0; st < nst; ++st) {
-    __syncthreads();            // every wave is done reading the previous stage
-    commit(kk0);
-    __syncthreads();
+    if (!RVCX_DBG(a, 32) || st == 0) {
+      __syncthreads();            // every wave is done reading the previous stage
+      commit(kk0);
+      __syncthreads();
+    }
     int kk1 = kk0 + KKT, ci1 = ci0;
     if (kk1 >= a.ksize) {
       kk1 = 0;
       ci1 += CIC;
     }
-    if (st + 1 < nst) fetch(ci1, kk1);
+    if (st + 1 < nst && !RVCX_DBG(a, 16)) fetch(ci1, kk1);
 #ifdef RVCX_ABLATION
     if (a.trace && tid == 0 && st == 0) tr1 = wall_clock64();
 #endif

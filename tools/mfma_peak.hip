@@ -38,9 +38,11 @@ void run(int blocks, int iters) {
   hipFree(out);
 }
 int main() {
-  run<4>(256 * 4, 20000);
-  run<4>(256 * 8, 20000);
-  run<2>(256 * 8, 40000);
-  run<4>(256 * 4, 200000);   // ~sustained (longer) run
+  // waves per SIMD = blocks / 256 CUs (256-thread blocks = 1 wave per SIMD each)
+  for (int wps : {1, 2, 3, 4, 5}) {
+    run<1>(256 * wps, 40000);
+    run<2>(256 * wps, 20000);
+    run<4>(256 * wps, 10000);
+  }
   return 0;
 }
