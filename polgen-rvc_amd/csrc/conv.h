@@ -53,7 +53,8 @@ struct ConvArgs {
   int ci_chunk = 0, kk_chunk = 0, wrow = 0, off_min = 0;
   int splitk = 1;
   long long* trace = nullptr;    // RVCX_ABLATION: per-workgroup {hw_id, xcc, t_start, t_stage0, t_mainloop_end, t_end}
-  int stagger = 0;               // cycles of start delay per resident-workgroup slot (first round only)
+  int stagger = 0;               // start delay per resident-workgroup slot in 100 MHz ticks (first round only)
+  int stagger_blocks = 0;        // workgroups of the first round (linear id below this get the delay)
   int dbg = 0;                   // timing ablations only (RVCX_CONV_DBG): 1 skip weight staging, 2 skip input staging, 4 skip MFMAs
 };
 

@@ -127,6 +127,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 constexpr int kMaxLdsFloats = 16384;  // 64 KiB per block -> 2 blocks/CU of the 160 KiB
 
 void conv_init() {
+  conv_fast_init();
   for (int t = 0; t < kNumTiles; ++t)
     RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[t].kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

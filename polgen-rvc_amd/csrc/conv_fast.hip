@@ -288,9 +288,26 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z / a.splitk, ks = blockIdx.z - b * a.splitk;
 #ifdef RVCX_ABLATION
-  long long tr0 = 0, tr1 = 0, tr2 = 0;
-  if (a.trace && tid == 0) tr0 = wall_clock64();
+  long long tr0 = 0, tr1 = 0, tr2 = 0, cy0 = 0;
+  if (a.trace && tid == 0) {
+    tr0 = wall_clock64();
+    cy0 = clock64();   // s_memtime: shader clock
+  }
 #endif
+  // Optional first-round stagger (RVCX_STAGGER, off by default): delays the k-th co-resident workgroup of a CU
+  // by k/occupancy of a block time.  The per-workgroup trace shows the phases of co-resident workgroups are
+  // already spread (a CU has no workgroup in its main loop < 1 % of the time), so this buys nothing.
+  if (a.stagger > 0) {
+    const long lin = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+    if (lin < a.stagger_blocks) {
+      if (tid == 0) {
+        const int slot = __builtin_amdgcn_s_getreg(63492) & 15;   // HW_ID.wave_id: slot of this wave on its SIMD
+        const long long t_end = wall_clock64() + (long long)slot * a.stagger;
+        while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16);
+      }
+      __syncthreads();
+    }
+  }
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
@@ -337,16 +354,16 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
   // register-staged software pipeline: the loads of stage st+1 are in flight while stage st computes
   float4 ra[NA4];
   float rb[NBR][NBJ];
-  auto fetch = [&](int ci0, int kk0) {
-    if (kk0 == 0) {
+  auto fetch_b = [&](int ci0) {
 #pragma unroll
-      for (int rr = 0; rr < NBR; ++rr) {
-        const int ci = ci0 + wave + 4 * rr;
-        const int rowb = ci * xrow;   // rows >= Cin_g land beyond num_records and read as 0
+    for (int rr = 0; rr < NBR; ++rr) {
+      const int ci = ci0 + wave + 4 * rr;
+      const int rowb = ci * xrow;   // rows >= Cin_g land beyond num_records and read as 0
 #pragma unroll
-        for (int j = 0; j < NBJ; ++j) rb[rr][j] = buf_load1(xr, b_off[j] == kBufOob ? kBufOob : rowb + b_off[j]);
-      }
+      for (int j = 0; j < NBJ; ++j) rb[rr][j] = buf_load1(xr, b_off[j] == kBufOob ? kBufOob : rowb + b_off[j]);
     }
+  };
+  auto fetch_a = [&](int ci0, int kk0) {
     const int wbase = ci0 * a.Cout_gp * 4;
 #pragma unroll
     for (int j = 0; j < NA4; ++j) {
@@ -372,8 +389,14 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
     for (int j = 0; j < NA4; ++j) *reinterpret_cast<float4*>(As + (tid + j * 256) * 4) = ra[j];
   };
 
+  // The weight tile (L2-resident) is fetched one stage ahead; the input tile (streamed from HBM, the long
+  // latency under load) as soon as its registers are free, i.e. at the first tap-stage of the previous channel
+  // chunk -- issued after the weights so that the next commit's vmcnt wait does not include it.
   int ci0 = cb0 * CIC, kk0 = 0;
-  if (nst > 0) fetch(ci0, 0);
+  if (nst > 0) {
+    fetch_b(ci0);
+    fetch_a(ci0, 0);
+  }
   for (int st = 0; st < nst; ++st) {
     if (!RVCX_DBG(a, 32) || st == 0) {
       __syncthreads();            // every wave is done reading the previous stage
@@ -385,7 +408,10 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
       kk1 = 0;
       ci1 += CIC;
     }
-    if (st + 1 < nst && !RVCX_DBG(a, 16)) fetch(ci1, kk1);
+    if (!RVCX_DBG(a, 16)) {
+      if (st + 1 < nst) fetch_a(ci1, kk1);
+      if (kk0 == 0 && ci0 + CIC < cb1 * CIC) fetch_b(ci0 + CIC);
+    }
 #ifdef RVCX_ABLATION
     if (a.trace && tid == 0 && st == 0) tr1 = wall_clock64();
 #endif
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
       const long lin = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
       long long* tp = a.trace + lin * 6;
       tp[0] = __builtin_amdgcn_s_getreg(63492);               // HW_REG_HW_ID
-      tp[1] = __builtin_amdgcn_s_getreg((20) | (31 << 11));   // HW_REG_XCC_ID
+      tp[1] = (long long)(__builtin_amdgcn_s_getreg((20) | (31 << 11)) & 15) | ((clock64() - cy0) << 8);   // XCC_ID | shader cycles of the block
       tp[2] = tr0;
       tp[3] = tr1;
       tp[4] = tr2;
@@ -558,7 +584,20 @@ constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
 ConvOverride g_conv_override;
 
-void conv_fast_init() {}
+namespace {
+int g_occ[32] = {0};          // resident workgroups per CU of each sb kernel
+float g_stagger_scale = 0.f;  // RVCX_STAGGER=<scale> enables the first-round stagger (measured: no gain, off)
+}  // namespace
+
+void conv_fast_init() {
+  for (int t = 0; t < kNumFast; ++t) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kFast[t].kern), 256, 0) != hipSuccess)
+      n = 3;
+    g_occ[t] = std::max(1, n);
+  }
+  if (const char* e = getenv("RVCX_STAGGER")) g_stagger_scale = (float)atof(e);
+}
 
 void conv_fast_describe(ConvProfile* p) {
   p->bm[7] = 16;
@@ -648,6 +687,15 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   // the register-prefetch kernel wins on every shape of the sweep; the LDS-DMA double-buffered variant
   // (conv_fast_kernel) stays reachable through rvcx_conv_override for A/B runs only
   bool use_db = false;
+  {
+    // spacing = one block's exclusive time on its CU (block wall time / occupancy), only worth it when the
+    // launch runs for several rounds
+    const int occ = g_occ[best];
+    const double excl_us = 2.0 * F.bm * F.bn * (kdepth / S + kFit[best].ovh) / (577e3 * kFit[best].eff);
+    const bool multi_round = blocks * S >= 2L * 256 * occ;
+    a.stagger = (multi_round && g_stagger_scale > 0.f) ? (int)(excl_us * 100.0 * g_stagger_scale) : 0;
+    a.stagger_blocks = 256 * occ;
+  }
   if (g_conv_override.variant >= 0) use_db = g_conv_override.variant != 0;
   if (!F.kern_db) use_db = false;
   hipLaunchKernelGGL(use_db ? F.kern_db : F.kern, grid, dim3(256), 0, stream, a);
