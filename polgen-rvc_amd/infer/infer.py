@@ -14,6 +14,32 @@ from .pipeline import VC
 
 _CTX = {}
 
+# ---- resident-asset cache -------------------------------------------------------------
+# The reference's scripts reload HuBERT, the voice model and RMVPE on every request
+# (rvc/scripts/voice_conversion.py:71-75,98-100).  Here a checkpoint path that was loaded before, and whose
+# (realpath, mtime, size) has not changed, maps to the models already folded and resident in HBM.
+_RESIDENT = {}            # (device index, kind) -> (file key, handle)      kind in {"hubert", "rmvpe"}
+_SYNTHS = {}              # (device index, file key) -> (light cpt, SynthHandle); insertion order = LRU order
+MAX_RESIDENT_SYNTHS = 8   # voice models kept per process (a 48 k model is ~115 MB of folded fp32 weights)
+
+
+def _file_key(path):
+    import os
+    st = os.stat(path)
+    return (os.path.realpath(path), st.st_mtime_ns, st.st_size)
+
+
+def _dev_index(device) -> int:
+    if isinstance(device, str) and ":" in device:
+        return int(device.split(":")[1])
+    return device if isinstance(device, int) else 0
+
+
+def clear_cache():
+    """Drop every cached handle (voice models are unloaded once their callers released them too)."""
+    _RESIDENT.clear()
+    _SYNTHS.clear()
+
 
 def _context(device) -> "_lib.Context":
     """One rvcx context per GPU, created on first use."""
@@ -66,12 +92,20 @@ def load_hubert(device, is_half, model_path, state=None, cfg=None):
     tensor dict is read with a restricted unpickler); alternatively pass the state dict directly."""
     from .. import synthetic
     ctx = _context(device)
+    slot, key = (_dev_index(device), "hubert"), None
     if state is None:
+        key = _file_key(model_path)
+        if slot in _RESIDENT and _RESIDENT[slot][0] == key:
+            return _RESIDENT[slot][1]
         from ..ckpt_io import load_fairseq_hubert
         state = load_fairseq_hubert(model_path)
     cfg = cfg or synthetic.HUBERT_CFG_BASE
     ctx.load_hubert(weights.hubert_cfg_struct(cfg), state)
-    return HubertHandle(ctx, cfg)
+    handle = HubertHandle(ctx, cfg)
+    _RESIDENT.pop(slot, None)
+    if key is not None:
+        _RESIDENT[slot] = (key, handle)
+    return handle
 
 
 def load_rmvpe(device, model_path=None, state=None, cfg=None):
@@ -79,14 +113,29 @@ def load_rmvpe(device, model_path=None, state=None, cfg=None):
     inside VC.get_f0_rmvpe from rvc/models/predictors/rmvpe.pt (pipeline.py:123-126)."""
     from .. import synthetic
     ctx = _context(device)
+    slot, key = (_dev_index(device), "rmvpe"), None
     if state is None:
+        key = _file_key(model_path)
+        if slot in _RESIDENT and _RESIDENT[slot][0] == key:
+            return
         state = _torch_load(model_path)
     ctx.load_rmvpe(weights.rmvpe_cfg_struct(cfg or synthetic.RMVPE_CFG_FULL), state)
+    _RESIDENT.pop(slot, None)
+    if key is not None:
+        _RESIDENT[slot] = (key, True)
 
 
 def get_vc(device, is_half, config, model_path, cpt=None):
-    """rvc/infer/infer.py:78-105 -> (cpt, version, net_g, tgt_sr, vc)."""
+    """rvc/infer/infer.py:78-105 -> (cpt, version, net_g, tgt_sr, vc).  A ``model_path`` seen before (same
+    realpath, mtime and size) returns the voice model already resident in HBM; the returned ``cpt`` then
+    carries the checkpoint's metadata (config, version, f0, ...) without the weight tensors."""
+    skey = None
     if cpt is None:
+        skey = (_dev_index(device), _file_key(model_path))
+        if skey in _SYNTHS:
+            light, net_g = _SYNTHS.pop(skey)
+            _SYNTHS[skey] = (light, net_g)          # most recently used
+            return dict(light), light.get("version", "v1"), net_g, light["config"][-1], VC(light["config"][-1], config)
         cpt = _torch_load(model_path)
     if "config" not in cpt or "weight" not in cpt:
         raise ValueError(f"Invalid format for {model_path}. Use a voice model trained with RVC v2.")
@@ -102,11 +151,18 @@ def get_vc(device, is_half, config, model_path, cpt=None):
     mid = ctx.load_synth(weights.synth_cfg_struct(cpt["config"], input_dim), state)
     net_g = SynthHandle(ctx, mid, list(cpt["config"]))
     vc = VC(tgt_sr, config)
+    if skey is not None:
+        _SYNTHS[skey] = ({k: v for k, v in cpt.items() if k != "weight"}, net_g)
+        while len(_SYNTHS) > MAX_RESIDENT_SYNTHS:
+            _SYNTHS.pop(next(iter(_SYNTHS)))        # least recently used; unloads when the caller let go too
     return cpt, version, net_g, tgt_sr, vc
 
 
 def load_audio(file, sample_rate):
-    """rvc/lib/my_utils.py:5-16 for PCM WAV input at the target rate (soundfile/librosa absent here)."""
+    """rvc/lib/my_utils.py:5-16: read -> mono mean -> resample -> flatten.  PCM/float WAV through scipy (soundfile
+    is absent here).  Other rates are converted with a Kaiser-windowed polyphase filter
+    (``scipy.signal.resample_poly``); the reference calls ``librosa.resample`` (soxr_hq), which is not vendored, so
+    this edge is "parity unpinned": same band-limiting intent, not the same filter taps."""
     try:
         file = file.strip(" ").strip('"').strip("\n").strip('"').strip(" ")
         from scipy.io import wavfile
@@ -120,7 +176,10 @@ def load_audio(file, sample_rate):
         if audio.ndim > 1:
             audio = audio.mean(axis=1)
         if sr != sample_rate:
-            raise ValueError(f"input is {sr} Hz; resampling is outside the accelerated path (SURVEY §8f)")
+            from math import gcd
+            from scipy.signal import resample_poly
+            g = gcd(int(sr), int(sample_rate))
+            audio = resample_poly(audio, int(sample_rate) // g, int(sr) // g, window=("kaiser", 14.0))
     except Exception as error:
         raise RuntimeError(f"An error occurred loading the audio: {error}")
     return audio.flatten()

@@ -16,6 +16,8 @@ import numpy as np
 
 from .. import _lib
 
+_INDEX_RESIDENT = {}   # id(context) -> (realpath, mtime_ns, size) of the FAISS index whose vectors are in HBM
+
 F0_METHODS = ("rmvpe+", "rmvpe")
 
 
@@ -39,7 +41,6 @@ class VC:
         self.device = config.device
         self.tgt_sr = tgt_sr
         self.seed = 0
-        self._index_path = None
 
     # ------------------------------------------------------------------------------------
     def _params(self, pitch, index_rate, volume_envelope, protect, f0_min, f0_max, sid=0):
@@ -68,22 +69,25 @@ class VC:
 
     def _load_index(self, ctx, file_index, index_rate):
         """pipeline.py:315-328: index + big_npy, failures swallowed (print, continue without index)."""
+        # residency is per context (a new VC is built per request): keyed by (realpath, mtime, size)
         if not (file_index is not None and file_index != "" and os.path.exists(file_index) and index_rate != 0):
-            if self._index_path is not None:
+            if _INDEX_RESIDENT.get(id(ctx)) is not None:
                 ctx.load_index(None)
-                self._index_path = None
-            return
-        if self._index_path == file_index:
+                _INDEX_RESIDENT[id(ctx)] = None
             return
         try:
+            st = os.stat(file_index)
+            key = (os.path.realpath(file_index), st.st_mtime_ns, st.st_size)
+            if _INDEX_RESIDENT.get(id(ctx)) == key:
+                return
             from ..index_io import read_index_vectors
             big_npy = read_index_vectors(file_index)
             ctx.load_index(big_npy)
-            self._index_path = file_index
+            _INDEX_RESIDENT[id(ctx)] = key
         except Exception as e:  # noqa: BLE001 -- same degrade-to-None behaviour as the reference
             print(f"Error reading the FAISS index: {e}")
             ctx.load_index(None)
-            self._index_path = None
+            _INDEX_RESIDENT[id(ctx)] = None
 
     def pipeline(self, model, net_g, sid, audio, input_audio_path, pitch, f0_method, file_index, index_rate,
                  pitch_guidance, filter_radius, tgt_sr, resample_sr, volume_envelope, version, protect,
@@ -102,7 +106,7 @@ class VC:
         if model.ctx is not ctx:
             raise ValueError("hubert and voice model live on different rvcx contexts")
         self._load_index(ctx, file_index, index_rate)
-        p = self._params(pitch, index_rate if self._index_path else 0.0, volume_envelope, protect, f0_min, f0_max,
+        p = self._params(pitch, index_rate if _INDEX_RESIDENT.get(id(ctx)) else 0.0, volume_envelope, protect, f0_min, f0_max,
                          sid)
         audio = np.asarray(audio, dtype=np.float32)
         res = ctx.convert_batch(net_g.model_id, [audio], p, None if noise is None else [noise],

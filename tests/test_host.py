@@ -94,3 +94,87 @@ def test_shard_is_a_balanced_partition():
 def test_make_clip_is_deterministic():
     a, b = S.make_clip(3, 1.0), S.make_clip(3, 1.0)
     assert a.dtype == np.float32 and a.shape == (16000,) and np.array_equal(a, b) and np.abs(a).max() < 1.0
+
+
+class _FakeCtx:
+    """Counts loads/unloads so the residency cache can be tested without a GPU."""
+
+    def __init__(self):
+        self.loads = []
+        self._h = None
+
+    def load_hubert(self, cfg, state):
+        self.loads.append("hubert")
+
+    def load_rmvpe(self, cfg, state):
+        self.loads.append("rmvpe")
+
+    def load_synth(self, cfg, state):
+        self.loads.append("synth")
+        return len(self.loads)
+
+
+def test_resident_asset_cache_is_keyed_by_path_and_mtime(tmp_path, monkeypatch):
+    """a checkpoint path loaded before (same realpath/mtime/size) is not reloaded; a touched
+    file is; voice models are kept least-recently-used up to MAX_RESIDENT_SYNTHS."""
+    import os
+    from polgen_rvc_amd import synthetic as S, weights as W, ckpt_io
+    from polgen_rvc_amd.infer import infer as I
+    fake = _FakeCtx()
+    monkeypatch.setitem(I._CTX, 0, fake)
+    I.clear_cache()
+    monkeypatch.setattr(W, "hubert_cfg_struct", lambda cfg: None)
+    monkeypatch.setattr(W, "rmvpe_cfg_struct", lambda cfg: None)
+    monkeypatch.setattr(W, "synth_cfg_struct", lambda cfg, d: None)
+    monkeypatch.setattr(ckpt_io, "load_fairseq_hubert", lambda p: {})
+    cpt = S.synth_checkpoint(S.SYNTH_CFG_TINY, 0)
+    cpt["weight"] = {"emb_g.weight": np.zeros((5, 4), np.float32),
+                     "enc_p.emb_phone.weight": np.zeros((48, 32), np.float32)}
+    monkeypatch.setattr(I, "_torch_load", lambda p: {k: (dict(v) if isinstance(v, dict) else
+                                                         (list(v) if isinstance(v, list) else v)) for k, v in cpt.items()})
+    hub, rm = tmp_path / "hubert_base.pt", tmp_path / "rmvpe.pt"
+    hub.write_bytes(b"x" * 10)
+    rm.write_bytes(b"y" * 10)
+    h1 = I.load_hubert("cuda:0", False, str(hub))
+    h2 = I.load_hubert("cuda:0", False, str(hub))
+    I.load_rmvpe("cuda:0", str(rm))
+    I.load_rmvpe("cuda:0", str(rm))
+    assert h1 is h2 and fake.loads == ["hubert", "rmvpe"]
+    os.utime(hub, ns=(1, 1))                                   # "new" file behind the same path
+    h3 = I.load_hubert("cuda:0", False, str(hub))
+    assert h3 is not h1 and fake.loads.count("hubert") == 2
+    # voice models
+    paths = []
+    for i in range(I.MAX_RESIDENT_SYNTHS + 2):
+        p = tmp_path / f"voice{i}.pth"
+        p.write_bytes(bytes([i]) * 8)
+        paths.append(str(p))
+    cfg = I.Config()
+    a = I.get_vc("cuda:0", False, cfg, paths[0])
+    b = I.get_vc("cuda:0", False, cfg, paths[0])
+    assert a[2] is b[2] and fake.loads.count("synth") == 1      # same resident model
+    assert b[0]["config"][-1] == a[3] == 4800 and "weight" not in b[0] and b[1] == "v2"
+    for p in paths[1:]:
+        I.get_vc("cuda:0", False, cfg, p)
+    assert len(I._SYNTHS) == I.MAX_RESIDENT_SYNTHS
+    n = fake.loads.count("synth")
+    I.get_vc("cuda:0", False, cfg, paths[0])                    # evicted meanwhile -> loaded again
+    assert fake.loads.count("synth") == n + 1
+    I.clear_cache()
+
+
+def test_load_audio_resamples_other_rates(tmp_path):
+    """my_utils.py:5-16: stereo 44.1 kHz int16 -> mono float64 at 16 kHz; a 440 Hz tone keeps its frequency and level."""
+    from scipy.io import wavfile
+    from polgen_rvc_amd.infer import infer as I
+    sr = 44100
+    t = np.arange(sr) / sr
+    tone = 0.5 * np.sin(2 * np.pi * 440 * t)
+    pcm = np.stack([tone, tone], axis=1)
+    wavfile.write(tmp_path / "a.wav", sr, (pcm * 32767).astype(np.int16))
+    y = I.load_audio(str(tmp_path / "a.wav"), 16000)
+    assert y.ndim == 1 and abs(len(y) - 16000) <= 1
+    ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(y)) / 16000)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3
+    wavfile.write(tmp_path / "b.wav", 16000, (ref * 32767).astype(np.int16))
+    assert np.abs(I.load_audio(str(tmp_path / "b.wav"), 16000) - ref).max() < 1e-4
