@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librvcx.so")
+LIB_PATH = os.environ.get("RVCX_LIBRARY") or os.path.join(_HERE, "librvcx.so")   # RVCX_LIBRARY: A/B runs of two builds
 
 
 class RvcxError(RuntimeError):

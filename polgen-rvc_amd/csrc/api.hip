@@ -67,6 +67,7 @@ int rvcx_create(int device, rvcx_ctx** out) {
     for (auto& s : h->c.aux) RVCX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     for (auto& e : h->c.ev_aux) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));
+    for (auto& e : h->c.ev_src) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     conv_init();
     h->c.resblock_streams = !getenv("RVCX_RESBLOCK_STREAMS") || atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;

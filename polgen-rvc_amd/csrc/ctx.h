@@ -58,6 +58,7 @@ struct Ctx {
   hipStream_t aux[2] = {nullptr, nullptr};   // the three ResBlocks of an NSF stage run side by side
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_src[2] = {nullptr, nullptr};   // NSF source branch (sine + noise convs) beside TextEncoder/flow
   Arena arena;
   Arena arena_f0;                 // RMVPE workspace: lives on stream2 across the main stream's arena resets
   WeightSlab slab;

@@ -72,6 +72,8 @@ Ctx::~Ctx() {
   for (auto* p : splitk_buf)
     if (p) (void)hipFree(p);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
+  for (auto e : ev_src)
+    if (e) (void)hipEventDestroy(e);
   if (ev_join) (void)hipEventDestroy(ev_join);
   for (auto e : ev_aux)
     if (e) (void)hipEventDestroy(e);

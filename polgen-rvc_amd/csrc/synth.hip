@@ -151,7 +151,7 @@ size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
     mx = std::max(mx, n);
     sum += n + 1024;
   }
-  return (enc + dec + sum + 9 * mx) * sizeof(float) + ((size_t)64 << 20);
+  return (enc + dec + 2 * sum + 9 * mx) * sizeof(float) + ((size_t)64 << 20);   // sum twice: stage outputs + noise-conv outputs
 }
 
 namespace {
@@ -208,6 +208,35 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
     }
   }
   std::vector<int> sidv(io.sid_host, io.sid_host + B);
+
+  // ================================================================ NSF source branch (nsf.py:116-129)
+  // The harmonic source and the four noise convs depend on f0 only: they run on a side stream beside the
+  // (latency-bound, 192-channel) TextEncoder and flow, and each stage's ConvTranspose1d adds its noise-conv
+  // output as the epilogue residual -- the same (up + bias) + (noise + bias) sum the reference forms, without
+  // a separate read-modify-write pass over the upsampled activations.
+  const long Tupp = (long)T * m.upp;
+  float* har = A.alloc<float>((size_t)B * Tupp);
+  std::vector<float*> nz(m.stages.size(), nullptr);
+  {
+    hipStream_t sn = c.serial ? s : c.aux[0];
+    if (sn != s) {
+      RVCX_HIP(hipEventRecord(c.ev_src[0], s));
+      RVCX_HIP(hipStreamWaitEvent(sn, c.ev_src[0], 0));
+    }
+    double* sc = A.alloc<double>((size_t)B * T * 2);
+    launch_sine_source(io.pitchf, io.src_noise, har, B, T, m.upp, (float)cf.sr, m.lin_wb, lens, sc, sn);
+    long tt = T;
+    for (size_t i = 0; i < m.stages.size(); ++i) {
+      const auto& S = m.stages[i];
+      tt *= cf.up_rates[i];
+      nz[i] = A.alloc<float>((size_t)B * S.ch * tt);
+      ConvArgs a = conv1d_args(S.noise, har, nz[i], B, (int)Tupp, (int)tt, S.noise_stride, 1, S.noise_pad);
+      a.lens_in = lens_stage[m.stages.size()];
+      a.lens_out = lens_stage[i + 1];
+      c.conv_on(a, sn);
+    }
+    if (sn != s) RVCX_HIP(hipEventRecord(c.ev_src[1], sn));
+  }
 
   // ================================================================ TextEncoder
   float* x = A.alloc<float>((size_t)B * hid * T);
@@ -303,12 +332,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
   tm.mark(2);
 
   // ================================================================ NSF-HiFi-GAN decoder
-  const long Tupp = (long)T * m.upp;
-  float* har = A.alloc<float>((size_t)B * Tupp);
-  {
-    double* sc = A.alloc<double>((size_t)B * T * 2);
-    launch_sine_source(io.pitchf, io.src_noise, har, B, T, m.upp, (float)cf.sr, m.lin_wb, lens, sc, s);
-  }
+  if (!c.serial) RVCX_HIP(hipStreamWaitEvent(s, c.ev_src[1], 0));
   const int C0 = cf.up_initial_channel;
   float* cur = A.alloc<float>((size_t)B * C0 * T);
   {
@@ -342,12 +366,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
     a.pre_slope = 0.1f;
     a.lens_in = lin;
     a.lens_out = lout;
-    c.conv(a);
-    // x = x + noise_conv(har_source)   (nsf.py:129)
-    a = conv1d_args(S.noise, har, xu, B, (int)Tupp, (int)Tout, S.noise_stride, 1, S.noise_pad);
-    conv_set_res(a, xu, S.ch, (int)Tout);
-    a.lens_in = lens_stage[m.stages.size()];
-    a.lens_out = lout;
+    conv_set_res(a, nz[i], S.ch, (int)Tout);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
     c.conv(a);
     // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
     // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases
