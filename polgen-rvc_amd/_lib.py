@@ -403,11 +403,11 @@ class Context:
         return ptr.value, n.value
 
     def conv_profile_begin(self):
-        z = (C.c_int64 * 40)()
+        z = (C.c_int64 * 48)()
         self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, None, 0), "conv_profile")
 
     def conv_profile_end(self):
-        N = 40
+        N = 48
         la, fl, ms = (C.c_int64 * N)(), (C.c_double * N)(), (C.c_double * N)()
         bm, bn, kd = (C.c_int32 * N)(), (C.c_int32 * N)(), (C.c_int32 * N)()
         self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, kd, N), "conv_profile")
@@ -415,6 +415,8 @@ class Context:
         def name(i):
             if kd[i] < 0:
                 return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
+            if kd[i] >= 400000:
+                return f"conv_h3<{bm[i]},{bn[i]}> (fp16 hi/lo split, 3 MFMA)"
             if kd[i] >= 300000:
                 return "conv_cin1 (vector FMA, Cin=1)"
             if kd[i] >= 200000:

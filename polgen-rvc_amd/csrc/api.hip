@@ -121,7 +121,7 @@ static void to_host(Ctx& c, float* h, const float* d, size_t n) {
   RVCX_HIP(hipMemcpyAsync(h, d, n * sizeof(float), hipMemcpyDeviceToHost, c.stream));
   RVCX_HIP(hipStreamSynchronize(c.stream));
 }
-static void ensure_slab(Ctx& c) { c.slab.init((size_t)3 << 30); }
+static void ensure_slab(Ctx& c) { c.slab.init((size_t)8 << 30); }
 
 int rvcx_op_conv1d(rvcx_ctx* ctx, const float* x, const float* w, const float* bias, const float* res,
                    float* y, int B, int Cin, int Tin, int Cout, int K, int stride, int dil,
@@ -132,7 +132,7 @@ int rvcx_op_conv1d(rvcx_ctx* ctx, const float* x, const float* w, const float* b
   size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tout;
   C->arena.reserve((nx + 2 * ny) * 4 + (64 << 20));
   C->arena.reset();
-  ConvW L = make_conv(*C, w, bias, Cout, Cin / groups, K, groups);
+  ConvW L = make_conv(*C, w, bias, Cout, Cin / groups, K, groups, true);
   float* dx = to_dev(*C, x, nx);
   float* dy = C->arena.alloc<float>(ny);
   ConvArgs a = conv1d_args(L, dx, dy, B, Tin, Tout, stride, dil, pad_left);
@@ -169,7 +169,7 @@ int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, i
   C->arena.reset();
   std::vector<float> w((size_t)Cout * (Cin / groups) * K), bias((size_t)Cout, 0.1f);
   for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
-  ConvW L = make_conv(*C, w.data(), bias.data(), Cout, Cin / groups, K, groups);
+  ConvW L = make_conv(*C, w.data(), bias.data(), Cout, Cin / groups, K, groups, true);
   float* dx = C->arena.alloc<float>(nx);
   float* dy = C->arena.alloc<float>(ny);
   float* dr = C->arena.alloc<float>(ny);

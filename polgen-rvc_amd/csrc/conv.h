@@ -23,6 +23,7 @@ enum Acc2 { ACC2_NONE = 0, ACC2_SET = 1, ACC2_ADD = 2, ACC2_ADD_DIV = 3 };
 struct ConvArgs {
   const float* x = nullptr;
   const float* w = nullptr;      // packed Wp[g][kk][Cin_gp][Cout_gp]
+  const void* w_h3 = nullptr;    // optional fp16 hi/lo split image of w (conv_h3.hip); null -> fp32 MFMA only
   const float* bias = nullptr;   // [groups*Cout_g] or null
   const float* res = nullptr;    // residual added after the activation (same indexing as y)
   float* y = nullptr;            // may be null when only y2 is wanted
@@ -64,7 +65,7 @@ inline int conv_tap_off(const ConvArgs& a, int kk) {
 }
 
 struct ConvProfile {
-  static constexpr int kMaxTiles = 40;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
+  static constexpr int kMaxTiles = 48;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
   long launches[kMaxTiles] = {0};
   double flops[kMaxTiles] = {0};
   double ms[kMaxTiles] = {0};
@@ -77,6 +78,9 @@ void conv_init();                                   // raise dynamic-LDS limits 
 void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + tile, launches
 int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-time-tiled family; profile slot or -1
 void conv_fast_describe(ConvProfile* p);
+int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream);   // fp16x3 split kernels; slot or -1
+bool conv_h3_enabled();
+void conv_h3_describe(ConvProfile* p);
 struct ConvOverride { int tile = -1, variant = -1, splitk = -1; };
 extern ConvOverride g_conv_override;   // tuning sweeps only (rvcx_conv_override)
 void conv_fast_init();

@@ -193,6 +193,7 @@ void conv_profile_end(ConvProfile* out) {
     out->halo[t] = -1;
   }
   conv_fast_describe(out);
+  conv_h3_describe(out);
   for (auto& r : g_prof) {
     RVCX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;

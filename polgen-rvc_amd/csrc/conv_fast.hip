@@ -628,6 +628,10 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     off_max = std::max(off_max, o);
   }
   const int halo = off_max - off_min;
+  {
+    const int slot = launch_conv_h3(a, halo, off_min, stream);
+    if (slot >= 0) return slot;
+  }
   // joint (tile, split-K) choice from a small cost model fitted to tools/sweep_conv.py on MI355X:
   //   block time = 2 bm bn (K/S + ovh_t) / (577 GFLOP/s x eff_t x f(c)),  c = blocks S / 256 blocks per CU,
   // f(c) = MFMA utilisation of a CU with c co-resident blocks (0.45 alone .. 1.0 from four up), ovh_t = the

@@ -1,0 +1,293 @@
+// Dense stride-1 1-D conv on the fp16 matrix cores with fp32-grade products ("h3": hi/lo split, 3 MFMAs).
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the fp16 rate.  Every fp32 operand is split into two
+// fp16 numbers, w = wh + wl, x = xh + xl (11 + 11 significant bits, |error| <= 2^-22 |w|), and
+//     w x  ~=  wh xh + wh xl + wl xh                       (the dropped wl xl term is 2^-22 relative)
+// Each fp16 x fp16 product is exact in fp32 and the sums accumulate in fp32 inside v_mfma_f32_32x32x16_f16, so the
+// result carries ~2^-21 relative error per product -- the size of fp32 rounding noise, not of fp16.  To keep the
+// low parts out of the fp16 subnormal range everything is computed at scale S = 256:
+//     S w x ~= (S wh) xh + wh (S xl) + (S wl) xh           operands A: {S wh, wh, S wl}   B: {xh, S xl}
+// and the epilogue multiplies by 1/S (exact).  Weights are split once at load (ctx.hip: pack_h3); activations are
+// split while they are committed to LDS.  3 MFMAs of 32 cycles replace 8 of 64: 5.3x fewer matrix-pipe cycles,
+// which moves the NSF decoder's ResBlock convs from the MFMA roofline to the HBM one.
+//
+// LDS images (16-byte elements = 8 halves = the k-slice a lane feeds to one MFMA):
+//   As[kkl][op][h][co]   co contiguous: lane (i, h) reads element (h, co0 + i)      -> linear, conflict-free
+//   Bs[op][h][p]         p  contiguous: lane (j, h) reads element (h, n + j + tap)  -> taps are plain offsets
+#include <cstdlib>
+
+#include "conv.h"
+#include "conv_device.h"
+
+namespace rvcx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr float kH3Scale = 256.f;
+
+struct H3Rsrc {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ H3Rsrc h3_rsrc(const void* base, int bytes) {
+  H3Rsrc b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+#endif
+  return b;
+}
+__device__ __forceinline__ float h3_load1(const H3Rsrc& b, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 0));
+#else
+  return 0.f;
+#endif
+}
+__device__ __forceinline__ uint4 h3_load4(const H3Rsrc& b, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 0));
+#else
+  return make_uint4(0, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x16 h3_mfma(half8 a, half8 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return c;
+#endif
+}
+constexpr int kH3Oob = 0x7ffffff0;
+
+template <int BM, int BN, int WR, int WC, int KKT>
+__global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
+  constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
+  constexpr int WROW = BN + 64;
+  constexpr int A_ELEMS = KKT * 3 * 2 * BM;          // 16-byte elements per stage
+  constexpr int NA = (A_ELEMS + 255) / 256;
+  constexpr int B_TASKS = 2 * WROW;                  // (h, position): 8 channels each
+  constexpr int NBT = (B_TASKS + 255) / 256;
+  static_assert(WR * WC == 4, "bad tile");
+  __shared__ uint4 As[A_ELEMS];
+  __shared__ uint4 Bs[2 * 2 * WROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int co0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
+  const int in_base = n0 + a.off_min;
+  const int wuse = BN + a.wrow;
+  const int pre_act = a.pre_act;
+  const float pre_slope = a.pre_slope;
+  const int nchunk = a.Cin_gp / 16;
+  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
+  const H3Rsrc wr_ = h3_rsrc(a.w_h3, a.ksize * nchunk * 6 * a.Cout_gp * 16);
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // chunk-invariant addressing
+  int a_kkl[NA], a_off[NA];     // element e = tid + 256 j -> (kkl, op, h, co); byte offset inside a (kk, chunk) slab
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int e = tid + 256 * j;
+    const int co = e % BM, rest = e / BM;              // rest = (kkl*3 + op)*2 + h
+    a_kkl[j] = rest / 6;
+    const bool ok = e < A_ELEMS && co0 + co < a.Cout_gp;
+    a_off[j] = ok ? ((rest % 6) * a.Cout_gp + co0 + co) * 16 : kH3Oob;
+  }
+  int b_off[NBT], b_h[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) {
+    const int t = tid + 256 * j;
+    const int hh = t / WROW, p = t - hh * WROW;
+    const int pos = in_base + p;
+    b_h[j] = hh;
+    b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len_in) ? pos * 4 : kH3Oob;
+  }
+  const int xrow = a.x_cs * 4;
+  const int slab = 6 * a.Cout_gp * 16;                 // bytes of one (kk, chunk) weight slab
+  const int nkk = (a.ksize + KKT - 1) / KKT;
+  const int nst = nchunk * nkk;
+
+  uint4 ra[NA];
+  float rb[NBT][8];
+  auto fetch_b = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int row0 = (chunk * 16 + 8 * b_h[j]) * xrow;   // rows >= Cin_g read as 0 (beyond num_records)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
+    }
+  };
+  auto fetch_a = [&](int chunk, int kk0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int kk = kk0 + a_kkl[j];
+      ra[j] = h3_load4(wr_, (kk < a.ksize && a_off[j] != kH3Oob) ? (kk * nchunk + chunk) * slab + a_off[j] : kH3Oob);
+    }
+  };
+  auto commit = [&](int kk0) {
+    if (kk0 == 0) {
+#pragma unroll
+      for (int j = 0; j < NBT; ++j) {
+        const int t = tid + 256 * j;
+        if (NBT * 256 == B_TASKS || t < B_TASKS) {
+          half8 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float v = rb[j][q];
+            if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
+            const _Float16 vh = (_Float16)v;
+            hi[q] = vh;
+            lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+          }
+          const int hh = t / WROW, p = t - hh * WROW;
+          Bs[hh * WROW + p] = __builtin_bit_cast(uint4, hi);
+          Bs[(2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (NA * 256 == A_ELEMS || tid + 256 * j < A_ELEMS) As[tid + 256 * j] = ra[j];
+  };
+
+  int chunk = 0, kk0 = 0;
+  if (nst > 0) {
+    fetch_b(0);
+    fetch_a(0, 0);
+  }
+  for (int st = 0; st < nst; ++st) {
+    __syncthreads();
+    commit(kk0);
+    __syncthreads();
+    int kk1 = kk0 + KKT, chunk1 = chunk;
+    if (kk1 >= a.ksize) {
+      kk1 = 0;
+      chunk1 += 1;
+    }
+    if (st + 1 < nst) fetch_a(chunk1, kk1);
+    if (kk0 == 0 && chunk + 1 < nchunk) fetch_b(chunk + 1);
+#pragma unroll
+    for (int kkl = 0; kkl < KKT; ++kkl) {
+      const int kk = kk0 + kkl;
+      if (KKT == 1 || kk < a.ksize) {
+        const int tp = kk * a.dil - a.pad - a.off_min;
+        half8 af[3][WM], bf[2][WN];
+#pragma unroll
+        for (int op = 0; op < 3; ++op)
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+            af[op][m] = __builtin_bit_cast(half8, As[((kkl * 3 + op) * 2 + h) * BM + wr * (WM * 32) + m * 32 + i]);
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+          for (int n = 0; n < WN; ++n)
+            bf[op][n] = __builtin_bit_cast(half8, Bs[(op * 2 + h) * WROW + wc * (WN * 32) + n * 32 + i + tp]);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) {
+            acc[m][n] = h3_mfma(af[0][m], bf[0][n], acc[m][n]);   // (S wh) xh
+            acc[m][n] = h3_mfma(af[1][m], bf[1][n], acc[m][n]);   // wh (S xl)
+            acc[m][n] = h3_mfma(af[2][m], bf[0][n], acc[m][n]);   // (S wl) xh
+          }
+      }
+    }
+    kk0 = kk1;
+    chunk = chunk1;
+  }
+
+  constexpr float inv = 1.f / kH3Scale;
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] *= inv;
+
+  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
+  const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+  if (fast_epilogue_ok(a)) {
+    store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
+    if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
+    if constexpr (WM > 1) {
+      store_tile_fast(a, b, co_w + 32, nn_w, acc[1][0], len_out);
+      if constexpr (WN > 1) store_tile_fast(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
+    }
+  } else {
+    store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
+    if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
+    if constexpr (WM > 1) {
+      store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
+      if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
+    }
+  }
+}
+
+namespace {
+struct H3Cfg {
+  int bm, bn;
+  void (*kern)(const ConvArgs);
+};
+const H3Cfg kH3[] = {
+    {32, 256, conv_h3_kernel<32, 256, 1, 4, 4>},
+    {64, 128, conv_h3_kernel<64, 128, 2, 2, 2>},
+    {64, 256, conv_h3_kernel<64, 256, 1, 4, 2>},
+};
+constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
+int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
+}  // namespace
+
+bool conv_h3_enabled() {
+  if (g_h3_mode < 0) g_h3_mode = getenv("RVCX_H3") ? atoi(getenv("RVCX_H3")) : 1;
+  return g_h3_mode != 0;
+}
+
+void conv_h3_describe(ConvProfile* p) {
+  for (int t = 0; t < kNumH3; ++t) {
+    p->bm[40 + t] = kH3[t].bm;
+    p->bn[40 + t] = kH3[t].bn;
+    p->halo[40 + t] = 400000;
+  }
+}
+
+// returns a profile slot (>= 0) when the launch was taken, -1 otherwise
+int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
+  if (!a.w_h3 || !conv_h3_enabled()) return -1;
+  if (a.stride != 1 || a.groups != 1 || a.kw != a.ksize || a.Cin_gp % 16 != 0 || halo > 64) return -1;
+  if (a.out_mode != OUT_NORMAL) return -1;
+  if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 6 >= kH3Oob) return -1;
+  // long sequences only: the split-K / small-grid cases stay on the fp32 family
+  int best = -1;
+  double best_w = 1e300;
+  for (int t = 0; t < kNumH3; ++t) {
+    if (g_conv_override.tile >= 100 && g_conv_override.tile - 100 != t) continue;
+    const long blocks = (long)cdiv(a.Cout_gp, kH3[t].bm) * cdiv(a.Nout, kH3[t].bn) * a.B;
+    if (blocks < 1024 && g_conv_override.tile < 100) continue;
+    const double work = (double)blocks * kH3[t].bm * kH3[t].bn * (t == 0 ? 1.0 : 1.02);
+    if (work < best_w) {
+      best_w = work;
+      best = t;
+    }
+  }
+  if (best < 0) return -1;
+  a.off_min = off_min;
+  a.wrow = halo;
+  a.splitk = 1;
+  dim3 grid(cdiv(a.Nout, kH3[best].bn), cdiv(a.Cout_gp, kH3[best].bm), a.B);
+  hipLaunchKernelGGL(kH3[best].kern, grid, dim3(256), 0, stream, a);
+  RVCX_HIP(hipGetLastError());
+  return 40 + best;   // profile slots 40.. (conv_h3_describe)
+}
+
+}  // namespace rvcx

@@ -93,16 +93,19 @@ struct Ctx {
 // packed conv layer living in the weight slab
 struct ConvW {
   const float* w = nullptr;
+  const void* w_h3 = nullptr;     // fp16 hi/lo split image (layers that may run on conv_h3_kernel)
   const float* bias = nullptr;
   int cin = 0, cout = 0, k = 1, groups = 1;
   int cin_gp = 0, cout_gp = 0;
 };
 
-ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups = 1);
+ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups = 1,
+               bool h3 = false);
 
 // fill the channel/pad fields of ConvArgs from a packed layer
 inline void conv_set_weights(ConvArgs& a, const ConvW& w) {
   a.w = w.w;
+  a.w_h3 = w.w_h3;
   a.bias = w.bias;
   a.groups = w.groups;
   a.Cin_g = w.cin / w.groups;

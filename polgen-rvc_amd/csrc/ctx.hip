@@ -1,4 +1,7 @@
 // Context lifecycle, checkpoint-tensor helpers, packed-layer constructors.
+#include <cmath>
+#include <cstring>
+
 #include "ctx.h"
 #include "layers.h"
 #include "models.h"
@@ -83,7 +86,35 @@ Ctx::~Ctx() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups) {
+// fp16 hi/lo split of the packed weights for conv_h3_kernel: H3[kk][chunk of 16 ci][op][h][co_pad][8 halves],
+// op 0 = S*wh, 1 = wh, 2 = S*wl  (S = 256; wh = fp16(w), wl = fp16((w - wh) * S) / S).  Returns an empty vector
+// when a weight would overflow fp16 at scale S (the layer then stays on the fp32 MFMA path).
+static std::vector<float> pack_h3(const std::vector<float>& wp, int k, int cin_gp, int cout_gp) {
+  const float S = 256.f;
+  const int nchunk = cin_gp / 16;
+  std::vector<_Float16> h((size_t)k * nchunk * 6 * cout_gp * 8);
+  for (int kk = 0; kk < k; ++kk)
+    for (int ch = 0; ch < nchunk; ++ch)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int co = 0; co < cout_gp; ++co)
+          for (int q = 0; q < 8; ++q) {
+            const int ci = ch * 16 + hh * 8 + q;
+            const float w = wp[((size_t)kk * cin_gp + ci) * cout_gp + co];
+            if (!(std::fabs(w) * S < 60000.f)) return {};
+            const _Float16 wh = (_Float16)w;
+            const _Float16 wl = (_Float16)((w - (float)wh) * S);
+            const size_t base = ((size_t)kk * nchunk + ch) * 6;
+            auto at = [&](int op) -> _Float16& { return h[(((base + op * 2 + hh) * cout_gp) + co) * 8 + q]; };
+            at(0) = (_Float16)((float)wh * S);
+            at(1) = wh;
+            at(2) = wl;
+          }
+  std::vector<float> out(h.size() / 2);
+  std::memcpy(out.data(), h.data(), h.size() * sizeof(_Float16));
+  return out;
+}
+
+ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups, bool h3) {
   ConvW L;
   L.cin = cin_g * groups;
   L.cout = cout;
@@ -91,7 +122,12 @@ ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, 
   L.groups = groups;
   L.cin_gp = conv_cin_pad(cin_g);
   L.cout_gp = conv_cout_pad(cout / groups);
-  L.w = c.slab.upload(pack_conv_weight(w, cout, cin_g, k, groups));
+  const std::vector<float> wp = pack_conv_weight(w, cout, cin_g, k, groups);
+  L.w = c.slab.upload(wp);
+  if (h3 && groups == 1 && L.cin_gp % 16 == 0 && conv_h3_enabled()) {
+    const std::vector<float> hp = pack_h3(wp, k, L.cin_gp, L.cout_gp);
+    if (!hp.empty()) L.w_h3 = c.slab.upload(hp);
+  }
   L.bias = bias ? c.slab.upload(bias, (size_t)cout) : nullptr;
   return L;
 }

@@ -40,7 +40,8 @@ std::vector<float> wn_weight(const TensorTable& t, const std::string& p, int dim
   return w;
 }
 
-static ConvW load_conv(Ctx& c, const TensorTable& t, const std::string& p, bool wn = false, bool bias = true) {
+static ConvW load_conv(Ctx& c, const TensorTable& t, const std::string& p, bool wn = false, bool bias = true,
+                       bool h3 = false) {
   std::vector<float> w = wn ? wn_weight(t, p) : t.f32(p + ".weight");
   const auto shp = wn ? t.shape(t.has(p + ".weight") ? p + ".weight"
                                 : (t.has(p + ".weight_v") ? p + ".weight_v"
@@ -49,7 +50,7 @@ static ConvW load_conv(Ctx& c, const TensorTable& t, const std::string& p, bool 
   const int cout = (int)shp[0], cin = (int)shp[1], k = shp.size() > 2 ? (int)shp[2] : 1;
   std::vector<float> b;
   if (bias && t.has(p + ".bias")) b = t.f32(p + ".bias");
-  return make_conv(c, w.data(), b.empty() ? nullptr : b.data(), cout, cin, k, 1);
+  return make_conv(c, w.data(), b.empty() ? nullptr : b.data(), cout, cin, k, 1, h3);
 }
 
 std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const TensorTable& t) {
@@ -128,8 +129,8 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
     for (int j = 0; j < cfg.n_resblocks; ++j)
       for (int m = 0; m < 3; ++m) {
         const std::string rp = "dec.resblocks." + std::to_string(i * cfg.n_resblocks + j);
-        S.c1[j][m] = load_conv(c, t, rp + ".convs1." + std::to_string(m), true);
-        S.c2[j][m] = load_conv(c, t, rp + ".convs2." + std::to_string(m), true);
+        S.c1[j][m] = load_conv(c, t, rp + ".convs1." + std::to_string(m), true, true, true);
+        S.c2[j][m] = load_conv(c, t, rp + ".convs2." + std::to_string(m), true, true, true);
       }
     M->stages.push_back(S);
     ch = co;

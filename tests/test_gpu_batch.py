@@ -102,5 +102,10 @@ def test_forced_tiles_and_splitk_agree(ctx, shape):
                 assert rms(got - ref) / rms(ref) < 2e-6, (tile, sk)
                 seen += 1
         assert seen == 45
+        # fp16 hi/lo split kernels (conv_h3.hip): fp32-grade products, same tolerance
+        for tile in (100, 101, 102):
+            ctx.conv_override(tile, 0, 1)
+            got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), stride=s, dil=d, pad_left=pad, Tout=ref.shape[2])
+            assert rms(got - ref) / rms(ref) < 2e-6, tile
     finally:
         ctx.conv_override(-1, -1, -1)

@@ -124,3 +124,22 @@ def test_convtranspose2d(ctx, case):
     ref = F.relu(F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1))
     got = ctx.convtranspose2d(x.numpy(), w.numpy(), b.numpy(), act=2)
     _chk(got, ref, str(case))
+
+
+@pytest.mark.parametrize("case", [(1, 32, 70000, 32, 3, 1), (2, 64, 40000, 64, 7, 3), (1, 128, 17000, 128, 11, 5),
+                                  (1, 256, 9000, 256, 7, 1)])
+def test_conv1d_h3_split_matches_fp64(ctx, case):
+    """Long-sequence dense convs run on conv_h3_kernel (fp16 hi/lo split, three v_mfma_f32_32x32x16_f16 per
+    product block): the result must be as close to the float64 convolution as an fp32 computation is
+    (relative RMS <= 1e-6; torch's own fp32 conv sits at ~2e-7), with the fused prologue/epilogue."""
+    B, C, T, Co, K, d = case
+    gen = torch.Generator().manual_seed(K * 1000 + C)
+    x = torch.randn(B, C, T, generator=gen) * 4
+    w = torch.randn(Co, C, K, generator=gen) / (C * K) ** 0.5
+    b = torch.randn(Co, generator=gen)
+    r = torch.randn(B, Co, T, generator=gen)
+    pad = (K * d - d) // 2
+    ref = (F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=d, padding=pad) + r.double()).numpy()
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), res=r.numpy(), dil=d, pad_left=pad, Tout=T, pre_lrelu=0.1)
+    e = rms(got - ref) / rms(ref)
+    assert np.isfinite(got).all() and e < 1e-6, e
