@@ -265,7 +265,6 @@ void conv_h3_describe(ConvProfile* p) {
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   if (!a.w_h3 || !conv_h3_enabled()) return -1;
   if (a.stride != 1 || a.groups != 1 || a.kw != a.ksize || a.Cin_gp % 16 != 0 || halo > 64) return -1;
-  if (a.out_mode != OUT_NORMAL) return -1;
   if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 6 >= kH3Oob) return -1;
   // long sequences only: the split-K / small-grid cases stay on the fp32 family
   int best = -1;

@@ -142,6 +142,10 @@ ConvT1dW make_convT1d(Ctx& c, const float* w, const float* bias, int cin, int co
   L.w.cin_gp = conv_cin_pad(cin);
   L.w.cout_gp = conv_cout_pad(pp.cout_total);
   L.w.w = c.slab.upload(pp.w);
+  if (L.w.cin_gp % 16 == 0 && conv_h3_enabled()) {   // polyphase taps are an ordinary dense stride-1 conv
+    const std::vector<float> hp = pack_h3(pp.w, pp.taps, L.w.cin_gp, L.w.cout_gp);
+    if (!hp.empty()) L.w.w_h3 = c.slab.upload(hp);
+  }
   L.w.bias = c.slab.upload(pp.bias);
   L.stride = s;
   L.pad_t = p;

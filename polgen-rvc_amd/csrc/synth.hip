@@ -108,9 +108,9 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
     std::vector<float> wb = {lw[0], lb[0]};
     M->lin_wb = c.slab.upload(wb);
   }
-  M->conv_pre = load_conv(c, t, "dec.conv_pre");
+  M->conv_pre = load_conv(c, t, "dec.conv_pre", false, true, true);
   M->cond = load_conv(c, t, "dec.cond");
-  M->conv_post = load_conv(c, t, "dec.conv_post", false, false);
+  M->conv_post = load_conv(c, t, "dec.conv_post", false, false, true);
   int ch = cfg.up_initial_channel;
   for (int i = 0; i < cfg.n_ups; ++i) {
     SynthModel::Stage S;
