@@ -80,6 +80,7 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-ti
 void conv_fast_describe(ConvProfile* p);
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream);   // fp16x3 split kernels; slot or -1
 bool conv_h3_enabled();
+void launch_splitk_finish(const ConvArgs& a, hipStream_t stream);   // deterministic reduction of the split-K slabs + epilogue
 void conv_h3_describe(ConvProfile* p);
 struct ConvOverride { int tile = -1, variant = -1, splitk = -1; };
 extern ConvOverride g_conv_override;   // tuning sweeps only (rvcx_conv_override)

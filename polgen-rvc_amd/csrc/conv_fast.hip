@@ -612,6 +612,12 @@ void conv_fast_describe(ConvProfile* p) {
     }
 }
 
+void launch_splitk_finish(const ConvArgs& a, hipStream_t stream) {
+  const long total = (long)a.B * a.Cout_g * a.Nout;
+  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)std::min<long>(cdiv64(total, 256), 4096)), dim3(256), 0,
+                     stream, a);
+}
+
 int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   if (a.Cin_g == 1 && a.groups == 1 && a.kw == a.ksize && a.ksize <= kCin1MaxK) {
     hipLaunchKernelGGL(conv_cin1_kernel, dim3(cdiv(a.Nout, 256), cdiv(a.Cout_g, 16), a.B), dim3(256), 0, stream, a);
@@ -703,11 +709,7 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   if (g_conv_override.variant >= 0) use_db = g_conv_override.variant != 0;
   if (!F.kern_db) use_db = false;
   hipLaunchKernelGGL(use_db ? F.kern_db : F.kern, grid, dim3(256), 0, stream, a);
-  if (S > 1) {
-    const long total = (long)a.B * a.Cout_g * a.Nout;
-    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)std::min<long>(cdiv64(total, 256), 4096)), dim3(256), 0,
-                       stream, a);
-  }
+  if (S > 1) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());
   return 8 + (use_db ? 16 : 0) + best;
 }

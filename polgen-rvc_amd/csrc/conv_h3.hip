@@ -14,6 +14,8 @@
 // LDS images (16-byte elements = 8 halves = the k-slice a lane feeds to one MFMA):
 //   As[kkl][op][h][co]   co contiguous: lane (i, h) reads element (h, co0 + i)      -> linear, conflict-free
 //   Bs[op][h][p]         p  contiguous: lane (j, h) reads element (h, n + j + tap)  -> taps are plain offsets
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "conv.h"
@@ -59,27 +61,30 @@ __device__ __forceinline__ f32x16 h3_mfma(half8 a, half8 b, f32x16 c) {
 }
 constexpr int kH3Oob = 0x7ffffff0;
 
-template <int BM, int BN, int WR, int WC, int KKT>
+// HALO: input-tile halo (64: 1-D k <= 11 d <= 5; 320: 3x3 on row-padded maps).  STRIDE 2: HuBERT extractor.
+// LIN: k = 1 layers -- a stage is KKT 16-channel chunks (each with its own input tile) instead of KKT taps.
+template <int BM, int BN, int WR, int WC, int KKT, int HALO, int STRIDE, bool LIN>
 __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
-  constexpr int WROW = BN + 64;
-  constexpr int A_ELEMS = KKT * 3 * 2 * BM;          // 16-byte elements per stage
+  constexpr int WROW = LIN ? BN : BN * STRIDE + HALO;
+  constexpr int NBTILE = LIN ? KKT : 1;               // input tiles resident per stage
+  constexpr int A_ELEMS = KKT * 3 * 2 * BM;           // 16-byte elements per stage
   constexpr int NA = (A_ELEMS + 255) / 256;
-  constexpr int B_TASKS = 2 * WROW;                  // (h, position): 8 channels each
+  constexpr int B_TASKS = NBTILE * 2 * WROW;          // (tile, h, position): 8 channels each
   constexpr int NBT = (B_TASKS + 255) / 256;
   static_assert(WR * WC == 4, "bad tile");
   __shared__ uint4 As[A_ELEMS];
-  __shared__ uint4 Bs[2 * 2 * WROW];
+  __shared__ uint4 Bs[NBTILE * 2 * 2 * WROW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int i = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / a.splitk, ks = blockIdx.z - b * a.splitk;
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
-  const int in_base = n0 + a.off_min;
-  const int wuse = BN + a.wrow;
+  const int in_base = n0 * STRIDE + a.off_min;
+  const int wuse = LIN ? BN : BN * STRIDE + a.wrow;
   const int pre_act = a.pre_act;
   const float pre_slope = a.pre_slope;
   const int nchunk = a.Cin_gp / 16;
@@ -104,39 +109,46 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     const bool ok = e < A_ELEMS && co0 + co < a.Cout_gp;
     a_off[j] = ok ? ((rest % 6) * a.Cout_gp + co0 + co) * 16 : kH3Oob;
   }
-  int b_off[NBT], b_h[NBT];
+  int b_off[NBT], b_row[NBT];    // task t = tid + 256 j -> (tile, h, p): position byte offset, first channel row
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int t = tid + 256 * j;
-    const int hh = t / WROW, p = t - hh * WROW;
+    const int th = t / WROW, p = t - th * WROW;        // th = tile*2 + h
     const int pos = in_base + p;
-    b_h[j] = hh;
+    b_row[j] = (th >> 1) * 16 + (th & 1) * 8;
     b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len_in) ? pos * 4 : kH3Oob;
   }
   const int xrow = a.x_cs * 4;
   const int slab = 6 * a.Cout_gp * 16;                 // bytes of one (kk, chunk) weight slab
-  const int nkk = (a.ksize + KKT - 1) / KKT;
-  const int nst = nchunk * nkk;
+  // this split's chunk range, and the stage structure: LIN -> stages of KKT chunks; else (chunk, tap-group)
+  const int cb0 = ks * nchunk / a.splitk, cb1 = (ks + 1) * nchunk / a.splitk;
+  const int nkk = LIN ? 1 : (a.ksize + KKT - 1) / KKT;
+  const int nst = LIN ? (cb1 - cb0 + KKT - 1) / KKT : (cb1 - cb0) * nkk;
 
   uint4 ra[NA];
   float rb[NBT][8];
-  auto fetch_b = [&](int chunk) {
+  auto fetch_b = [&](int chunk) {                      // LIN: chunks chunk .. chunk+KKT-1 (clipped to cb1)
 #pragma unroll
     for (int j = 0; j < NBT; ++j) {
-      const int row0 = (chunk * 16 + 8 * b_h[j]) * xrow;   // rows >= Cin_g read as 0 (beyond num_records)
+      const int crow = chunk * 16 + b_row[j];
+      const bool cok = !LIN || crow < cb1 * 16;
+      const int row0 = crow * xrow;                    // rows >= Cin_g read as 0 (beyond num_records)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
+      for (int q = 0; q < 8; ++q)
+        rb[j][q] = h3_load1(xr, (b_off[j] == kH3Oob || !cok) ? kH3Oob : row0 + q * xrow + b_off[j]);
     }
   };
   auto fetch_a = [&](int chunk, int kk0) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int kk = kk0 + a_kkl[j];
-      ra[j] = h3_load4(wr_, (kk < a.ksize && a_off[j] != kH3Oob) ? (kk * nchunk + chunk) * slab + a_off[j] : kH3Oob);
+      const int kk = LIN ? 0 : kk0 + a_kkl[j];
+      const int ch = LIN ? chunk + a_kkl[j] : chunk;
+      const bool ok = a_off[j] != kH3Oob && (LIN ? ch < cb1 : kk < a.ksize);
+      ra[j] = h3_load4(wr_, ok ? (kk * nchunk + ch) * slab + a_off[j] : kH3Oob);
     }
   };
   auto commit = [&](int kk0) {
-    if (kk0 == 0) {
+    if (LIN || kk0 == 0) {
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
         const int t = tid + 256 * j;
@@ -150,9 +162,10 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
             hi[q] = vh;
             lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
           }
-          const int hh = t / WROW, p = t - hh * WROW;
-          Bs[hh * WROW + p] = __builtin_bit_cast(uint4, hi);
-          Bs[(2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+          const int th = t / WROW, p = t - th * WROW;
+          const int tile = th >> 1, hh = th & 1;
+          Bs[(tile * 4 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
+          Bs[(tile * 4 + 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
         }
       }
     }
@@ -161,27 +174,37 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
       if (NA * 256 == A_ELEMS || tid + 256 * j < A_ELEMS) As[tid + 256 * j] = ra[j];
   };
 
-  int chunk = 0, kk0 = 0;
+  int chunk = cb0, kk0 = 0;
   if (nst > 0) {
-    fetch_b(0);
-    fetch_a(0, 0);
+    fetch_b(cb0);
+    fetch_a(cb0, 0);
   }
   for (int st = 0; st < nst; ++st) {
     __syncthreads();
     commit(kk0);
     __syncthreads();
-    int kk1 = kk0 + KKT, chunk1 = chunk;
-    if (kk1 >= a.ksize) {
-      kk1 = 0;
-      chunk1 += 1;
+    int kk1 = kk0, chunk1 = chunk;
+    if (LIN) {
+      chunk1 += KKT;
+    } else {
+      kk1 += KKT;
+      if (kk1 >= a.ksize) {
+        kk1 = 0;
+        chunk1 += 1;
+      }
     }
     if (st + 1 < nst) fetch_a(chunk1, kk1);
-    if (kk0 == 0 && chunk + 1 < nchunk) fetch_b(chunk + 1);
+    if (LIN) {
+      if (st + 1 < nst) fetch_b(chunk1);
+    } else if (kk0 == 0 && chunk + 1 < cb1) {
+      fetch_b(chunk + 1);
+    }
 #pragma unroll
     for (int kkl = 0; kkl < KKT; ++kkl) {
       const int kk = kk0 + kkl;
-      if (KKT == 1 || kk < a.ksize) {
-        const int tp = kk * a.dil - a.pad - a.off_min;
+      if (LIN ? (chunk + kkl < cb1) : (KKT == 1 || kk < a.ksize)) {
+        const int tp = LIN ? 0 : (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
+        const uint4* Bt = Bs + (LIN ? kkl * 4 * WROW : 0);
         half8 af[3][WM], bf[2][WN];
 #pragma unroll
         for (int op = 0; op < 3; ++op)
@@ -192,7 +215,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
         for (int op = 0; op < 2; ++op)
 #pragma unroll
           for (int n = 0; n < WN; ++n)
-            bf[op][n] = __builtin_bit_cast(half8, Bs[(op * 2 + h) * WROW + wc * (WN * 32) + n * 32 + i + tp]);
+            bf[op][n] = __builtin_bit_cast(half8, Bt[(op * 2 + h) * WROW + (wc * (WN * 32) + n * 32 + i) * STRIDE + tp]);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -217,6 +240,24 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+  if (a.splitk > 1) {
+    // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
+    float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int nn = nn_w + n * 32;
+        if (nn < a.Nout) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_w + m * 32 + (r & 3) + 8 * (r >> 2);
+            if (co < a.Cout_g) pb[(long)co * a.Nout + nn] = acc[m][n][r];
+          }
+        }
+      }
+    return;
+  }
   if (fast_epilogue_ok(a)) {
     store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
     if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
@@ -236,13 +277,26 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 
 namespace {
 struct H3Cfg {
-  int bm, bn;
+  int bm, bn, halo, stride;   // halo 0 + lin: k = 1 layers
+  bool lin;
+  float ovh;                  // per-block prologue + epilogue in 16-channel k-steps of MFMA time (cost model)
+  float eff;                  // relative main-loop efficiency (wave tile 32x64 reuses fragments, 32x32 does not)
   void (*kern)(const ConvArgs);
 };
 const H3Cfg kH3[] = {
-    {32, 256, conv_h3_kernel<32, 256, 1, 4, 4>},
-    {64, 128, conv_h3_kernel<64, 128, 2, 2, 2>},
-    {64, 256, conv_h3_kernel<64, 256, 1, 4, 2>},
+    // 1-D, halo <= 64
+    {32, 256, 64, 1, false, 18.f, 1.00f, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false>},
+    {64, 128, 64, 1, false, 16.f, 0.97f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false>},
+    {64, 64, 64, 1, false, 16.f, 0.75f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false>},
+    // 3x3 on row-padded maps
+    {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>},
+    {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>},
+    // stride 2
+    {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>},
+    {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>},
+    // k = 1
+    {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>},
+    {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
@@ -254,39 +308,56 @@ bool conv_h3_enabled() {
 }
 
 void conv_h3_describe(ConvProfile* p) {
-  for (int t = 0; t < kNumH3; ++t) {
-    p->bm[40 + t] = kH3[t].bm;
-    p->bn[40 + t] = kH3[t].bn;
-    p->halo[40 + t] = 400000;
+  for (int t = 0; t < kNumH3 && 39 + t < ConvProfile::kMaxTiles; ++t) {
+    p->bm[39 + t] = kH3[t].bm;
+    p->bn[39 + t] = kH3[t].bn;
+    p->halo[39 + t] = 400000;
   }
 }
 
 // returns a profile slot (>= 0) when the launch was taken, -1 otherwise
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   if (!a.w_h3 || !conv_h3_enabled()) return -1;
-  if (a.stride != 1 || a.groups != 1 || a.kw != a.ksize || a.Cin_gp % 16 != 0 || halo > 64) return -1;
+  if (a.groups != 1 || a.Cin_gp % 16 != 0 || (a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize))) return -1;
   if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 6 >= kH3Oob) return -1;
-  // long sequences only: the split-K / small-grid cases stay on the fp32 family
-  int best = -1;
-  double best_w = 1e300;
+  const bool lin = a.ksize == 1 && a.stride == 1;
+  const int nchunk = a.Cin_gp / 16;
+  // cost model in the shape of conv_fast's: the three fp16 MFMAs of a (tap, 16-channel) k-step cost 96 matrix-pipe
+  // cycles for 32x32x16 MACs; fitted on the NSF shapes: a CU retires ~39 k-steps of a 32x32 tile per microsecond with
+  // >= 4 blocks resident, a block's prologue + epilogue cost ~18 k-steps per 32x32 tile
+  int best = -1, S = 1;
+  double best_t = 1e300;
   for (int t = 0; t < kNumH3; ++t) {
+    const H3Cfg& F = kH3[t];
     if (g_conv_override.tile >= 100 && g_conv_override.tile - 100 != t) continue;
-    const long blocks = (long)cdiv(a.Cout_gp, kH3[t].bm) * cdiv(a.Nout, kH3[t].bn) * a.B;
-    if (blocks < 1024 && g_conv_override.tile < 100) continue;
-    const double work = (double)blocks * kH3[t].bm * kH3[t].bn * (t == 0 ? 1.0 : 1.02);
-    if (work < best_w) {
-      best_w = work;
-      best = t;
+    if (F.lin != lin || F.stride != a.stride) continue;
+    if (!lin && (halo > F.halo || (F.halo == 320 && halo <= 64))) continue;
+    const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * a.B;
+    const double ksteps = (double)a.ksize * nchunk;
+    for (int s = 1; s <= 8; s *= 2) {
+      if (s > 1 && (!a.part || nchunk / s < 1 || ksteps / s < 8.0 || (long)s * a.B * a.Cout_g * a.Nout > a.part_cap)) break;
+      if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
+      const double c = (double)blocks * s / 256.0;
+      const double f = std::min(1.0, 0.45 + 0.55 * (std::max(c, 1.0) - 1.0) / 3.0);
+      double us = std::ceil(c) * (F.bm / 32) * (F.bn / 32) * (ksteps / s + F.ovh) / (39.0 * F.eff * f);
+      if (s > 1) us += 3.0 + (double)(s + 1) * a.B * a.Cout_g * a.Nout * 4.0 / 3e6;
+      if (us < best_t) {
+        best_t = us;
+        best = t;
+        S = s;
+      }
     }
   }
   if (best < 0) return -1;
+  const H3Cfg& F = kH3[best];
   a.off_min = off_min;
   a.wrow = halo;
-  a.splitk = 1;
-  dim3 grid(cdiv(a.Nout, kH3[best].bn), cdiv(a.Cout_gp, kH3[best].bm), a.B);
-  hipLaunchKernelGGL(kH3[best].kern, grid, dim3(256), 0, stream, a);
+  a.splitk = S;
+  dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
+  hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
+  if (S > 1) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());
-  return 40 + best;   // profile slots 40.. (conv_h3_describe)
+  return 39 + best;   // profile slots 39.. (conv_h3_describe)
 }
 
 }  // namespace rvcx

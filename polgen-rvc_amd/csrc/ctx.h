@@ -100,7 +100,7 @@ struct ConvW {
 };
 
 ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups = 1,
-               bool h3 = false);
+               bool h3 = true);
 
 // fill the channel/pad fields of ConvArgs from a packed layer
 inline void conv_set_weights(ConvArgs& a, const ConvW& w) {

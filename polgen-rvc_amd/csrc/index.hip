@@ -13,7 +13,7 @@ std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, i
   auto ix = std::make_unique<IndexData>();
   ix->n = n;
   ix->dim = dim;
-  ix->mat = make_conv(c, big_npy, nullptr, (int)n, dim, 1, 1);
+  ix->mat = make_conv(c, big_npy, nullptr, (int)n, dim, 1, 1, false);   // exact fp32 products: neighbour ids are bit-exact
   ix->rows = c.slab.upload(big_npy, (size_t)n * dim);
   std::vector<float> norms((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
