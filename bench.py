@@ -26,6 +26,10 @@ import polgen_rvc_amd  # noqa: E402
 from polgen_rvc_amd import _lib, dist as D, synthetic as S, weights as W  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
+PEAK_F16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
+# conv_h3 kernels form every fp32 product block from three fp16 MFMAs (hi/lo split, fp32 accumulate): the ceiling
+# for ALGORITHMIC conv FLOPs on them is a third of the fp16 MFMA peak.
+PEAK_H3_TFLOPS = PEAK_F16_TFLOPS / 3.0
 CLIP_SECONDS = 30.0
 CPU_SAMPLE_SECONDS = 8.0
 
@@ -72,6 +76,15 @@ def pmc_traffic(tile_name):
     path = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
     if not os.path.exists(path):
         return None, None
+    kernels = json.load(open(path))["kernels"]
+    mh = re.match(r"conv_h3<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
+    if mh:
+        want = f"conv_h3_kernel<{mh.group(1)}, {mh.group(2)},"
+        tail = {"linear": ", 0, 1, true>", "stride2": ", 64, 2, false>"}.get(mh.group(3), f", {mh.group(4)}, 1, false>")
+        for k, v in kernels.items():
+            if want in k and tail in k:
+                return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        return None, None
     m = re.match(r"conv_fast_(sb|db)<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
     if not m:
         return None, None
@@ -80,7 +93,7 @@ def pmc_traffic(tile_name):
     tail = {"linear": ", 32, 0", "stride2": ", 16, 64, 2>"}.get(m.group(4), f", 16, {m.group(5)}")
     if m.group(1) == "sb" and m.group(4) != "stride2":
         tail += ", 1>"   # trailing STRIDE template argument of conv_fast_sb_kernel
-    for k, v in json.load(open(path))["kernels"].items():
+    for k, v in kernels.items():
         if want in k and tail in k:
             return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
     return None, None
@@ -151,13 +164,18 @@ def main():
     conv_flops = sum(r["flops"] for r in prof)
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(dom["tile"])
+    h3 = dom["tile"].startswith("conv_h3")
+    peak = PEAK_H3_TFLOPS if h3 else PEAK_F32_TFLOPS
     roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
-                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (each fp32 product block = 3 fp16 MFMAs of a hi/lo "
+                              "split); 'achieved' counts algorithmic 2*M*N*K conv FLOPs" if h3 else
+                              "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                 "traffic_source": traffic_src,
                 "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                 "flops_per_launch": dom["flops"] / dom["launches"],
                 "family": {"ms": conv_ms, "tflops": conv_flops / (conv_ms * 1e-3) / 1e12,
-                           "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                           "frac_of_fp32_mfma_peak": conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                            "share_of_step": conv_ms / ms_per_step},
                 "whole_path_tflops": total_flops / (ms_per_step * 1e-3) / 1e12}
 
@@ -165,7 +183,8 @@ def main():
         res = {"metric": "real-time-factor (audio-sec/wall-sec) per GPU, 30s@16kHz RMVPE->48kHz",
                "value": rtf, "unit": "x real-time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32 (conv products as 3 fp16 MFMAs of a hi/lo split, fp32 accumulate; fp32 elsewhere)",
+               "data": "synthetic",
                "config": {"workload": "single 30 s 16 kHz clip per GPU per step, RVC v2 48k, f0_method=rmvpe+, "
                                       "HuBERT-base, index_rate=0, geometry (1,6,38,41), PCM resident in HBM",
                           "out_samples": got, "weights_bcast_bytes": nbytes, "weights_bcast_s": t_bcast,

@@ -311,7 +311,7 @@ void conv_h3_describe(ConvProfile* p) {
   for (int t = 0; t < kNumH3 && 39 + t < ConvProfile::kMaxTiles; ++t) {
     p->bm[39 + t] = kH3[t].bm;
     p->bn[39 + t] = kH3[t].bn;
-    p->halo[39 + t] = 400000;
+    p->halo[39 + t] = 400000 + (kH3[t].lin ? 1 : (kH3[t].stride == 2 ? 2 : kH3[t].halo));
   }
 }
 
