@@ -403,11 +403,11 @@ class Context:
         return ptr.value, n.value
 
     def conv_profile_begin(self):
-        z = (C.c_int64 * 48)()
+        z = (C.c_int64 * 56)()
         self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, None, 0), "conv_profile")
 
     def conv_profile_end(self):
-        N = 48
+        N = 56
         la, fl, ms = (C.c_int64 * N)(), (C.c_double * N)(), (C.c_double * N)()
         bm, bn, kd = (C.c_int32 * N)(), (C.c_int32 * N)(), (C.c_int32 * N)()
         self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, kd, N), "conv_profile")

@@ -65,7 +65,7 @@ inline int conv_tap_off(const ConvArgs& a, int kk) {
 }
 
 struct ConvProfile {
-  static constexpr int kMaxTiles = 48;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
+  static constexpr int kMaxTiles = 56;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
   long launches[kMaxTiles] = {0};
   double flops[kMaxTiles] = {0};
   double ms[kMaxTiles] = {0};

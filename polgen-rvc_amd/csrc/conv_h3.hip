@@ -21,6 +21,12 @@
 #include "conv.h"
 #include "conv_device.h"
 
+#ifdef RVCX_ABLATION
+#define H3_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define H3_DBG(a, bit) 0
+#endif
+
 namespace rvcx {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -180,9 +186,11 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     fetch_a(cb0, 0);
   }
   for (int st = 0; st < nst; ++st) {
-    __syncthreads();
-    commit(kk0);
-    __syncthreads();
+    if (!H3_DBG(a, 32) || st == 0) {
+      __syncthreads();
+      commit(kk0);
+      __syncthreads();
+    }
     int kk1 = kk0, chunk1 = chunk;
     if (LIN) {
       chunk1 += KKT;
@@ -193,16 +201,18 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
         chunk1 += 1;
       }
     }
-    if (st + 1 < nst) fetch_a(chunk1, kk1);
-    if (LIN) {
-      if (st + 1 < nst) fetch_b(chunk1);
-    } else if (kk0 == 0 && chunk + 1 < cb1) {
-      fetch_b(chunk + 1);
+    if (!H3_DBG(a, 16)) {
+      if (st + 1 < nst) fetch_a(chunk1, kk1);
+      if (LIN) {
+        if (st + 1 < nst) fetch_b(chunk1);
+      } else if (kk0 == 0 && chunk + 1 < cb1) {
+        fetch_b(chunk + 1);
+      }
     }
 #pragma unroll
     for (int kkl = 0; kkl < KKT; ++kkl) {
       const int kk = kk0 + kkl;
-      if (LIN ? (chunk + kkl < cb1) : (KKT == 1 || kk < a.ksize)) {
+      if ((LIN ? (chunk + kkl < cb1) : (KKT == 1 || kk < a.ksize)) && !H3_DBG(a, 4)) {
         const int tp = LIN ? 0 : (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
         const uint4* Bt = Bs + (LIN ? kkl * 4 * WROW : 0);
         half8 af[3][WM], bf[2][WN];
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
+  if (H3_DBG(a, 8)) return;
   if (a.splitk > 1) {
     // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
     float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
@@ -297,6 +308,9 @@ const H3Cfg kH3[] = {
     // k = 1
     {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>},
     {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>},
+    // 64x64 wave tiles (fewer LDS fragment reads per MFMA)
+    {64, 256, 64, 1, false, 18.f, 0.5f, conv_h3_kernel<64, 256, 1, 4, 2, 64, 1, false>},
+    {128, 128, 64, 1, false, 18.f, 0.5f, conv_h3_kernel<128, 128, 2, 2, 2, 64, 1, false>},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
@@ -353,6 +367,11 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   a.off_min = off_min;
   a.wrow = halo;
   a.splitk = S;
+  {
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("RVCX_CONV_DBG") ? atoi(getenv("RVCX_CONV_DBG")) : 0;
+    a.dbg = dbg;
+  }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
   hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) launch_splitk_finish(a, stream);
