@@ -308,9 +308,6 @@ const H3Cfg kH3[] = {
     // k = 1
     {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>},
     {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>},
-    // 64x64 wave tiles (fewer LDS fragment reads per MFMA)
-    {64, 256, 64, 1, false, 18.f, 0.5f, conv_h3_kernel<64, 256, 1, 4, 2, 64, 1, false>},
-    {128, 128, 64, 1, false, 18.f, 0.5f, conv_h3_kernel<128, 128, 2, 2, 2, 64, 1, false>},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)

@@ -18,7 +18,7 @@ for name, cin, T, cout, k, st, d in SH:
     ctx.conv_override(-1, -1, -1)
     base, _ = ctx.bench_conv1d(1, cin, T, cout, k, st, d, 1, it)
     res = []
-    for t in range(11):
+    for t in range(9):
         for sk in (1, 2, 4, 8):
             if sk > 1 and T > 8000:
                 continue
