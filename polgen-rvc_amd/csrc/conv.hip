@@ -294,7 +294,8 @@ PolyPhase1d pack_convtranspose1d(const float* w, const float* bias, int cin, int
                                  int p) {
   // y[co][t] = sum_ci sum_kk W[ci][co][kk] x[ci][(t+p-kk)/s].  With u=t+p, q=u/s, ph=u%s,
   // kk = ph + m*s, the input index is q-m: a conv over q with taps m' = M-1-m at offset
-  // m' - (M-1), producing channel ph*cout+co, stored at t = q*s + ph - p.
+  // m' - (M-1), producing channel co*s+ph (phase fastest: the 4 consecutive accumulator rows a lane owns are 4
+  // consecutive output samples, so the shuffle store writes 16 contiguous bytes per lane), stored at t = q*s + ph - p.
   PolyPhase1d r;
   const int M = cdiv(k, s);
   r.taps = M;
@@ -307,13 +308,13 @@ PolyPhase1d pack_convtranspose1d(const float* w, const float* bias, int cin, int
         for (int mp = 0; mp < M; ++mp) {
           int kk = ph + (M - 1 - mp) * s;
           if (kk < k)
-            wc[(((size_t)(ph * cout + co)) * cin + ci) * M + mp] = w[((size_t)ci * cout + co) * k + kk];
+            wc[(((size_t)(co * s + ph)) * cin + ci) * M + mp] = w[((size_t)ci * cout + co) * k + kk];
         }
   r.w = pack_conv_weight(wc.data(), s * cout, cin, M, 1);
   r.bias.resize((size_t)s * cout, 0.f);
   if (bias)
     for (int ph = 0; ph < s; ++ph)
-      for (int co = 0; co < cout; ++co) r.bias[(size_t)ph * cout + co] = bias[co];
+      for (int co = 0; co < cout; ++co) r.bias[(size_t)co * s + ph] = bias[co];
   return r;
 }
 

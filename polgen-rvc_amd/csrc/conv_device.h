@@ -37,7 +37,7 @@ __device__ __forceinline__ void store_elem(const ConvArgs& a, int b, int cg, int
       else *p2 = (*p2 + v) / a.acc2_div;
     }
   } else if (a.out_mode == OUT_SHUF1D) {
-    const int ph = cg / a.sh_cout, c = cg - ph * a.sh_cout;
+    const int c = cg / a.sh_s, ph = cg - c * a.sh_s;   // packed channel = c * stride + phase
     const int t = nn * a.sh_s + ph - a.sh_pad;
     if (t >= 0 && t < a.sh_tout) {
       if (a.res) v += a.res[(long)b * a.res_bs + (long)c * a.res_cs + t];
