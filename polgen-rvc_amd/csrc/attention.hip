@@ -167,31 +167,39 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
 }
 
 // merge the split-KV partials: out = sum_s e^(m_s - m) O_s / sum_s e^(m_s - m) l_s
-__global__ void attn_merge_kernel(const float* __restrict__ opart, float* __restrict__ out, float* m_out,
-                                  float* l_out, int H, int D, int DP, int T, int ld, long out_bs, int nsplit,
-                                  const int* lens) {
+// grid.y = head * 4 + quarter of the head dimension: 4x the workgroups of a (query block, head) grid
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ opart, float* __restrict__ out,
+                                                         float* m_out, float* l_out, int H, int D, int DP, int T, int ld,
+                                                         long out_bs, int nsplit, const int* lens) {
   const int t = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  const int hd = blockIdx.y, b = blockIdx.z;
+  const int hd = blockIdx.y >> 2, dq = blockIdx.y & 3, b = blockIdx.z;
   if (t >= T) return;
   const float* pb = opart + (((long)b * H + hd) * nsplit) * (DP + 2) * T;
   const long ss = (long)(DP + 2) * T;
-  float m = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pb[s * ss + (long)DP * T + t]);
-  float w[8], l = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float ms = pb[s * ss + (long)DP * T + t];
-    w[s] = (ms == -INFINITY) ? 0.f : expf(ms - m);
-    l += w[s] * pb[s * ss + (long)(DP + 1) * T + t];
+  float ms[8], w[8];
+  float m = -INFINITY, l = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    ms[s] = s < nsplit ? pb[s * ss + (long)DP * T + t] : -INFINITY;
+    m = fmaxf(m, ms[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    w[s] = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - m);
+    if (s < nsplit) l += w[s] * pb[s * ss + (long)(DP + 1) * T + t];
   }
   const int len = lens ? lens[b] : T;
   const float inv = 1.f / l;
   float* ob = out + (long)b * out_bs + (long)hd * D * ld;
-  for (int d = part; d < D; d += 4) {
+  const int dper = (D + 3) / 4, d0 = dq * dper, d1 = min(D, d0 + dper);
+  for (int d = d0 + part; d < d1; d += 4) {
     float acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) acc += w[s] * pb[s * ss + (long)d * T + t];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < nsplit) acc += w[s] * pb[s * ss + (long)d * T + t];
     ob[(long)d * ld + t] = t < len ? acc * inv : 0.f;
   }
-  if (m_out && part == 0) {
+  if (m_out && part == 0 && dq == 0) {
     m_out[((long)b * H + hd) * T + t] = m;
     l_out[((long)b * H + hd) * T + t] = l;
   }
@@ -325,7 +333,7 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
     hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
                        out_bs, scale, window, lens, nsplit, opart);
   if (nsplit > 1)
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(T, 64), H, B), dim3(256), 0, stream, opart, out, mb, lb, H, D,
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(cdiv(T, 64), H * 4, B), dim3(256), 0, stream, opart, out, mb, lb, H, D,
                        32 * DT, T, ld, out_bs, nsplit, lens);
   if (emb_rel_v) {
     size_t lds = ((size_t)nrel * D + 32 * (nrel + 1) + (size_t)D * 32 + (size_t)D * (32 + 2 * window)) * sizeof(float);

@@ -41,7 +41,7 @@ std::vector<float> wn_weight(const TensorTable& t, const std::string& p, int dim
 }
 
 static ConvW load_conv(Ctx& c, const TensorTable& t, const std::string& p, bool wn = false, bool bias = true,
-                       bool h3 = false) {
+                       bool h3 = true) {
   std::vector<float> w = wn ? wn_weight(t, p) : t.f32(p + ".weight");
   const auto shp = wn ? t.shape(t.has(p + ".weight") ? p + ".weight"
                                 : (t.has(p + ".weight_v") ? p + ".weight_v"
