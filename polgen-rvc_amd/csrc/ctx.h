@@ -55,6 +55,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second stream: RMVPE runs beside HuBERT
+  hipStream_t stream_h = nullptr; // optional CU-masked stream for HuBERT (RVCX_HUBERT_CUS): leaves CUs free for RMVPE
+  hipEvent_t ev_hub = nullptr;
   hipStream_t aux[2] = {nullptr, nullptr};   // the three ResBlocks of an NSF stage run side by side
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -448,7 +448,16 @@ long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_para
     float* feats = A.alloc<float>((size_t)E * Th);
     {
       const size_t mk2 = A.mark();
-      hubert_forward(c, *c.hubert, 1, apad + ch.s, ns, 12, feats, s, &enqueue_f0);
+      hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;
+      if (sh != s) {
+        RVCX_HIP(hipEventRecord(c.ev_hub, s));
+        RVCX_HIP(hipStreamWaitEvent(sh, c.ev_hub, 0));
+      }
+      hubert_forward(c, *c.hubert, 1, apad + ch.s, ns, 12, feats, sh, &enqueue_f0);
+      if (sh != s) {
+        RVCX_HIP(hipEventRecord(c.ev_hub, sh));
+        RVCX_HIP(hipStreamWaitEvent(s, c.ev_hub, 0));
+      }
       A.reset(mk2);
     }
     const int h1 = clk.mark(s);
