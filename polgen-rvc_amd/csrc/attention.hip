@@ -7,6 +7,8 @@
 // plus one cross-half shuffle, and the softmaxed registers are *already* the B fragment of
 // O^T += V P^T (MFMA k-slot s of lane-half h <-> key (s&3)+8(s>>2)+4h; V's A fragment is read
 // from LDS with the same permutation, so P never moves between lanes).
+#include <cstdlib>
+
 #include "ops.h"
 
 namespace rvcx {
@@ -166,6 +168,271 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same flash-style kernel on the fp16 matrix cores with fp32-grade products (hi/lo split, three
+// v_mfma_f32_32x32x16_f16 per product block, scale S = 256; see conv_h3.hip for the arithmetic).
+//   S^T = K^T Q : A = K tile, LDS image [k16-step][op {S kh, kh, S kl}][h][key] (16 B = 8 head dims),
+//                 B = Q fragment {qh, S ql} in registers (loaded once per workgroup)
+//   O^T += V P^T: the 16 score registers of a lane are keys (r&3)+8(r>>2)+4h, so registers 8s..8s+7 ARE the 8 key
+//                 slots of k16-step s (the summation order over keys is free): P never moves between lanes;
+//                 V's LDS image [dt][k16-step][op][h][d] stores the keys of each element in that same order.
+typedef _Float16 ahalf8 __attribute__((ext_vector_type(8)));
+constexpr float kAttS = 256.f;
+__device__ __forceinline__ f32x16 att_mfma(ahalf8 a, ahalf8 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return c;
+#endif
+}
+
+struct AttRsrc {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ AttRsrc att_rsrc(const float* base, int bytes) {
+  AttRsrc b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+#endif
+  return b;
+}
+__device__ __forceinline__ float att_load(const AttRsrc& b, int off) {   // offset >= bytes reads 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 0));
+#else
+  return 0.f;
+#endif
+}
+constexpr int kAttOob = 0x7ffffff0;
+
+template <int DT>  // D <= 32*DT
+__global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, float* __restrict__ out,
+                                                      float* __restrict__ m_out, float* __restrict__ l_out,
+                                                      const float* __restrict__ relq, int H, int D, int T,
+                                                      int ld, long in_bs, long out_bs, float scale, int window,
+                                                      const int* lens, int nsplit, float* opart) {
+  constexpr int NS = 2 * DT;                       // k16-steps over the head dimension
+  __shared__ uint4 Ks[NS * 3 * 2 * 32];            // [s][op][h][key]
+  __shared__ uint4 Vs[DT * 2 * 3 * 2 * 32];        // [dt][s2][op][h][d]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int qblk = blockIdx.x / nsplit, split = blockIdx.x - qblk * nsplit;
+  const int q0 = qblk * 128 + wave * 32;
+  const int len = lens ? lens[b] : T;
+  const long base = (long)b * in_bs + (long)hd * D * ld;
+  const long obase = (long)b * out_bs + (long)hd * D * ld;
+  const float* qb = q + base;
+  const float* kb = k + base;
+  const float* vb = v + base;
+
+  // Q fragment: lane (query i, half h), step s, slot e -> Q[16 s + 8 h + e][q0 + i] * scale, split {qh, S ql}
+  ahalf8 qh[NS], ql[NS];
+  const int qi = q0 + i;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = 16 * s + 8 * h + e;
+      const float val = (d < D && qi < T) ? qb[(long)d * ld + qi] * scale : 0.f;
+      const _Float16 vh = (_Float16)val;
+      qh[s][e] = vh;
+      ql[s][e] = (_Float16)((val - (float)vh) * kAttS);
+    }
+
+  f32x16 acc_o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nrel = 2 * window + 1;
+  const float* relrow = relq ? relq + (((long)b * H + hd) * T + min(qi, T - 1)) * nrel : nullptr;
+
+  // staging: element e0 = tid + 256 j is 8 values (K: 8 head dims of one key; V: 8 permuted keys of one head dim).
+  // Loads are buffer loads (out-of-range offset -> 0: no branches) issued one key tile ahead into registers.
+  constexpr int K_ELEMS = NS * 2 * 32;             // (s, h, key)
+  constexpr int V_ELEMS = DT * 2 * 2 * 32;         // (dt, s2, h, d)
+  constexpr int NKE = (K_ELEMS + 255) / 256, NVE = (V_ELEMS + 255) / 256;
+  constexpr float invS = 1.f / kAttS;
+  const AttRsrc kr = att_rsrc(kb, D * ld * 4), vr = att_rsrc(vb, D * ld * 4);
+  float rk[NKE][8], rv[NVE][8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NKE; ++j) {
+      const int e0 = tid + 256 * j;
+      const int key = e0 & 31, hh = (e0 >> 5) & 1, s = e0 >> 6;
+      const bool ok = e0 < K_ELEMS && k0 + key < len;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rk[j][e] = att_load(kr, ok ? ((16 * s + 8 * hh + e) * ld + k0 + key) * 4 : kAttOob);
+    }
+#pragma unroll
+    for (int j = 0; j < NVE; ++j) {
+      const int e0 = tid + 256 * j;
+      const int dd = e0 & 31, hh = (e0 >> 5) & 1, s2 = (e0 >> 6) & 1, dt = e0 >> 7;
+      const int d = dt * 32 + dd;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * s2 + e;
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        rv[j][e] = att_load(vr, (e0 < V_ELEMS && key < len) ? (d * ld + key) * 4 : kAttOob);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NKE; ++j) {
+      const int e0 = tid + 256 * j;
+      if (NKE * 256 == K_ELEMS || e0 < K_ELEMS) {
+        const int key = e0 & 31, hh = (e0 >> 5) & 1, s = e0 >> 6;
+        ahalf8 a0, a1, a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float val = rk[j][e];
+          const _Float16 vh = (_Float16)val;
+          a0[e] = (_Float16)((float)vh * kAttS);
+          a1[e] = vh;
+          a2[e] = (_Float16)((val - (float)vh) * kAttS);
+        }
+        Ks[((s * 3 + 0) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a0);
+        Ks[((s * 3 + 1) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a1);
+        Ks[((s * 3 + 2) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a2);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVE; ++j) {
+      const int e0 = tid + 256 * j;
+      if (NVE * 256 == V_ELEMS || e0 < V_ELEMS) {
+        const int dd = e0 & 31, hh = (e0 >> 5) & 1, s2 = (e0 >> 6) & 1, dt = e0 >> 7;
+        ahalf8 a0, a1, a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float val = rv[j][e];
+          const _Float16 vh = (_Float16)val;
+          a0[e] = (_Float16)((float)vh * kAttS);
+          a1[e] = vh;
+          a2[e] = (_Float16)((val - (float)vh) * kAttS);
+        }
+        Vs[(((dt * 2 + s2) * 3 + 0) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a0);
+        Vs[(((dt * 2 + s2) * 3 + 1) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a1);
+        Vs[(((dt * 2 + s2) * 3 + 2) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a2);
+      }
+    }
+  };
+
+  const int tiles = (len + 31) / 32;
+  const int klo = (int)((long)tiles * split / nsplit) * 32;
+  const int khi = min(len, (int)((long)tiles * (split + 1) / nsplit) * 32);
+  if (klo < khi) fetch(klo);
+  for (int k0 = klo; k0 < khi; k0 += 32) {
+    __syncthreads();
+    commit();
+    if (k0 + 32 < khi) fetch(k0 + 32);
+    __syncthreads();
+    // ---- S^T tile (scaled by S): rows = keys, cols = queries
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (16 * s < D) {
+        const ahalf8 a0 = __builtin_bit_cast(ahalf8, Ks[((s * 3 + 0) * 2 + h) * 32 + i]);
+        const ahalf8 a1 = __builtin_bit_cast(ahalf8, Ks[((s * 3 + 1) * 2 + h) * 32 + i]);
+        const ahalf8 a2 = __builtin_bit_cast(ahalf8, Ks[((s * 3 + 2) * 2 + h) * 32 + i]);
+        sacc = att_mfma(a0, qh[s], sacc);
+        sacc = att_mfma(a1, ql[s], sacc);
+        sacc = att_mfma(a2, qh[s], sacc);
+      }
+    }
+    const bool band = relq && (k0 <= q0 + 31 + window) && (k0 + 31 >= q0 - window);
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float sv = sacc[r] * invS;
+      if (band) {
+        const int rel = key - qi + window;
+        if (rel >= 0 && rel < nrel && qi < T) sv += relrow[rel];
+      }
+      if (key >= len) sv = -INFINITY;
+      sacc[r] = sv;
+      mloc = fmaxf(mloc, sv);
+    }
+    const float mtile = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mtile);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    float lloc = 0.f;
+    ahalf8 ph[2], pl[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (sacc[r] == -INFINITY) ? 0.f : __expf(sacc[r] - m_new);
+      lloc += p;
+      const _Float16 vh = (_Float16)p;
+      ph[r >> 3][r & 7] = vh;
+      pl[r >> 3][r & 7] = (_Float16)((p - (float)vh) * kAttS);
+    }
+    l_run = l_run * alpha + lloc + __shfl_xor(lloc, 32);
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[dt][r] *= alpha;
+    // ---- O^T (scaled by S) += V P^T
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const ahalf8 a0 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 3 + 0) * 2 + h) * 32 + i]);
+        const ahalf8 a1 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 3 + 1) * 2 + h) * 32 + i]);
+        const ahalf8 a2 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 3 + 2) * 2 + h) * 32 + i]);
+        acc_o[dt] = att_mfma(a0, ph[s2], acc_o[dt]);
+        acc_o[dt] = att_mfma(a1, pl[s2], acc_o[dt]);
+        acc_o[dt] = att_mfma(a2, ph[s2], acc_o[dt]);
+      }
+  }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[dt][r] *= invS;
+  if (nsplit > 1) {
+    if (qi < T) {
+      const int DP = 32 * DT;
+      float* pb = opart + (((long)b * H + hd) * nsplit + split) * (DP + 2) * T;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          pb[(long)d * T + qi] = acc_o[dt][r];
+        }
+      if (h == 0) {
+        pb[(long)DP * T + qi] = m_run;
+        pb[(long)(DP + 1) * T + qi] = l_run;
+      }
+    }
+    return;
+  }
+  if (qi < T) {
+    const float inv = 1.f / l_run;
+    float* ob = out + obase;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (d < D) ob[(long)d * ld + qi] = (qi < len) ? acc_o[dt][r] * inv : 0.f;
+      }
+    if (m_out && h == 0) {
+      m_out[((long)b * H + hd) * T + qi] = m_run;
+      l_out[((long)b * H + hd) * T + qi] = l_run;
+    }
+  }
+}
+
+
 // merge the split-KV partials: out = sum_s e^(m_s - m) O_s / sum_s e^(m_s - m) l_s
 // grid.y = head * 4 + quarter of the head dimension: 4x the workgroups of a (query block, head) grid
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ opart, float* __restrict__ out,
@@ -323,7 +590,18 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
   float* mo = nsplit > 1 ? nullptr : mb;
   float* lo = nsplit > 1 ? nullptr : lb;
   dim3 grid(cdiv(T, 128) * nsplit, H, B);
-  if (DT == 1)
+  static int h3 = -1;   // RVCX_ATT_H3=0: exact-fp32 MFMA attention
+  if (h3 < 0) h3 = getenv("RVCX_ATT_H3") ? atoi(getenv("RVCX_ATT_H3")) : 1;
+  if (h3 && DT == 1)
+    hipLaunchKernelGGL(attn_h3_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens, nsplit, opart);
+  else if (h3 && DT == 2)
+    hipLaunchKernelGGL(attn_h3_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens, nsplit, opart);
+  else if (h3)
+    hipLaunchKernelGGL(attn_h3_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
+                       out_bs, scale, window, lens, nsplit, opart);
+  else if (DT == 1)
     hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
                        out_bs, scale, window, lens, nsplit, opart);
   else if (DT == 2)
