@@ -73,18 +73,22 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, int b, int g, int 
   }
 }
 
-// Lean epilogue for the common case: OUT_NORMAL, no pad-column zeroing, activation in {none, lrelu,
+// Lean epilogue for the common case: OUT_NORMAL (pad-column zeroing of row-padded maps included), activation in {none, lrelu,
 // relu} (all three are max(v, slope*v)), optional bias / residual / secondary accumulator.  Everything
 // that is uniform is decided once per tile, so an element costs ~8 instructions instead of ~50.
 __device__ __forceinline__ bool fast_epilogue_ok(const ConvArgs& a) {
-  return a.out_mode == OUT_NORMAL && a.zero_wp == 0 && a.act <= ACT_RELU;
+  return a.out_mode == OUT_NORMAL && a.act <= ACT_RELU;
 }
 
 __device__ __forceinline__ void store_tile_fast(const ConvArgs& a, int b, int co_base, int nn, const f32x16& t,
                                                 int len_out) {
   if (nn >= a.Nout) return;
   const float slope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : a.act_slope);
-  const bool live = nn < len_out;
+  bool live = nn < len_out;
+  if (a.zero_wp > 0) {   // a lane owns one output column: one modulo per tile, not per element
+    const int col = nn % a.zero_wp;
+    live = live && col != 0 && col != a.zero_wp - 1;
+  }
   float* yb = a.y ? a.y + (long)b * a.y_bs + nn : nullptr;
   const float* rb = a.res ? a.res + (long)b * a.res_bs + nn : nullptr;
   float* y2b = a.acc2_mode != ACC2_NONE ? a.y2 + (long)b * a.y2_bs + nn : nullptr;

@@ -308,6 +308,9 @@ const H3Cfg kH3[] = {
     // k = 1
     {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>},
     {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>},
+    // wide 3x3 tiles for the shallow U-Net levels (C = 16/32): the 2*Wp+2 halo is amortised over more outputs
+    {32, 256, 320, 1, false, 22.f, 1.10f, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false>},
+    {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
