@@ -146,4 +146,44 @@ __device__ __forceinline__ void store_tile_fast(const ConvArgs& a, int b, int co
   }
 }
 
+// Polyphase ConvTranspose1d shuffle store (OUT_SHUF1D) without a division per element: packed channel cg = c*s + ph,
+// so the 4 consecutive accumulator rows of a register group are 4 consecutive (c, ph) pairs -- one division per
+// group, then increments.  Residual loads of a group are issued before its stores.
+__device__ __forceinline__ void store_tile_shuf1d(const ConvArgs& a, int b, int co_base, int nn, const f32x16& t,
+                                                  int len_out) {
+  if (nn >= a.Nout) return;
+  const int s = a.sh_s;
+  float* yb = a.y + (long)b * a.y_bs;
+  const float* rb = a.res ? a.res + (long)b * a.res_bs : nullptr;
+  const int tbase = nn * s - a.sh_pad;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int cg0 = co_base + 8 * g;
+    int c = cg0 / s, ph = cg0 - c * s;
+    int cc[4], tt[4];
+    bool ok[4];
+    float bv[4], rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cc[q] = c;
+      tt[q] = tbase + ph;
+      ok[q] = cg0 + q < a.Cout_g && tt[q] >= 0 && tt[q] < a.sh_tout;
+      bv[q] = (a.bias && cg0 + q < a.Cout_g) ? a.bias[cg0 + q] : 0.f;
+      rv[q] = (rb && ok[q]) ? rb[(long)c * a.res_cs + tt[q]] : 0.f;
+      if (++ph == s) {
+        ph = 0;
+        ++c;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (ok[q]) {
+        float v = apply_act(t[4 * g + q] + bv[q], a.act, a.act_slope) + rv[q];
+        if (tt[q] >= len_out) v = 0.f;
+        yb[(long)cc[q] * a.y_cs + tt[q]] = v;
+      }
+    }
+  }
+}
+
 }  // namespace rvcx

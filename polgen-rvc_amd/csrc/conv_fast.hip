@@ -256,6 +256,13 @@ __global__ __launch_bounds__(256, 3) void conv_fast_kernel(const ConvArgs a) {
       store_tile_fast(a, b, co_w + 32, nn_w, acc[1][0], len_out);
       if constexpr (WN > 1) store_tile_fast(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
     }
+  } else if (a.out_mode == OUT_SHUF1D) {
+    store_tile_shuf1d(a, b, co_w, nn_w, acc[0][0], len_out);
+    if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w, nn_w + 32, acc[0][1], len_out);
+    if constexpr (WM > 1) {
+      store_tile_shuf1d(a, b, co_w + 32, nn_w, acc[1][0], len_out);
+      if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
+    }
   } else {
     store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
     if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
@@ -484,6 +491,13 @@ __global__ __launch_bounds__(256, 3) void conv_fast_sb_kernel(const ConvArgs a) 
       tp[5] = wall_clock64();
     }
 #endif
+  } else if (a.out_mode == OUT_SHUF1D) {
+    store_tile_shuf1d(a, b, co_w, nn_w, acc[0][0], len_out);
+    if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w, nn_w + 32, acc[0][1], len_out);
+    if constexpr (WM > 1) {
+      store_tile_shuf1d(a, b, co_w + 32, nn_w, acc[1][0], len_out);
+      if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
+    }
   } else {
     store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
     if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
