@@ -611,6 +611,7 @@ void conv_fast_init() {
     g_occ[t] = std::max(1, n);
   }
   if (const char* e = getenv("RVCX_STAGGER")) g_stagger_scale = (float)atof(e);
+  if (const char* e = getenv("RVCX_CONV_TILE")) g_conv_override.tile = atoi(e);   // tuning runs only
 }
 
 void conv_fast_describe(ConvProfile* p) {

@@ -143,3 +143,15 @@ def test_conv1d_h3_split_matches_fp64(ctx, case):
     got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), res=r.numpy(), dil=d, pad_left=pad, Tout=T, pre_lrelu=0.1)
     e = rms(got - ref) / rms(ref)
     assert np.isfinite(got).all() and e < 1e-6, e
+
+
+def test_conv1d_h3_falls_back_when_weights_overflow_fp16(ctx):
+    """A layer whose weights would overflow fp16 at the split scale (|w| * 256 >= 60000) keeps the exact-fp32 MFMA
+    kernel (ctx.hip: pack_h3 returns no image): results stay correct for weights of magnitude ~1e3."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 20000, generator=gen)
+    w = torch.randn(64, 64, 3, generator=gen) * 400.0
+    b = torch.randn(64, generator=gen)
+    ref = F.conv1d(x.double(), w.double(), b.double(), padding=1).numpy()
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), pad_left=1, Tout=20000)
+    assert np.isfinite(got).all() and rms(got - ref) / rms(ref) < 1e-6
