@@ -488,7 +488,21 @@ __global__ __launch_bounds__(256) void rel_logits_kernel(const float* __restrict
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  for (int d = 0; d < D; ++d) {
+  // the q loads are hoisted 8 at a time: one at a time they form a chain of D dependent-latency global loads
+  int d = 0;
+  for (; d + 8 <= D; d += 8) {
+    float qv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) qv[u] = qb[(long)(d + u) * ld + t] * scale;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = part + 4 * i;
+        if (r < nrel) acc[i] = fmaf(qv[u], eks[r * D + d + u], acc[i]);
+      }
+  }
+  for (; d < D; ++d) {
     const float qv = qb[(long)d * ld + t] * scale;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
