@@ -34,7 +34,12 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
 #pragma unroll
   for (int k = 0; k < LN_RPT; ++k) {
     const int c = part + k * LN_PARTS;
-    v[k] = (valid && c < C) ? xb[(long)c * T + t] : 0.f;
+    v[k] = xb[(long)min(c, C - 1) * T + min(t, T - 1)];   // always in range: 64 independent loads in flight
+  }
+#pragma unroll
+  for (int k = 0; k < LN_RPT; ++k) {
+    const int c = part + k * LN_PARTS;
+    v[k] = (valid && c < C) ? v[k] : 0.f;
     s += v[k];
   }
   red[part][tx] = s;
