@@ -543,9 +543,12 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const ConvArgs a) {
   float acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const int last = max(len_in - 1, 0);
+#pragma unroll 4
   for (int kk = 0; kk < K; ++kk) {
     const int pos = p0 + kk * a.dil;
-    float xv = (pos >= 0 && pos < len_in) ? xb[pos] : 0.f;
+    float xv = xb[min(max(pos, 0), last)];                 // always in range: no branch around the load
+    xv = (pos >= 0 && pos < len_in) ? xv : 0.f;
     if (a.pre_act == ACT_LRELU) xv = xv > 0.f ? xv : xv * a.pre_slope;
     const float4* w4 = reinterpret_cast<const float4*>(ws + kk * 16);
 #pragma unroll
