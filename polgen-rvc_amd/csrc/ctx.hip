@@ -1,5 +1,7 @@
 // Context lifecycle, checkpoint-tensor helpers, packed-layer constructors.
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <cstring>
 
 #include "ctx.h"
@@ -94,25 +96,42 @@ Ctx::~Ctx() {
 static std::vector<float> pack_h3(const std::vector<float>& wp, int k, int cin_gp, int cout_gp) {
   const float S = 256.f;
   const int nchunk = cin_gp / 16;
-  std::vector<_Float16> h((size_t)k * nchunk * 6 * cout_gp * 8);
-  for (int kk = 0; kk < k; ++kk)
-    for (int ch = 0; ch < nchunk; ++ch)
+  std::vector<float> out((size_t)k * nchunk * 6 * cout_gp * 4);          // 8 halves = 4 floats per element
+  _Float16* h = reinterpret_cast<_Float16*>(out.data());
+  const int slabs = k * nchunk;                                          // independent (tap, chunk) slabs
+  std::atomic<bool> overflow{false};
+  auto work = [&](int s0, int s1) {
+    for (int sl = s0; sl < s1 && !overflow.load(std::memory_order_relaxed); ++sl) {
+      const int kk = sl / nchunk, ch = sl % nchunk;
+      _Float16* hs = h + (size_t)sl * 6 * cout_gp * 8;
       for (int hh = 0; hh < 2; ++hh)
-        for (int co = 0; co < cout_gp; ++co)
-          for (int q = 0; q < 8; ++q) {
-            const int ci = ch * 16 + hh * 8 + q;
-            const float w = wp[((size_t)kk * cin_gp + ci) * cout_gp + co];
-            if (!(std::fabs(w) * S < 60000.f)) return {};
+        for (int q = 0; q < 8; ++q) {
+          const float* src = wp.data() + ((size_t)kk * cin_gp + ch * 16 + hh * 8 + q) * cout_gp;
+          for (int co = 0; co < cout_gp; ++co) {
+            const float w = src[co];
+            if (!(std::fabs(w) * S < 60000.f)) {
+              overflow.store(true, std::memory_order_relaxed);
+              return;
+            }
             const _Float16 wh = (_Float16)w;
-            const _Float16 wl = (_Float16)((w - (float)wh) * S);
-            const size_t base = ((size_t)kk * nchunk + ch) * 6;
-            auto at = [&](int op) -> _Float16& { return h[(((base + op * 2 + hh) * cout_gp) + co) * 8 + q]; };
-            at(0) = (_Float16)((float)wh * S);
-            at(1) = wh;
-            at(2) = wl;
+            hs[((size_t)(0 * 2 + hh) * cout_gp + co) * 8 + q] = (_Float16)((float)wh * S);
+            hs[((size_t)(1 * 2 + hh) * cout_gp + co) * 8 + q] = wh;
+            hs[((size_t)(2 * 2 + hh) * cout_gp + co) * 8 + q] = (_Float16)((w - (float)wh) * S);
           }
-  std::vector<float> out(h.size() / 2);
-  std::memcpy(out.data(), h.data(), h.size() * sizeof(_Float16));
+        }
+    }
+  };
+  const size_t total = (size_t)k * cin_gp * cout_gp;
+  const int nthreads = total > (1u << 20) ? std::min<int>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (nthreads <= 1) {
+    work(0, slabs);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back(work, (int)((long)slabs * t / nthreads), (int)((long)slabs * (t + 1) / nthreads));
+    for (auto& t : th) t.join();
+  }
+  if (overflow.load()) return {};
   return out;
 }
 
