@@ -6,13 +6,14 @@
 // Each fp16 x fp16 product is exact in fp32 and the sums accumulate in fp32 inside v_mfma_f32_32x32x16_f16, so the
 // result carries ~2^-21 relative error per product -- the size of fp32 rounding noise, not of fp16.  To keep the
 // low parts out of the fp16 subnormal range everything is computed at scale S = 256:
-//     S w x ~= (S wh) xh + wh (S xl) + (S wl) xh           operands A: {S wh, wh, S wl}   B: {xh, S xl}
+//     S w x ~= (S wh) xh + wh (S xl) + (S wl) xh           operands A: {S wh, wh = (S wh)/S, S wl}   B: {xh, S xl}
 // and the epilogue multiplies by 1/S (exact).  Weights are split once at load (ctx.hip: pack_h3); activations are
 // split while they are committed to LDS.  3 MFMAs of 32 cycles replace 8 of 64: 5.3x fewer matrix-pipe cycles,
 // which moves the NSF decoder's ResBlock convs from the MFMA roofline to the HBM one.
 //
 // LDS images (16-byte elements = 8 halves = the k-slice a lane feeds to one MFMA):
-//   As[kkl][op][h][co]   co contiguous: lane (i, h) reads element (h, co0 + i)      -> linear, conflict-free
+//   As[kkl][op {S wh, S wl}][h][co]   (wh itself is re-derived in registers: one LDS read and a third of the weight
+//                        image saved)   co contiguous: lane (i, h) reads element (h, co0 + i)      -> linear, conflict-free
 //   Bs[op][h][p]         p  contiguous: lane (j, h) reads element (h, n + j + tap)  -> taps are plain offsets
 #include <algorithm>
 #include <cmath>
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
   constexpr int WROW = LIN ? BN : BN * STRIDE + HALO;
   constexpr int NBTILE = LIN ? KKT : 1;               // input tiles resident per stage
-  constexpr int A_ELEMS = KKT * 3 * 2 * BM;           // 16-byte elements per stage
+  constexpr int A_ELEMS = KKT * 2 * 2 * BM;           // 16-byte elements per stage: ops {S wh, S wl}
   constexpr int NA = (A_ELEMS + 255) / 256;
   constexpr int B_TASKS = NBTILE * 2 * WROW;          // (tile, h, position): 8 channels each
   constexpr int NBT = (B_TASKS + 255) / 256;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
   const float pre_slope = a.pre_slope;
   const int nchunk = a.Cin_gp / 16;
   const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
-  const H3Rsrc wr_ = h3_rsrc(a.w_h3, a.ksize * nchunk * 6 * a.Cout_gp * 16);
+  const H3Rsrc wr_ = h3_rsrc(a.w_h3, a.ksize * nchunk * 4 * a.Cout_gp * 16);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int e = tid + 256 * j;
-    const int co = e % BM, rest = e / BM;              // rest = (kkl*3 + op)*2 + h
-    a_kkl[j] = rest / 6;
+    const int co = e % BM, rest = e / BM;              // rest = (kkl*2 + op)*2 + h
+    a_kkl[j] = rest / 4;
     const bool ok = e < A_ELEMS && co0 + co < a.Cout_gp;
-    a_off[j] = ok ? ((rest % 6) * a.Cout_gp + co0 + co) * 16 : kH3Oob;
+    a_off[j] = ok ? ((rest % 4) * a.Cout_gp + co0 + co) * 16 : kH3Oob;
   }
   int b_off[NBT], b_row[NBT];    // task t = tid + 256 j -> (tile, h, p): position byte offset, first channel row
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len_in) ? pos * 4 : kH3Oob;
   }
   const int xrow = a.x_cs * 4;
-  const int slab = 6 * a.Cout_gp * 16;                 // bytes of one (kk, chunk) weight slab
+  const int slab = 4 * a.Cout_gp * 16;                 // bytes of one (kk, chunk) weight slab
   // this split's chunk range, and the stage structure: LIN -> stages of KKT chunks; else (chunk, tap-group)
   const int cb0 = ks * nchunk / a.splitk, cb1 = (ks + 1) * nchunk / a.splitk;
   const int nkk = LIN ? 1 : (a.ksize + KKT - 1) / KKT;
@@ -215,12 +216,13 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
       if ((LIN ? (chunk + kkl < cb1) : (KKT == 1 || kk < a.ksize)) && !H3_DBG(a, 4)) {
         const int tp = LIN ? 0 : (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
         const uint4* Bt = Bs + (LIN ? kkl * 4 * WROW : 0);
-        half8 af[3][WM], bf[2][WN];
+        half8 af[3][WM], bf[2][WN];     // af[0] = S wh and af[2] = S wl from LDS; af[1] = wh = af[0] / S in registers
 #pragma unroll
-        for (int op = 0; op < 3; ++op)
-#pragma unroll
-          for (int m = 0; m < WM; ++m)
-            af[op][m] = __builtin_bit_cast(half8, As[((kkl * 3 + op) * 2 + h) * BM + wr * (WM * 32) + m * 32 + i]);
+        for (int m = 0; m < WM; ++m) {
+          af[0][m] = __builtin_bit_cast(half8, As[((kkl * 2 + 0) * 2 + h) * BM + wr * (WM * 32) + m * 32 + i]);
+          af[2][m] = __builtin_bit_cast(half8, As[((kkl * 2 + 1) * 2 + h) * BM + wr * (WM * 32) + m * 32 + i]);
+          af[1][m] = af[0][m] * (_Float16)(1.f / kH3Scale);   // exact: a power-of-two scaling (4 v_pk_mul_f16)
+        }
 #pragma unroll
         for (int op = 0; op < 2; ++op)
 #pragma unroll
@@ -340,7 +342,7 @@ void conv_h3_describe(ConvProfile* p) {
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   if (!a.w_h3 || !conv_h3_enabled()) return -1;
   if (a.groups != 1 || a.Cin_gp % 16 != 0 || (a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize))) return -1;
-  if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 6 >= kH3Oob) return -1;
+  if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kH3Oob) return -1;
   const bool lin = a.ksize == 1 && a.stride == 1;
   const int nchunk = a.Cin_gp / 16;
   // cost model in the shape of conv_fast's: the three fp16 MFMAs of a (tap, 16-channel) k-step cost 96 matrix-pipe

@@ -90,20 +90,20 @@ Ctx::~Ctx() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-// fp16 hi/lo split of the packed weights for conv_h3_kernel: H3[kk][chunk of 16 ci][op][h][co_pad][8 halves],
-// op 0 = S*wh, 1 = wh, 2 = S*wl  (S = 256; wh = fp16(w), wl = fp16((w - wh) * S) / S).  Returns an empty vector
+// fp16 hi/lo split of the packed weights for conv_h3_kernel: H3[kk][chunk of 16 ci][op (2)][h][co_pad][8 halves],
+// op 0 = S*wh, 1 = S*wl  (S = 256; wh = fp16(w), wl = fp16((w - wh) * S) / S; the kernel re-derives wh = op0 / S).  Returns an empty vector
 // when a weight would overflow fp16 at scale S (the layer then stays on the fp32 MFMA path).
 static std::vector<float> pack_h3(const std::vector<float>& wp, int k, int cin_gp, int cout_gp) {
   const float S = 256.f;
   const int nchunk = cin_gp / 16;
-  std::vector<float> out((size_t)k * nchunk * 6 * cout_gp * 4);          // 8 halves = 4 floats per element
+  std::vector<float> out((size_t)k * nchunk * 4 * cout_gp * 4);          // 8 halves = 4 floats per element
   _Float16* h = reinterpret_cast<_Float16*>(out.data());
   const int slabs = k * nchunk;                                          // independent (tap, chunk) slabs
   std::atomic<bool> overflow{false};
   auto work = [&](int s0, int s1) {
     for (int sl = s0; sl < s1 && !overflow.load(std::memory_order_relaxed); ++sl) {
       const int kk = sl / nchunk, ch = sl % nchunk;
-      _Float16* hs = h + (size_t)sl * 6 * cout_gp * 8;
+      _Float16* hs = h + (size_t)sl * 4 * cout_gp * 8;
       for (int hh = 0; hh < 2; ++hh)
         for (int q = 0; q < 8; ++q) {
           const float* src = wp.data() + ((size_t)kk * cin_gp + ch * 16 + hh * 8 + q) * cout_gp;
@@ -115,8 +115,7 @@ static std::vector<float> pack_h3(const std::vector<float>& wp, int k, int cin_g
             }
             const _Float16 wh = (_Float16)w;
             hs[((size_t)(0 * 2 + hh) * cout_gp + co) * 8 + q] = (_Float16)((float)wh * S);
-            hs[((size_t)(1 * 2 + hh) * cout_gp + co) * 8 + q] = wh;
-            hs[((size_t)(2 * 2 + hh) * cout_gp + co) * 8 + q] = (_Float16)((w - (float)wh) * S);
+            hs[((size_t)(1 * 2 + hh) * cout_gp + co) * 8 + q] = (_Float16)((w - (float)wh) * S);
           }
         }
     }
