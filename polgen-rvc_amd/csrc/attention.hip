@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
                                                       int ld, long in_bs, long out_bs, float scale, int window,
                                                       const int* lens, int nsplit, float* opart) {
   constexpr int NS = 2 * DT;                       // k16-steps over the head dimension
-  __shared__ uint4 Ks[NS * 3 * 2 * 32];            // [s][op][h][key]
-  __shared__ uint4 Vs[DT * 2 * 3 * 2 * 32];        // [dt][s2][op][h][d]
+  __shared__ uint4 Ks[NS * 2 * 2 * 32];            // [s][op {S kh, S kl}][h][key]   (kh = (S kh)/S in registers)
+  __shared__ uint4 Vs[DT * 2 * 2 * 2 * 32];        // [dt][s2][op {S vh, S vl}][h][d]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -297,9 +297,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
           a1[e] = vh;
           a2[e] = (_Float16)((val - (float)vh) * kAttS);
         }
-        Ks[((s * 3 + 0) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a0);
-        Ks[((s * 3 + 1) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a1);
-        Ks[((s * 3 + 2) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a2);
+        Ks[((s * 2 + 0) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a0);
+        Ks[((s * 2 + 1) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a2);
       }
     }
 #pragma unroll
@@ -316,9 +315,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
           a1[e] = vh;
           a2[e] = (_Float16)((val - (float)vh) * kAttS);
         }
-        Vs[(((dt * 2 + s2) * 3 + 0) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a0);
-        Vs[(((dt * 2 + s2) * 3 + 1) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a1);
-        Vs[(((dt * 2 + s2) * 3 + 2) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a2);
+        Vs[(((dt * 2 + s2) * 2 + 0) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a0);
+        Vs[(((dt * 2 + s2) * 2 + 1) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a2);
       }
     }
   };
@@ -339,9 +337,9 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (16 * s < D) {
-        const ahalf8 a0 = __builtin_bit_cast(ahalf8, Ks[((s * 3 + 0) * 2 + h) * 32 + i]);
-        const ahalf8 a1 = __builtin_bit_cast(ahalf8, Ks[((s * 3 + 1) * 2 + h) * 32 + i]);
-        const ahalf8 a2 = __builtin_bit_cast(ahalf8, Ks[((s * 3 + 2) * 2 + h) * 32 + i]);
+        const ahalf8 a0 = __builtin_bit_cast(ahalf8, Ks[((s * 2 + 0) * 2 + h) * 32 + i]);
+        const ahalf8 a2 = __builtin_bit_cast(ahalf8, Ks[((s * 2 + 1) * 2 + h) * 32 + i]);
+        const ahalf8 a1 = a0 * (_Float16)invS;
         sacc = att_mfma(a0, qh[s], sacc);
         sacc = att_mfma(a1, ql[s], sacc);
         sacc = att_mfma(a2, qh[s], sacc);
@@ -385,9 +383,9 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const ahalf8 a0 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 3 + 0) * 2 + h) * 32 + i]);
-        const ahalf8 a1 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 3 + 1) * 2 + h) * 32 + i]);
-        const ahalf8 a2 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 3 + 2) * 2 + h) * 32 + i]);
+        const ahalf8 a0 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 2 + 0) * 2 + h) * 32 + i]);
+        const ahalf8 a2 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 2 + 1) * 2 + h) * 32 + i]);
+        const ahalf8 a1 = a0 * (_Float16)invS;
         acc_o[dt] = att_mfma(a0, ph[s2], acc_o[dt]);
         acc_o[dt] = att_mfma(a1, pl[s2], acc_o[dt]);
         acc_o[dt] = att_mfma(a2, ph[s2], acc_o[dt]);
