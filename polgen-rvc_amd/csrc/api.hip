@@ -71,10 +71,10 @@ int rvcx_create(int device, rvcx_ctx** out) {
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_hub, hipEventDisableTiming));
     {
-      // HuBERT gets its own stream, restricted to 248 of the 256 CUs: RMVPE's many small kernels (and the 8
+      // HuBERT gets its own stream, restricted to 232 of the 256 CUs: RMVPE's many small kernels (and the 8
       // workgroups of its GRU) always find free CUs instead of queueing behind HuBERT's wide launches, and the
       // two branches finish together (12.4 ms each instead of 14.0 / 9.0).  RVCX_HUBERT_CUS=0: main stream.
-      const int n = getenv("RVCX_HUBERT_CUS") ? atoi(getenv("RVCX_HUBERT_CUS")) : 248;
+      const int n = getenv("RVCX_HUBERT_CUS") ? atoi(getenv("RVCX_HUBERT_CUS")) : 232;
       if (n > 0 && n < 256) {
         uint32_t mask[8] = {0};
         for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
