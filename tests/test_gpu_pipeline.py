@@ -162,3 +162,29 @@ def test_full_size_pipeline_vs_reference_golden(ctx, tag):
     assert diff.max() <= 8 and np.mean(diff > 1) < 0.02
     assert np.mean(vc.get_f0("x", audio, len(d["f0"]), 0.0, "rmvpe+", 3, 128, None, 50, 1100, ctx=ctx)[0]
                    != d["coarse"]) < 1e-3
+
+
+@pytest.mark.parametrize("seconds,clip", [(1.37, 71), (2.003, 72), (3.71, 73)])
+def test_odd_lengths_vs_oracle(ctx, seconds, clip):
+    """Odd clip lengths (frame counts that are not multiples of any tile size, single- and multi-chunk) against the
+    CPU oracle: float waveform within 1e-4 RMS (budget 1e-3), PCM within 8 LSB."""
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import synthetic as S
+    from polgen_rvc_amd.infer import infer as I
+    cfgs = (S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY)
+    hub, cpt = _setup(ctx, cfgs, 4)
+    cfg = I.Config()
+    cfg.x_pad, cfg.x_query, cfg.x_center, cfg.x_max = 1, 1, 2, 3
+    cpt, version, net_g, tgt_sr, vc = I.get_vc("cuda:0", False, cfg, None, cpt=cpt)
+    audio = S.make_clip(clip, seconds)
+    models = OP.Models(S.to_torch(S.hubert_state(cfgs[0], 4)), cfgs[0], S.to_torch(S.rmvpe_state(cfgs[1], 4)),
+                       cfgs[1], S.to_torch(cpt["weight"]), cfgs[2])
+    opcm, parts = OP.pipeline(models, OP.Geometry(tgt_sr, 1, 1, 2, 3), audio, 0.0, 0, None, 0.0, 1.0, 0.33, 50,
+                              1100, seed=3, return_parts=True)
+    noise = np.concatenate([np.concatenate([z.numpy().ravel(), s.numpy().ravel()]) for z, s in parts["noises"]])
+    pcm, f32 = vc.pipeline(hub, net_g, 0, audio, "x.wav", 0.0, "rmvpe+", None, 0, 1, 3, tgt_sr, 0, 1.0, "v2", 0.33,
+                           128, None, 50, 1100, noise=noise, return_f32=True)
+    assert pcm.shape == opcm.shape
+    e = rms(f32 - parts["audio_f32"])
+    assert e < 1e-4, e
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 8
