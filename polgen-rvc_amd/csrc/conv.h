@@ -24,6 +24,10 @@ struct ConvArgs {
   const float* x = nullptr;
   const float* w = nullptr;      // packed Wp[g][kk][Cin_gp][Cout_gp]
   const void* w_h3 = nullptr;    // optional fp16 hi/lo split image of w (conv_h3.hip); null -> fp32 MFMA only
+  // conv_h3 only: activations exchanged already split, XS[c/16][op {hi, S*lo}][(c%16)/8][t][8 halves] (same bytes as
+  // fp32, 16-byte elements = exactly the kernel's LDS input-tile elements).  x_split replaces x, y_split replaces y.
+  const void* x_split = nullptr;
+  void* y_split = nullptr;
   const float* bias = nullptr;   // [groups*Cout_g] or null
   const float* res = nullptr;    // residual added after the activation (same indexing as y)
   float* y = nullptr;            // may be null when only y2 is wanted
@@ -80,6 +84,7 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-ti
 void conv_fast_describe(ConvProfile* p);
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream);   // fp16x3 split kernels; slot or -1
 bool conv_h3_enabled();
+bool conv_h3_split_ok(const ConvArgs& a);   // may this launch read / write pre-split activations?
 void launch_splitk_finish(const ConvArgs& a, hipStream_t stream);   // deterministic reduction of the split-K slabs + epilogue
 void conv_h3_describe(ConvProfile* p);
 struct ConvOverride { int tile = -1, variant = -1, splitk = -1; };

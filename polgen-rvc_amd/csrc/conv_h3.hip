@@ -68,9 +68,42 @@ __device__ __forceinline__ f32x16 h3_mfma(half8 a, half8 b, f32x16 c) {
 }
 constexpr int kH3Oob = 0x7ffffff0;
 
+// c1 -> c2 hand-off of a ResBlock: the activated outputs are stored already split (see ConvArgs::y_split).  A lane owns
+// rows (r&3) + 8(r>>2) + 4 hl of a 32x32 tile: register group g = r>>2 is the 4 channels q = 4 hl .. 4 hl + 3 of
+// element (chunk = (c0 + 8 g)/16, h = g & 1) -- one 8-byte store for the hi halves and one for the scaled lo halves.
+__device__ __forceinline__ void store_tile_split(const ConvArgs& a, int b, int c0, int nn, int hl, const f32x16& t,
+                                                 int len_out) {
+  if (nn >= a.Nout) return;
+  const bool live = nn < len_out;
+  char* base = static_cast<char*>(a.y_split) + (long)b * a.y_bs * 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int cg = c0 + 8 * g;                       // first channel of the 8-channel element this group belongs to
+    if (cg + 4 * hl < a.Cout_g) {
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      half4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = t[4 * g + q] + (a.bias ? a.bias[cg + 4 * hl + q] : 0.f);
+        v = apply_act(v, a.act, a.act_slope);
+        v = live ? v : 0.f;
+        const _Float16 vh = (_Float16)v;
+        hi[q] = vh;
+        lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+      }
+      const long e_hi = ((long)((cg >> 4) * 2 + 0) * 2 + (g & 1)) * a.y_cs + nn;
+      const long e_lo = ((long)((cg >> 4) * 2 + 1) * 2 + (g & 1)) * a.y_cs + nn;
+      *reinterpret_cast<half4*>(base + e_hi * 16 + 8 * hl) = hi;
+      *reinterpret_cast<half4*>(base + e_lo * 16 + 8 * hl) = lo;
+    }
+  }
+}
+
 // HALO: input-tile halo (64: 1-D k <= 11 d <= 5; 320: 3x3 on row-padded maps).  STRIDE 2: HuBERT extractor.
 // LIN: k = 1 layers -- a stage is KKT 16-channel chunks (each with its own input tile) instead of KKT taps.
-template <int BM, int BN, int WR, int WC, int KKT, int HALO, int STRIDE, bool LIN>
+// XS: the input arrives pre-split (ConvArgs::x_split) -- a separate instantiation so that the fp32-input staging
+// code keeps its straight-line, batched loads.
+template <int BM, int BN, int WR, int WC, int KKT, int HALO, int STRIDE, bool LIN, bool XS = false>
 __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
   constexpr int WROW = LIN ? BN : BN * STRIDE + HALO;
@@ -95,7 +128,10 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
   const int pre_act = a.pre_act;
   const float pre_slope = a.pre_slope;
   const int nchunk = a.Cin_gp / 16;
-  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
+  constexpr bool xsplit = XS;
+  static_assert(!XS || (!LIN && STRIDE == 1), "pre-split input: dense stride-1 tiles only");
+  const H3Rsrc xr = xsplit ? h3_rsrc(static_cast<const char*>(a.x_split) + (long)b * a.x_bs * 4, a.Cin_g * a.x_cs * 4)
+                           : h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
   const H3Rsrc wr_ = h3_rsrc(a.w_h3, a.ksize * nchunk * 4 * a.Cout_gp * 16);
 
   f32x16 acc[WM][WN];
@@ -125,6 +161,9 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     b_row[j] = (th >> 1) * 16 + (th & 1) * 8;
     b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len_in) ? pos * 4 : kH3Oob;
   }
+  // pre-split input: task t = tid + 256 j -> (op*2 + h, p): one 16-byte element per task, no conversion at commit
+  constexpr int NBS = LIN ? 1 : (4 * WROW + 255) / 256;
+  static_assert(LIN || NBS * 4 <= NBT * 8, "split-input staging must fit the register set of the fp32 path");
   const int xrow = a.x_cs * 4;
   const int slab = 4 * a.Cout_gp * 16;                 // bytes of one (kk, chunk) weight slab
   // this split's chunk range, and the stage structure: LIN -> stages of KKT chunks; else (chunk, tap-group)
@@ -135,6 +174,21 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
   uint4 ra[NA];
   float rb[NBT][8];
   auto fetch_b = [&](int chunk) {                      // LIN: chunks chunk .. chunk+KKT-1 (clipped to cb1)
+    if constexpr (xsplit) {
+      const int cbyte = chunk * 4 * a.x_cs * 16;
+#pragma unroll
+      for (int j = 0; j < NBS; ++j) {
+        const int t = tid + 256 * j;                     // offsets recomputed per chunk: cheaper than 5 live registers
+        const int oph = t / WROW, p = t - oph * WROW;
+        const int pos = in_base + p;
+        const bool ok = t < 4 * WROW && p < wuse && pos >= 0 && pos < len_in;
+        const uint4 v = h3_load4(xr, ok ? cbyte + (oph * a.x_cs + pos) * 16 : kH3Oob);
+        rb[(4 * j + 0) / 8][(4 * j + 0) % 8] = __builtin_bit_cast(float, v.x);   // compile-time indices: registers
+        rb[(4 * j + 1) / 8][(4 * j + 1) % 8] = __builtin_bit_cast(float, v.y);
+        rb[(4 * j + 2) / 8][(4 * j + 2) % 8] = __builtin_bit_cast(float, v.z);
+        rb[(4 * j + 3) / 8][(4 * j + 3) % 8] = __builtin_bit_cast(float, v.w);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < NBT; ++j) {
       const int crow = chunk * 16 + b_row[j];
@@ -143,6 +197,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         rb[j][q] = h3_load1(xr, (b_off[j] == kH3Oob || !cok) ? kH3Oob : row0 + q * xrow + b_off[j]);
+    }
     }
   };
   auto fetch_a = [&](int chunk, int kk0) {
@@ -155,7 +210,22 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     }
   };
   auto commit = [&](int kk0) {
-    if (LIN || kk0 == 0) {
+    if constexpr (xsplit) {
+      if (kk0 == 0) {
+#pragma unroll
+        for (int j = 0; j < NBS; ++j) {
+          const int t = tid + 256 * j;
+          if (NBS * 256 == 4 * WROW || t < 4 * WROW) {
+            uint4 v;
+            v.x = __builtin_bit_cast(unsigned, rb[(4 * j + 0) / 8][(4 * j + 0) % 8]);
+            v.y = __builtin_bit_cast(unsigned, rb[(4 * j + 1) / 8][(4 * j + 1) % 8]);
+            v.z = __builtin_bit_cast(unsigned, rb[(4 * j + 2) / 8][(4 * j + 2) % 8]);
+            v.w = __builtin_bit_cast(unsigned, rb[(4 * j + 3) / 8][(4 * j + 3) % 8]);
+            Bs[t] = v;                                   // Bs index (op*2 + h) * WROW + p == t
+          }
+        }
+      }
+    } else if (LIN || kk0 == 0) {
 #pragma unroll
       for (int j = 0; j < NBT; ++j) {
         const int t = tid + 256 * j;
@@ -271,7 +341,13 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
       }
     return;
   }
-  if (fast_epilogue_ok(a)) {
+  if (a.y_split) {
+    const int c_t = co0 + wr * (WM * 32);
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) store_tile_split(a, b, c_t + m * 32, nn_w + n * 32, h, acc[m][n], len_out);
+  } else if (fast_epilogue_ok(a)) {
     store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
     if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
     if constexpr (WM > 1) {
@@ -302,24 +378,25 @@ struct H3Cfg {
   float ovh;                  // per-block prologue + epilogue in 16-channel k-steps of MFMA time (cost model)
   float eff;                  // relative main-loop efficiency (wave tile 32x64 reuses fragments, 32x32 does not)
   void (*kern)(const ConvArgs);
+  void (*kern_xs)(const ConvArgs);   // same tile reading a pre-split input (null: none)
 };
 const H3Cfg kH3[] = {
     // 1-D, halo <= 64
-    {32, 256, 64, 1, false, 18.f, 1.00f, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false>},
-    {64, 128, 64, 1, false, 16.f, 0.97f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false>},
-    {64, 64, 64, 1, false, 16.f, 0.75f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false>},
+    {32, 256, 64, 1, false, 18.f, 1.00f, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false>, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false, true>},
+    {64, 128, 64, 1, false, 16.f, 0.97f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false, true>},
+    {64, 64, 64, 1, false, 16.f, 0.75f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false>, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false, true>},
     // 3x3 on row-padded maps
-    {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>},
-    {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>},
+    {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>, nullptr},
+    {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>, nullptr},
     // stride 2
-    {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>},
-    {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>},
+    {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>, nullptr},
+    {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>, nullptr},
     // k = 1
-    {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>},
-    {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>},
+    {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>, nullptr},
+    {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>, nullptr},
     // wide 3x3 tiles for the shallow U-Net levels (C = 16/32): the 2*Wp+2 halo is amortised over more outputs
-    {32, 256, 320, 1, false, 22.f, 1.10f, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false>},
-    {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>},
+    {32, 256, 320, 1, false, 22.f, 1.10f, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false>, nullptr},
+    {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>, nullptr},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
@@ -338,8 +415,19 @@ void conv_h3_describe(ConvProfile* p) {
   }
 }
 
+bool conv_h3_split_ok(const ConvArgs& a) {
+  if (!a.w_h3 || !conv_h3_enabled()) return false;
+  if (a.groups != 1 || a.stride != 1 || a.kw != a.ksize || a.ksize == 1 || a.out_mode != OUT_NORMAL) return false;
+  if (a.Cin_g % 16 != 0 || a.Cout_g % 16 != 0 || a.Cin_g != a.Cin_gp) return false;
+  if ((long)(a.ksize - 1) * a.dil > 64) return false;
+  if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.Cout_g * a.y_cs * 4 >= kH3Oob) return false;
+  return true;
+}
+
 // returns a profile slot (>= 0) when the launch was taken, -1 otherwise
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
+  const bool split = a.x_split || a.y_split;
+  RVCX_CHECK(!split || conv_h3_split_ok(a), "conv_h3: pre-split activations on a launch that cannot take them");
   if (!a.w_h3 || !conv_h3_enabled()) return -1;
   if (a.groups != 1 || a.Cin_gp % 16 != 0 || (a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize))) return -1;
   if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kH3Oob) return -1;
@@ -354,10 +442,11 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
     const H3Cfg& F = kH3[t];
     if (g_conv_override.tile >= 100 && g_conv_override.tile - 100 != t) continue;
     if (F.lin != lin || F.stride != a.stride) continue;
+    if (a.x_split && !F.kern_xs) continue;
     if (!lin && (halo > F.halo || (F.halo == 320 && halo <= 64))) continue;
     const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * a.B;
     const double ksteps = (double)a.ksize * nchunk;
-    for (int s = 1; s <= 8; s *= 2) {
+    for (int s = 1; s <= (split ? 1 : 8); s *= 2) {
       if (s > 1 && (!a.part || nchunk / s < 1 || ksteps / s < 8.0 || (long)s * a.B * a.Cout_g * a.Nout > a.part_cap)) break;
       if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
       const double c = (double)blocks * s / 256.0;
@@ -382,7 +471,7 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
     a.dbg = dbg;
   }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
-  hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(a.x_split ? F.kern_xs : F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());
   return 39 + best;   // profile slots 39.. (conv_h3_describe)

@@ -392,8 +392,17 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
         a.act_slope = 0.1f;
         a.lens_in = lout;
         a.lens_out = lout;
+        // c1 -> c2 hand-off: when both run on the split-fp16 kernels, xt travels already split (hi / scaled lo
+        // halves in the consumer's LDS element order): c2 stages it with 16-byte loads and no conversion
+        ConvArgs a2 = conv1d_args(S.c2[j][mi], xt, xc, B, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
+        const bool split = conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
+        if (split) {
+          a.y_split = xt;
+          a.y = nullptr;
+        }
         c.conv_on(a, sj);
-        a = conv1d_args(S.c2[j][mi], xt, xc, B, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
+        a = a2;
+        if (split) a.x_split = xt;
         conv_set_res(a, xin, S.ch, (int)Tout);
         a.lens_in = lout;
         a.lens_out = lout;
