@@ -80,7 +80,9 @@ def pmc_traffic(tile_name):
     mh = re.match(r"conv_h3<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
     if mh:
         want = f"conv_h3_kernel<{mh.group(1)}, {mh.group(2)},"
-        tail = {"linear": ", 0, 1, true>", "stride2": ", 64, 2, false>"}.get(mh.group(3), f", {mh.group(4)}, 1, false>")
+        # template args: <BM, BN, WR, WC, KKT, HALO, STRIDE, LIN, XS>; XS = false is the fp32-input instantiation
+        tail = {"linear": ", 0, 1, true, false>", "stride2": ", 64, 2, false, false>"}.get(
+            mh.group(3), f", {mh.group(4)}, 1, false, false>")
         for k, v in kernels.items():
             if want in k and tail in k:
                 return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
