@@ -120,3 +120,28 @@ def test_synth_philox_noise_runs(ctx):
     b = ctx.synth_infer(mid, phone, pitch, f0, seed=5)
     c2 = ctx.synth_infer(mid, phone, pitch, f0, seed=6)
     assert np.isfinite(a).all() and (a == b).all() and not (a == c2).all()
+
+
+def test_synth_48k_ragged_batch_equals_single(ctx):
+    """Full-size 48 k synthesizer (its ResBlock convs run on the split-fp16 kernels, c1 -> c2 hand-off in split
+    form): a ragged batch (B = 2, 40 and 23 frames) must reproduce each item run alone to fp32 rounding."""
+    from polgen_rvc_amd import synthetic as S
+    cfg = S.SYNTH_CFG_48K
+    mid, _ = _load_model(ctx, cfg, 7)
+    g = torch.Generator().manual_seed(2)
+    T, lens = 40, [40, 23]
+    upp = 480
+    phone = torch.randn(2, T, 768, generator=g)
+    pitch = torch.randint(1, 256, (2, T), generator=g)
+    f0 = 100 + 300 * torch.rand(2, T, generator=g)
+    zn = torch.randn(2, 192, T, generator=g)
+    sn = torch.randn(2, T * upp, generator=g)
+    both = ctx.synth_infer(mid, phone.numpy(), pitch.numpy(), f0.numpy(), lens=lens, z_noise=zn.numpy(),
+                           src_noise=sn.numpy())
+    for i, L in enumerate(lens):
+        one = ctx.synth_infer(mid, phone[i:i + 1, :L].numpy(), pitch[i:i + 1, :L].numpy(), f0[i:i + 1, :L].numpy(),
+                              z_noise=zn[i:i + 1, :, :L].numpy().copy(), src_noise=sn[i:i + 1, :L * upp].numpy().copy())
+        e = rms(both[i, :L * upp] - one[0, :L * upp]) / rms(one[0, :L * upp])
+        assert np.isfinite(both[i]).all() and e < 1e-5, (i, e)
+        if L < T:
+            assert np.abs(both[i, L * upp:]).max() == 0.0      # beyond the item's length: exact zeros
