@@ -74,7 +74,11 @@ constexpr int kH3Oob = 0x7ffffff0;
 __device__ __forceinline__ void store_tile_split(const ConvArgs& a, int b, int c0, int nn, int hl, const f32x16& t,
                                                  int len_out) {
   if (nn >= a.Nout) return;
-  const bool live = nn < len_out;
+  bool live = nn < len_out;
+  if (a.zero_wp > 0) {                               // pad columns of a row-padded 2-D map stay zero
+    const int col = nn % a.zero_wp;
+    live = live && col != 0 && col != a.zero_wp - 1;
+  }
   char* base = static_cast<char*>(a.y_split) + (long)b * a.y_bs * 4;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -386,8 +390,8 @@ const H3Cfg kH3[] = {
     {64, 128, 64, 1, false, 16.f, 0.97f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false, true>},
     {64, 64, 64, 1, false, 16.f, 0.75f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false>, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false, true>},
     // 3x3 on row-padded maps
-    {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>, nullptr},
-    {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>, nullptr},
+    {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false, true>},
+    {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false, true>},
     // stride 2
     {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>, nullptr},
     {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>, nullptr},
@@ -395,8 +399,8 @@ const H3Cfg kH3[] = {
     {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>, nullptr},
     {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>, nullptr},
     // wide 3x3 tiles for the shallow U-Net levels (C = 16/32): the 2*Wp+2 halo is amortised over more outputs
-    {32, 256, 320, 1, false, 22.f, 1.10f, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false>, nullptr},
-    {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>, nullptr},
+    {32, 256, 320, 1, false, 22.f, 1.10f, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false, true>},
+    {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false, true>},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
@@ -417,9 +421,16 @@ void conv_h3_describe(ConvProfile* p) {
 
 bool conv_h3_split_ok(const ConvArgs& a) {
   if (!a.w_h3 || !conv_h3_enabled()) return false;
-  if (a.groups != 1 || a.stride != 1 || a.kw != a.ksize || a.ksize == 1 || a.out_mode != OUT_NORMAL) return false;
+  if (a.groups != 1 || a.stride != 1 || a.ksize == 1 || a.out_mode != OUT_NORMAL) return false;
   if (a.Cin_g % 16 != 0 || a.Cout_g % 16 != 0 || a.Cin_g != a.Cin_gp) return false;
-  if ((long)(a.ksize - 1) * a.dil > 64) return false;
+  {
+    int lo = 1 << 30, hi = -(1 << 30);
+    for (int kk = 0; kk < a.ksize; ++kk) {
+      lo = std::min(lo, conv_tap_off(a, kk));
+      hi = std::max(hi, conv_tap_off(a, kk));
+    }
+    if (hi - lo > 320) return false;
+  }
   if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.Cout_g * a.y_cs * 4 >= kH3Oob) return false;
   return true;
 }

@@ -209,6 +209,14 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
   ConvArgs a = conv2d_args(b.c1, x.p, tmp1, B, H, Wp);
   a.x_bs = x.bs;
   a.act = ACT_RELU;
+  // conv1 -> conv2 hand-off in split fp16 form on the large (shallow) levels; the deep levels keep fp32 because
+  // their launches rely on split-K, which the split store does not go through
+  ConvArgs a2 = conv2d_args(b.c2, tmp1, y.p, B, H, Wp);
+  const bool split = (long)H * Wp >= 20000 && conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
+  if (split) {
+    a.y_split = tmp1;
+    a.y = nullptr;
+  }
   c.conv_on(a, s);
   const float* res = x.p;
   long res_bs = x.bs;
@@ -219,7 +227,8 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
     res = tmp2;
     res_bs = (long)b.cout * H * Wp;
   }
-  a = conv2d_args(b.c2, tmp1, y.p, B, H, Wp);
+  a = a2;
+  if (split) a.x_split = tmp1;
   a.act = ACT_RELU;
   a.res = res;
   a.res_bs = res_bs;
