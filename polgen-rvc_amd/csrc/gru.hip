@@ -62,7 +62,12 @@ constexpr int GRU_H = 256;
 constexpr int GRU_NC = 4;                 // workgroups per (direction, item)
 constexpr int GRU_U = GRU_H / GRU_NC;     // hidden units owned by a workgroup (64)
 constexpr int GRU_ROWS = 3 * GRU_U;       // gate rows owned (192)
-constexpr int GRU_THREADS = 2 * GRU_ROWS; // thread = (row, column half): 128 weights in registers
+constexpr int GRU_THREADS = 2 * GRU_ROWS; // 384 threads, 128 weights each in registers
+constexpr int GRU_RPT = 4;                // a thread owns 4 gate rows x 32 columns: 8 broadcast LDS reads of h per step
+constexpr int GRU_CPT = 32;               // (1 row x 128 columns needed 32 and made the LDS the longest part of a step)
+constexpr int GRU_NCS = GRU_H / GRU_CPT;  // column slices (8)
+constexpr int GRU_NRG = GRU_ROWS / GRU_RPT;   // row groups (48)
+static_assert(GRU_NRG * GRU_NCS == GRU_THREADS, "thread mapping");
 constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;   // ~seconds: a lost partner ends the kernel instead of hanging the GPU
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
                                                                     int* err, int T, int nq, int colocate) {
   constexpr int H = GRU_H;
   __shared__ __attribute__((aligned(16))) float hs[H];
-  __shared__ float part[2][GRU_ROWS];
+  __shared__ float part[GRU_NCS][GRU_ROWS];
   __shared__ int sfail;
   // workgroup -> (cluster q = dir + 2 b, member c).  Workgroups are dealt round-robin to the 8 XCDs, so with
   // `colocate` the NC members of a cluster are the ids congruent mod 8: they share one XCD and its L2.
@@ -105,14 +110,18 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
   __builtin_amdgcn_s_setprio(3);   // latency-bound serial chain: issue ahead of co-resident conv waves
   const int dir = q & 1, b = q >> 1;
   const int tid = threadIdx.x;
-  const int row = tid % GRU_ROWS, half = tid / GRU_ROWS;
-  const int gate = row / GRU_U, ul = row % GRU_U;
-  const int grow = gate * H + c * GRU_U + ul;          // row of W_hh (3H x H)
+  const int rg = tid % GRU_NRG, cs = tid / GRU_NRG;
   const float* W = whh_t + (long)dir * H * 3 * H;
-  // this thread's 128 weights: W_hh[grow][half*128 .. +128)  (whh_t is (H, 3H): column-major rows)
-  float w[H / 2];
+  // this thread's 4 x 32 weights: W_hh[grow(rg*4+q)][cs*32 .. +32)  (whh_t is (H, 3H): column-major rows)
+  float w[GRU_RPT][GRU_CPT];
 #pragma unroll
-  for (int k = 0; k < H / 2; ++k) w[k] = W[(long)(half * (H / 2) + k) * 3 * H + grow];
+  for (int q = 0; q < GRU_RPT; ++q) {
+    const int row = rg * GRU_RPT + q;
+    const int gate = row / GRU_U, ul = row % GRU_U;
+    const int grow = gate * H + c * GRU_U + ul;          // row of W_hh (3H x H)
+#pragma unroll
+    for (int k = 0; k < GRU_CPT; ++k) w[q][k] = W[(long)(cs * GRU_CPT + k) * 3 * H + grow];
+  }
   const float* gib = gi + (long)b * T * 6 * H + dir * 3 * H;
   float* yb = y + ((long)b * 2 + dir) * H * T;
   unsigned long long* xb = xbuf + ((long)b * 2 + dir) * 2 * H;
@@ -143,24 +152,33 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
       gz_n = g[H + ju];
       gn_n = g[2 * H + ju];
     }
-    // ---- partial dot product over this thread's 128 columns (h broadcast from LDS, 16 B at a time)
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float4* h4 = reinterpret_cast<const float4*>(hs + half * (H / 2));
+    // ---- partial dot products of this thread's 4 rows over its 32 columns (h broadcast from LDS, 16 B at a time)
+    float acc[GRU_RPT] = {0.f, 0.f, 0.f, 0.f};
+    const float4* h4 = reinterpret_cast<const float4*>(hs + cs * GRU_CPT);
 #pragma unroll
-    for (int k = 0; k < H / 8; ++k) {
+    for (int k = 0; k < GRU_CPT / 4; ++k) {
       const float4 hv = h4[k];
-      a0 = fmaf(w[4 * k + 0], hv.x, a0);
-      a1 = fmaf(w[4 * k + 1], hv.y, a1);
-      a2 = fmaf(w[4 * k + 2], hv.z, a2);
-      a3 = fmaf(w[4 * k + 3], hv.w, a3);
+#pragma unroll
+      for (int q = 0; q < GRU_RPT; ++q) {
+        acc[q] = fmaf(w[q][4 * k + 0], hv.x, acc[q]);
+        acc[q] = fmaf(w[q][4 * k + 1], hv.y, acc[q]);
+        acc[q] = fmaf(w[q][4 * k + 2], hv.z, acc[q]);
+        acc[q] = fmaf(w[q][4 * k + 3], hv.w, acc[q]);
+      }
     }
-    part[half][row] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int q = 0; q < GRU_RPT; ++q) part[cs][rg * GRU_RPT + q] = acc[q];
     __syncthreads();
     // ---- gates for the owned units, publish h_t[ju] as a {value, step+1} granule
     if (tid < GRU_U) {
-      const float ghr = part[0][tid] + part[1][tid] + bh_r;
-      const float ghz = part[0][GRU_U + tid] + part[1][GRU_U + tid] + bh_z;
-      const float ghn = part[0][2 * GRU_U + tid] + part[1][2 * GRU_U + tid] + bh_n;
+      float sr = 0.f, sz = 0.f, sn = 0.f;
+#pragma unroll
+      for (int p = 0; p < GRU_NCS; ++p) {
+        sr += part[p][tid];
+        sz += part[p][GRU_U + tid];
+        sn += part[p][2 * GRU_U + tid];
+      }
+      const float ghr = sr + bh_r, ghz = sz + bh_z, ghn = sn + bh_n;
       // hardware exp2 / rcp (1-2 ulp): the gate chain is on the serial critical path of every step
       const float r = fast_sigmoid(g_r + ghr);
       const float z = fast_sigmoid(g_z + ghz);
