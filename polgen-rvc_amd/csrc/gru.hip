@@ -77,6 +77,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(__fdividef(1.f - e, 1.f + e), x);
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits vmcnt(0): here that would put
+// the write-acknowledge of the h_t / y stores and the next step's prefetched input-projection loads (global round trips
+// of ~0.5-1 us) on the serial path of every step.  Global visibility between workgroups is carried by the tagged granules.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 union Granule {
   unsigned long long u;
   struct {
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
     }
 #pragma unroll
     for (int q = 0; q < GRU_RPT; ++q) part[cs][rg * GRU_RPT + q] = acc[q];
-    __syncthreads();
+    lds_barrier();
     // ---- gates for the owned units, publish h_t[ju] as a {value, step+1} granule
     if (tid < GRU_U) {
       float sr = 0.f, sz = 0.f, sn = 0.f;
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
       } while (true);
       hs[k] = gr.s.v;
     }
-    __syncthreads();
+    lds_barrier();
     if (sfail) break;     // block-uniform: every thread sees the flag after the barrier
   }
   if (tid == 0 && sfail) atomicExch(err, 1);
