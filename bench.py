@@ -4,11 +4,15 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
 
-Workload (BASELINE.json configs[1]): one 30 s 16 kHz mono clip per step per GPU, RVC v2 48 kHz voice
+Workload c2 (default, BASELINE.json configs[1]): one 30 s 16 kHz mono clip per step per GPU, RVC v2 48 kHz voice
 model, rmvpe+ F0, contentvec-shaped HuBERT-base, index_rate 0, fp32, chunk geometry (1,6,38,41);
 synthetic clip + synthetic weights in the real checkpoint layouts (no real weights exist offline).
-A step = VC.pipeline on one clip with the PCM already resident in HBM (device in, device int16 out).
-Weak scaling: every rank converts its own clip per step; value = all ranks' audio seconds / max-rank wall.
+Workload c3 (--workload c3, BASELINE.json configs[2]): a batch of 64 x 30 s clips per step, index_rate 0.75 with
+a 65 536 x 768 retrieval matrix resident in HBM.
+A step = VC.pipeline on the step's clip(s) as SURVEY.md 8(d) defines the metric: H2D of the float PCM (pinned
+host memory), every kernel, D2H of the int16 PCM -- all inside the timed region.
+Weak scaling: every rank converts its own clip(s) per step; value = all ranks' audio seconds / max-rank wall
+(whole-job aggregate, as the driver contract asks; value_per_gpu = value / n_gpus).
 """
 import argparse
 import json
@@ -31,6 +35,8 @@ PEAK_F16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma
 # for ALGORITHMIC conv FLOPs on them is a third of the fp16 MFMA peak.
 PEAK_H3_TFLOPS = PEAK_F16_TFLOPS / 3.0
 CLIP_SECONDS = 30.0
+C3_BATCH = 64
+C3_INDEX_ROWS = 65536
 CPU_SAMPLE_SECONDS = 8.0
 
 
@@ -101,40 +107,84 @@ def pmc_traffic(tile_name):
     return None, None
 
 
+def exact_fp32_child(steps, warmup):
+    """The same workload with every product on the exact-fp32 MFMA (RVCX_H3=0 RVCX_ATT_H3=0) in a FRESH child
+    process, started before this process touches the GPU and run to completion (never an exec of a GPU-initialised
+    process, never two benches sharing the device)."""
+    import subprocess
+    env = dict(os.environ, RVCX_H3="0", RVCX_ATT_H3="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-exact-fp32", "--no-roofline"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "warmup": d["warmup"], "dtype": "f32 (v_mfma_f32_32x32x2_f32 products, exact fp32)",
+                "env": "RVCX_H3=0 RVCX_ATT_H3=0", "how": "child process of this bench run, same workload"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2")
+    ap.add_argument("--batch", type=int, default=None, help="clips per step (c3 default 64, c2 default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default="")
     a = ap.parse_args()
+    c3 = a.workload == "c3"
+    B = a.batch or (C3_BATCH if c3 else 1)
+    if a.steps is None:
+        a.steps = 3 if c3 else 10
 
-    rank, local, world = D.init("nccl")
+    rank, local, world = D.env_rank()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit(f"--gpus {a.gpus} needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
+    # torch.cuda.device_count() does not initialise the GPU on this image
+    if torch.cuda.device_count() < max(a.gpus, local + 1):
+        raise SystemExit(f"--gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    fp32 = None
+    if world == 1 and not a.no_exact_fp32 and not c3:
+        fp32 = exact_fp32_child(a.steps, a.warmup)       # before the first GPU call of this process
+    rank, local, world = D.init("nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ctx = _lib.Context(local)
 
-    # rank 0 parses/folds/packs the checkpoints; the folded slab goes to the other GPUs over RCCL/xGMI
+    # rank 0 parses/folds/packs the checkpoints; the folded weight regions go to the other GPUs over RCCL/xGMI
     t0 = time.perf_counter()
     mid = load_models(ctx, zero=(rank != 0))
+    if c3:
+        big = S.make_index(C3_INDEX_ROWS, 768, 0)
+        ctx.load_index(np.zeros_like(big) if rank != 0 else big)
     t_load = time.perf_counter() - t0
     t0 = time.perf_counter()
     nbytes = D.broadcast_weights(ctx, local, 0)
     t_bcast = time.perf_counter() - t0
 
     params = make_params()
-    clip = S.make_clip(rank, CLIP_SECONDS)
-    n = clip.shape[0]
-    wav = torch.from_numpy(clip).to(dev)
+    if c3:
+        params.index_rate = 0.75
+    # pinned host buffers: the step's H2D / D2H copies are asynchronous DMA inside the timed region
+    clips = [S.make_clip(rank * B + i, CLIP_SECONDS) for i in range(B)]
+    n = clips[0].shape[0]
+    wavs = [torch.from_numpy(c).pin_memory() for c in clips]
     cap = ctx.out_capacity(mid, n, params)
-    out = torch.empty(cap, dtype=torch.int16, device=dev)
+    outs = [torch.empty(cap, dtype=torch.int16).pin_memory() for _ in range(B)]
+    wp, op, ns = [w.data_ptr() for w in wavs], [o.data_ptr() for o in outs], [n] * B
     torch.cuda.synchronize()
 
     def step():
-        return ctx.convert_batch_raw(mid, [wav.data_ptr()], [n], params, [out.data_ptr()])[0]
+        return ctx.convert_batch_raw(mid, wp, ns, params, op)[0]
 
     for _ in range(a.warmup):
         step()
@@ -147,51 +197,64 @@ def main():
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = dt / a.steps * 1e3
-    rtf = world * a.steps * CLIP_SECONDS / dt
-
-    # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv): one extra, untimed step with a
-    # HIP event pair around every conv launch on the library's stream
+    rtf = world * a.steps * B * CLIP_SECONDS / dt
     stage = ctx.last_timing()
-    ctx.flop_counter(reset=True)
-    ctx.conv_profile_begin()
-    step()
-    prof = ctx.conv_profile_end()
-    if a.profile_out and rank == 0:
-        with open(a.profile_out.replace('.json', '') + '_conv_launches.csv', 'w') as f:
-            f.write(ctx.conv_profile_csv())
-    total_flops = ctx.flop_counter()
-    prof.sort(key=lambda r: -r["ms"])
-    dom = prof[0]
-    conv_ms = sum(r["ms"] for r in prof)
-    conv_flops = sum(r["flops"] for r in prof)
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic(dom["tile"])
-    h3 = dom["tile"].startswith("conv_h3")
-    peak = PEAK_H3_TFLOPS if h3 else PEAK_F32_TFLOPS
-    roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (each fp32 product block = 3 fp16 MFMAs of a hi/lo "
-                              "split); 'achieved' counts algorithmic 2*M*N*K conv FLOPs" if h3 else
-                              "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-                "traffic_source": traffic_src,
-                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                "flops_per_launch": dom["flops"] / dom["launches"],
-                "family": {"ms": conv_ms, "tflops": conv_flops / (conv_ms * 1e-3) / 1e12,
-                           "frac_of_fp32_mfma_peak": conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                           "share_of_step": conv_ms / ms_per_step},
-                "whole_path_tflops": total_flops / (ms_per_step * 1e-3) / 1e12}
+
+    # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv): one extra, untimed step in SERIAL mode
+    # (every launch on the library's one stream, so a launch's duration is its own) with a HIP event pair around
+    # every conv launch.  `rocprofv3 --kernel-trace --stats` of `RVCX_SERIAL=1 python bench.py ...` gives the same
+    # per-kernel averages (profiles/rocprof_r02_*).
+    roofline, prof = None, None
+    if not a.no_roofline:
+        ctx.flop_counter(reset=True)
+        ctx.conv_profile_begin()
+        step()
+        prof = ctx.conv_profile_end()
+        if a.profile_out and rank == 0:
+            with open(a.profile_out.replace('.json', '') + '_conv_launches.csv', 'w') as f:
+                f.write(ctx.conv_profile_csv())
+        total_flops = ctx.flop_counter()
+        prof.sort(key=lambda r: -r["ms"])
+        dom = prof[0]
+        conv_ms = sum(r["ms"] for r in prof)
+        conv_flops = sum(r["flops"] for r in prof)
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom["tile"])
+        h3 = dom["tile"].startswith("conv_h3")
+        peak = PEAK_H3_TFLOPS if h3 else PEAK_F32_TFLOPS
+        roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
+                    "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                    "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (each fp32 product block = 3 fp16 MFMAs of a "
+                                  "hi/lo split); 'achieved' counts algorithmic 2*M*N*K conv FLOPs" if h3 else
+                                  "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                    "traffic_source": traffic_src,
+                    "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "family": {"ms": conv_ms, "tflops": conv_flops / (conv_ms * 1e-3) / 1e12,
+                               "frac_of_fp32_mfma_peak": conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                               "share_of_step": conv_ms / ms_per_step},
+                    "whole_path_tflops": total_flops / (ms_per_step * 1e-3) / 1e12}
 
     if rank == 0:
+        wl = (f"batch of {B} x 30 s 16 kHz clips per GPU per step, RVC v2 48k, f0_method=rmvpe+, HuBERT-base, "
+              f"index_rate=0.75 over a resident {C3_INDEX_ROWS} x 768 index, geometry (1,6,38,41)" if c3 else
+              ("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
+              ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
         res = {"metric": "real-time-factor (audio-sec/wall-sec) per GPU, 30s@16kHz RMVPE->48kHz",
                "value": rtf, "unit": "x real-time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 (conv products as 3 fp16 MFMAs of a hi/lo split, fp32 accumulate; fp32 elsewhere)",
+               "dtype": ("f32 (conv products as 3 fp16 MFMAs of a hi/lo split, fp32 accumulate; fp32 elsewhere)"
+                         if os.environ.get("RVCX_H3", "1") != "0" else "f32 (exact fp32 MFMA products)"),
                "data": "synthetic",
-               "config": {"workload": "single 30 s 16 kHz clip per GPU per step, RVC v2 48k, f0_method=rmvpe+, "
-                                      "HuBERT-base, index_rate=0, geometry (1,6,38,41), PCM resident in HBM",
+               "value_per_gpu": rtf / world,
+               "value_is": "whole-job aggregate over n_gpus (driver contract); value_per_gpu = value / n_gpus",
+               "config": {"workload": wl + "; timed region = H2D of float PCM (pinned host) + all kernels + D2H of int16",
+                          "clips_per_step": B, "micro_batch": ctx.micro_batch(mid, n, params),
                           "out_samples": got, "weights_bcast_bytes": nbytes, "weights_bcast_s": t_bcast,
                           "load_s": t_load},
                "stage_ms": stage, "roofline": roofline, "conv_tiles": prof}
+        if fp32 is not None:
+            res["exact_fp32"] = fp32
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         else:

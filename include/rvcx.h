@@ -87,9 +87,16 @@ int rvcx_unload_synth(rvcx_ctx*, int model_id);
  * big_npy is the (n, dim) float32 matrix of stored vectors; NULL/0 drops the index. */
 int rvcx_load_index(rvcx_ctx*, const float* big_npy, int64_t n, int dim);
 
-/* folded-weight blob of everything loaded so far (contiguous device memory) -- used to
- * broadcast weights to other ranks with RCCL instead of re-loading from host */
-int rvcx_weights_blob(rvcx_ctx*, void** dev_ptr, int64_t* nbytes);
+/* Folded weights live in per-model regions (freed by rvcx_unload_synth / rvcx_load_index(NULL) / a reload).
+ * rvcx_weights_regions lists the device chunks of everything loaded, in a fixed order (HuBERT, RMVPE, voice
+ * models by id, index): up to `cap` (pointer, used bytes) pairs are written, the total chunk count is returned.
+ * Chunk sizes, offsets and *layout_hash depend on tensor SHAPES only, so ranks that loaded placeholder values
+ * (zeros) with the same configurations report the same layout; rank 0's chunks can then be RCCL-broadcast into
+ * them (polgen-rvc_amd/dist.py) instead of parsing / folding the checkpoints once per GPU.  New in rvcx -- the
+ * reference is single-device.  After the chunks were overwritten, rvcx_weights_adopt re-reads
+ * the value-dependent layer flags that travel in each region's header. */
+int rvcx_weights_regions(rvcx_ctx*, int cap, void** dev_ptrs, int64_t* nbytes, uint64_t* layout_hash);
+int rvcx_weights_adopt(rvcx_ctx*);
 
 /* ---- stage-level entry points (parity tests bind these) ------------------------------- */
 /* RMVPE0Predictor.infer_from_audio_with_pitch -- rvc/lib/predictors/RMVPE.py:487-496.
@@ -125,10 +132,22 @@ int64_t rvcx_out_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
  * f0_method="rmvpe+", pitch_guidance=1, resample_sr=0, f0_file=None.
  * wav16k[i] (n[i] samples, 16 kHz mono f32, host or device); out[i] caller-allocated int16
  * buffers of rvcx_out_len samples (host or device); out_f32[i] optional (same capacity) float
- * waveform before int16 quantisation; out_n[i] receives the number of samples produced; noise[i] optional packed parity noise (see rvcx_noise_len). */
+ * waveform before int16 quantisation; out_n[i] receives the number of samples produced; noise[i] optional
+ * packed parity noise (see rvcx_noise_len).
+ * Utterances of equal length are converted together as micro-batches (B > 1 through HuBERT, RMVPE and the
+ * synthesizer; rvcx_micro_batch tells how many at a time); every utterance's result is bit-identical to
+ * converting it alone.  Without parity noise utterance i draws its Gaussians from Philox(seed + i).
+ * Batch conversion is listed as not done in the reference (TODO.md:11). */
 int rvcx_convert_batch(rvcx_ctx*, int model_id, int B, const float* const* wav16k_hd,
                        const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
                        int16_t* const* out_hd, float* const* out_f32_hd, int64_t* out_n);
+/* the same with float64 input, the dtype rvc_infer hands to VC.pipeline (load_audio -> float64,
+ * rvc/lib/my_utils.py:5-16): the float64 zero-phase high-pass (pipeline.py:329) then sees the reference's input */
+int rvcx_convert_batch_f64(rvcx_ctx*, int model_id, int B, const double* const* wav16k_hd,
+                           const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
+                           int16_t* const* out_hd, float* const* out_f32_hd, int64_t* out_n);
+/* utterances of n samples converted per launch sequence (memory-bounded; RVCX_MAX_BATCH, RVCX_ARENA_GB) */
+int rvcx_micro_batch(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* floats of parity noise rvcx_convert_batch consumes for one n-sample utterance: for each
  * chunk in order, z_noise (inter*T) then src_noise (T*upp) -- the draw order of the reference */
 int64_t rvcx_noise_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
@@ -136,6 +155,19 @@ int64_t rvcx_noise_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p)
  * returns coarse (int32) and f0 (Hz) of p_len frames for one utterance */
 int rvcx_get_f0(rvcx_ctx*, const float* wav16k_hd, int64_t n, const rvcx_params* p,
                 int32_t* coarse, float* f0, int64_t* p_len);
+/* VC.get_f0(input_audio_path, x, p_len, pitch, "rmvpe+", ...) -- rvc/infer/pipeline.py:132-201 with the
+ * reference's meaning of x: the ALREADY reflect-padded, high-passed signal (n samples).  Writes 1 + n/160 frames
+ * of coarse (1..255) and f0 (Hz, shifted by p->pitch semitones), un-truncated like the reference's return. */
+int rvcx_get_f0_x(rvcx_ctx*, const float* x_hd, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0);
+/* VC.vc(model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version="v2", protect) --
+ * rvc/infer/pipeline.py:203-287: HuBERT -> (retrieval blend with the resident index when index_rate != 0) ->
+ * x2 upsample / protect mix -> Synthesizer.infer.  audio0 (n samples of audio_pad); pitch / pitchf (n_pitch
+ * frames, n_pitch >= rvcx_vc_frames(n)); out receives rvcx_vc_frames(n) * upp float32 samples (*out_n), the
+ * un-trimmed audio1 of the reference.  z_noise / src_noise as in rvcx_synth_infer. */
+int rvcx_vc(rvcx_ctx*, int model_id, const float* audio0_hd, int64_t n, const int32_t* pitch_hd,
+            const float* pitchf_hd, int n_pitch, int sid, float index_rate, float protect,
+            const float* z_noise_hd, const float* src_noise_hd, uint64_t seed, float* out_hd, int64_t* out_n);
+int rvcx_vc_frames(rvcx_ctx*, int64_t n);
 
 /* ---- instrumentation ------------------------------------------------------------------- */
 /* per-stage GPU milliseconds (HIP events on the library's stream) of the last

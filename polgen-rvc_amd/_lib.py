@@ -59,9 +59,10 @@ _lib = None
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
     "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index",
-    "rvcx_weights_blob", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
+    "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
-    "rvcx_out_len", "rvcx_convert_batch", "rvcx_noise_len", "rvcx_get_f0", "rvcx_last_timing",
+    "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
+    "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
     "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
@@ -267,6 +268,7 @@ class Context:
     def load_rmvpe(self, cfg_struct, state: dict):
         tbl, keep = make_table(state)
         self._ck(lib().rvcx_load_rmvpe(self._h, C.byref(cfg_struct), tbl, len(tbl)), "load_rmvpe")
+        self.rmvpe_loaded = True
 
     def load_hubert(self, cfg_struct, state: dict):
         tbl, keep = make_table(state)
@@ -350,12 +352,15 @@ class Context:
         return int(lib().rvcx_noise_len(self._h, model_id, C.c_int64(n), C.byref(params)))
 
     def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False):
-        """VC.pipeline for a list of 16 kHz mono float32 clips -> list of int16 arrays
-        (and the pre-quantisation float waveforms when want_f32)."""
+        """VC.pipeline for a list of 16 kHz mono clips -> list of int16 arrays (and the pre-quantisation
+        float waveforms when want_f32).  float64 clips (what the reference's load_audio returns) cross the
+        ABI as float64; anything else as float32.  Equal-length clips are converted as micro-batches."""
         B = len(wavs)
-        wavs = [f32(w) for w in wavs]
+        is64 = B > 0 and all(np.asarray(w).dtype == np.float64 for w in wavs)
+        wavs = [np.ascontiguousarray(w, dtype=np.float64 if is64 else np.float32) for w in wavs]
         ns = (C.c_int64 * B)(*[w.shape[0] for w in wavs])
-        wp = (C.POINTER(C.c_float) * B)(*[_p(w) for w in wavs])
+        wt = C.c_double if is64 else C.c_float
+        wp = (C.POINTER(wt) * B)(*[_p(w, wt) for w in wavs])
         caps = [self.out_capacity(model_id, w.shape[0], params) for w in wavs]
         outs = [np.empty(c, np.int16) for c in caps]
         op = (C.POINTER(C.c_int16) * B)(*[_p(o, C.c_int16) for o in outs])
@@ -376,16 +381,16 @@ class Context:
                 nz.append(buf)
             npp = (C.POINTER(C.c_float) * B)(*[_p(b) for b in nz])
         out_n = (C.c_int64 * B)()
-        self._ck(lib().rvcx_convert_batch(self._h, model_id, B, wp, ns, C.byref(params), npp, op, fp, out_n),
-                 "convert_batch")
+        fn = lib().rvcx_convert_batch_f64 if is64 else lib().rvcx_convert_batch
+        self._ck(fn(self._h, model_id, B, wp, ns, C.byref(params), npp, op, fp, out_n), "convert_batch")
         pcm = [o[:out_n[i]].copy() for i, o in enumerate(outs)]
         if want_f32:
             return pcm, [o[:out_n[i]].copy() for i, o in enumerate(f32s)]
         return pcm
 
     def convert_batch_raw(self, model_id, wav_ptrs, ns, params, out_ptrs, f32_ptrs=None, noise_ptrs=None):
-        """Same as convert_batch but with raw (host or device) addresses: nothing is staged through numpy.
-        Returns the list of produced sample counts."""
+        """Same as convert_batch but with raw (host or device) addresses of float32 clips: nothing is staged
+        through numpy.  Returns the list of produced sample counts."""
         B = len(wav_ptrs)
         wp = (C.c_void_p * B)(*wav_ptrs)
         op = (C.c_void_p * B)(*out_ptrs)
@@ -397,10 +402,53 @@ class Context:
                  "convert_batch")
         return [int(v) for v in out_n]
 
-    def weights_blob(self):
-        ptr, n = C.c_void_p(), C.c_int64()
-        self._ck(lib().rvcx_weights_blob(self._h, C.byref(ptr), C.byref(n)), "weights_blob")
-        return ptr.value, n.value
+    def micro_batch(self, model_id, n, params) -> int:
+        return int(lib().rvcx_micro_batch(self._h, model_id, C.c_int64(n), C.byref(params)))
+
+    def get_f0_x(self, x, params: "Params"):
+        """VC.get_f0 on the already padded + filtered signal: (coarse, f0) of 1 + n/160 frames."""
+        x = f32(x)
+        F = 1 + x.shape[0] // 160
+        coarse = np.empty(F, np.int32)
+        f0 = np.empty(F, np.float32)
+        self._ck(lib().rvcx_get_f0_x(self._h, _p(x), C.c_int64(x.shape[0]), C.byref(params), _p(coarse, C.c_int32),
+                                     _p(f0)), "get_f0_x")
+        return coarse, f0
+
+    def vc_frames(self, n: int) -> int:
+        return int(lib().rvcx_vc_frames(self._h, C.c_int64(n)))
+
+    def vc(self, model_id, audio0, pitch, pitchf, sid=0, index_rate=0.0, protect=0.5, z_noise=None, src_noise=None,
+           seed=0):
+        """VC.vc: one chunk of audio_pad -> the un-trimmed float32 waveform."""
+        a = f32(audio0)
+        pitch, pitchf = i32(np.asarray(pitch).ravel()), f32(np.asarray(pitchf).ravel())
+        T = self.vc_frames(a.shape[0])
+        if T <= 0:
+            raise RvcxError("vc: chunk too short")
+        out = np.empty(T * self.synth_upp(model_id), np.float32)
+        zn = None if z_noise is None else f32(z_noise)
+        sn = None if src_noise is None else f32(src_noise)
+        got = C.c_int64(0)
+        self._ck(lib().rvcx_vc(self._h, model_id, _p(a), C.c_int64(a.shape[0]), _p(pitch, C.c_int32), _p(pitchf),
+                               int(min(pitch.shape[0], pitchf.shape[0])), int(sid), C.c_float(index_rate),
+                               C.c_float(protect), _p(zn), _p(sn), C.c_uint64(seed), _p(out), C.byref(got)), "vc")
+        return out[:got.value]
+
+    def weights_regions(self):
+        """[(device pointer, used bytes)] of every weight chunk + the shape-only layout hash."""
+        h = C.c_uint64(0)
+        n = lib().rvcx_weights_regions(self._h, 0, None, None, C.byref(h))
+        if n < 0:
+            self._ck(-1, "weights_regions")
+        ptrs, sizes = (C.c_void_p * max(n, 1))(), (C.c_int64 * max(n, 1))()
+        n2 = lib().rvcx_weights_regions(self._h, n, ptrs, sizes, C.byref(h))
+        if n2 != n:
+            raise RvcxError("weights_regions: chunk count changed between calls")
+        return [(int(ptrs[i] or 0), int(sizes[i])) for i in range(n)], int(h.value)
+
+    def weights_adopt(self):
+        self._ck(lib().rvcx_weights_adopt(self._h), "weights_adopt")
 
     def conv_profile_begin(self):
         z = (C.c_int64 * 56)()

@@ -2,15 +2,34 @@
 
 ``hubert_base.pt`` is a fairseq checkpoint: a pickle whose ``"model"`` entry is the tensor dict we need
 and whose ``"cfg"`` / ``"args"`` entries reference fairseq / omegaconf classes that are not installed.
-A restricted unpickler resolves torch / numpy / builtins normally and replaces every other global by an
-inert stub, so only tensors are ever materialised.
+A restricted unpickler resolves an exact allow-list of (module, name) pairs -- tensor rebuild helpers, storages,
+dtypes, OrderedDict, harmless builtin containers -- and replaces every other global (including builtins.eval /
+exec / getattr / __import__) by an inert stub, so only tensors are ever materialised.
 """
 from __future__ import annotations
 
 import pickle
 import types
 
-_SAFE_ROOTS = ("torch", "collections", "numpy", "builtins", "_codecs", "copyreg")
+import re
+
+# Exact (module, name) pairs the unpickler may resolve: what torch.save emits for tensors and plain containers.
+# Everything else -- fairseq / omegaconf / argparse classes AND dangerous builtins such as eval, exec, getattr or
+# __import__ -- becomes an inert stub, so a crafted file cannot run code through find_class (ADVICE r1).
+_ALLOWED = {
+    ("collections", "OrderedDict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Tensor"), ("torch", "Size"), ("torch", "device"),
+    ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "dtype"), ("numpy", "ndarray"), ("_codecs", "encode"),
+}
+_SAFE_BUILTINS = {"set", "frozenset", "slice", "complex", "bytearray", "range", "int", "float", "bool", "list",
+                  "dict", "tuple", "str", "bytes", "object"}
+_TORCH_DATA = re.compile(r"^(\w+Storage|float\d+|bfloat16|half|double|int\d+|uint8|long|short|bool|complex\d+)$")
 
 
 class _Stub:
@@ -26,7 +45,8 @@ class _Stub:
 
 class _StubUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module.split(".")[0] in _SAFE_ROOTS:
+        if (module, name) in _ALLOWED or (module == "builtins" and name in _SAFE_BUILTINS) or \
+                (module == "torch" and _TORCH_DATA.match(name)):
             return super().find_class(module, name)
         return type(name, (_Stub,), {})
 

@@ -29,7 +29,9 @@ static thread_local std::string g_last_error;
     g_last_error = e.what();                  \
     if (C) {                                  \
       C->last_error = e.what();               \
+      (void)hipDeviceSynchronize(); /* side streams may still use arena memory */ \
       C->arena.reset();                       \
+      C->arena_f0.reset();                    \
     }                                         \
     (void)hipGetLastError();                  \
     return -1;                                \
@@ -70,6 +72,10 @@ int rvcx_create(int device, rvcx_ctx** out) {
     for (auto& e : h->c.ev_src) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_hub, hipEventDisableTiming));
+    RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream_io, hipStreamNonBlocking));
+    RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_io, hipEventDisableTiming));
+    for (auto& e : h->c.ev_front) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : h->c.ev_done) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     {
       // HuBERT gets its own stream, restricted to 232 of the 256 CUs: RMVPE's many small kernels (and the 8
       // workgroups of its GRU) always find free CUs instead of queueing behind HuBERT's wide launches, and the
@@ -89,6 +95,9 @@ int rvcx_create(int device, rvcx_ctx** out) {
     }
     conv_init();
     h->c.resblock_streams = !getenv("RVCX_RESBLOCK_STREAMS") || atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
+    // RVCX_SERIAL=1: every launch on the one main stream (rocprofv3 kernel durations are then each launch's own)
+    h->c.serial_env = getenv("RVCX_SERIAL") && atoi(getenv("RVCX_SERIAL")) != 0;
+    h->c.serial = h->c.serial_env;
     RVCX_HIP(hipMalloc(&h->c.dev_err, sizeof(int)));
     RVCX_HIP(hipMemset(h->c.dev_err, 0, sizeof(int)));
     h->c.arena.reserve((size_t)256 << 20);
@@ -139,14 +148,15 @@ static void to_host(Ctx& c, float* h, const float* d, size_t n) {
   RVCX_HIP(hipMemcpyAsync(h, d, n * sizeof(float), hipMemcpyDeviceToHost, c.stream));
   RVCX_HIP(hipStreamSynchronize(c.stream));
 }
-static void ensure_slab(Ctx& c) { c.slab.init((size_t)8 << 30); }
+// kernel-level entry points pack their weights into a region that lives for the call only
+#define TEMP_REGION(C) WeightRegion tmp_region_; RegionScope tmp_scope_(*(C), tmp_region_)
 
 int rvcx_op_conv1d(rvcx_ctx* ctx, const float* x, const float* w, const float* bias, const float* res,
                    float* y, int B, int Cin, int Tin, int Cout, int K, int stride, int dil,
                    int pad_left, int Tout, int groups, int pre_lrelu, float pre_slope, int act,
                    float act_slope, const int32_t* lens_in, const int32_t* lens_out) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
+  TEMP_REGION(C);
   size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tout;
   C->arena.reserve((nx + 2 * ny) * 4 + (64 << 20));
   C->arena.reset();
@@ -179,7 +189,7 @@ int rvcx_conv_override(int tile, int variant, int splitk) {
 int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
                       int iters, float* ms_per_launch) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
+  TEMP_REGION(C);
   const int pad = (K * dil - dil) / 2;
   const int Tout = (Tin + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tout;
@@ -234,7 +244,7 @@ int rvcx_op_convtranspose1d(rvcx_ctx* ctx, const float* x, const float* w, const
                             int B, int Cin, int Tin, int Cout, int K, int stride, int pad,
                             int pre_lrelu, float pre_slope) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
+  TEMP_REGION(C);
   const int Tout = (Tin - 1) * stride - 2 * pad + K;
   size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tout;
   C->arena.reserve((nx + ny) * 4 + (64 << 20));
@@ -272,7 +282,7 @@ static void unpad_rows(const std::vector<float>& xp, float* y, size_t planes, in
 int rvcx_op_conv2d3x3(rvcx_ctx* ctx, const float* x, const float* w, const float* bias, const float* res,
                       float* y, int B, int Cin, int H, int W, int Cout, int act) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
+  TEMP_REGION(C);
   const int Wp = W + 2;
   size_t nx = (size_t)B * Cin * H * Wp, ny = (size_t)B * Cout * H * Wp;
   C->arena.reserve((nx + 2 * ny) * 4 + (64 << 20));
@@ -302,7 +312,7 @@ int rvcx_op_conv2d3x3(rvcx_ctx* ctx, const float* x, const float* w, const float
 int rvcx_op_convtranspose2d(rvcx_ctx* ctx, const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int H, int W, int Cout, int act) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
+  TEMP_REGION(C);
   const int Wp = W + 2, Wpo = 2 * W + 2;
   size_t nx = (size_t)B * Cin * H * Wp, ny = (size_t)B * Cout * 2 * H * Wpo;
   C->arena.reserve((nx + ny) * 4 + (64 << 20));
@@ -341,7 +351,6 @@ static TensorTable make_table(const rvcx_tensor* tbl, int n) {
 
 int rvcx_load_synth(rvcx_ctx* ctx, const rvcx_synth_cfg* cfg, const rvcx_tensor* tbl, int n, int* model_id) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
   TensorTable t = make_table(tbl, n);
   auto m = synth_load(*C, *cfg, t);
   int id = -1;
@@ -359,7 +368,8 @@ int rvcx_load_synth(rvcx_ctx* ctx, const rvcx_synth_cfg* cfg, const rvcx_tensor*
 int rvcx_unload_synth(rvcx_ctx* ctx, int model_id) {
   API_BEGIN(ctx)
   if (model_id < 0 || model_id >= (int)C->synths.size()) fail("bad model id");
-  C->synths[model_id].reset();   // slab space is reclaimed when the context is destroyed
+  RVCX_HIP(hipDeviceSynchronize());
+  C->synths[model_id].reset();   // frees the model's weight region
   API_END
 }
 
@@ -373,13 +383,49 @@ int rvcx_synth_upp(rvcx_ctx* ctx, int model_id) {
   return ctx->c.synths[model_id]->upp;
 }
 
-int rvcx_weights_blob(rvcx_ctx* ctx, void** dev_ptr, int64_t* nbytes) {
-  API_BEGIN(ctx)
-  *dev_ptr = C->slab.base();
-  *nbytes = (int64_t)C->slab.used();
-  API_END
+// every weight region of the context in a fixed order: HuBERT, RMVPE, voice models by id, index
+static std::vector<WeightRegion*> all_regions(Ctx& c, uint64_t* hash) {
+  std::vector<WeightRegion*> r;
+  uint64_t h = 1469598103934665603ull;
+  auto add = [&](WeightRegion* w, uint64_t tag) {
+    h = (h ^ tag) * 1099511628211ull;
+    h = (h ^ (w ? w->layout_hash() : 0)) * 1099511628211ull;
+    if (w) r.push_back(w);
+  };
+  add(c.hubert ? c.hubert->region.get() : nullptr, 1);
+  add(c.rmvpe ? c.rmvpe->region.get() : nullptr, 2);
+  for (size_t i = 0; i < c.synths.size(); ++i) add(c.synths[i] ? c.synths[i]->region.get() : nullptr, 16 + i);
+  add(c.index ? c.index->region.get() : nullptr, 3);
+  if (hash) *hash = h;
+  return r;
 }
 
+int rvcx_weights_regions(rvcx_ctx* ctx, int cap, void** dev_ptrs, int64_t* nbytes, uint64_t* layout_hash) {
+  Ctx* C = ctx ? &ctx->c : nullptr;
+  try {
+    if (!C) fail("null context");
+    RVCX_HIP(hipSetDevice(C->device));
+    int k = 0;
+    for (WeightRegion* r : all_regions(*C, layout_hash))
+      for (int i = 0; i < r->n_chunks(); ++i, ++k)
+        if (k < cap) {
+          dev_ptrs[k] = r->chunk_base(i);
+          nbytes[k] = (int64_t)r->chunk_used(i);
+        }
+    return k;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    if (C) C->last_error = e.what();
+    return -1;
+  }
+}
+
+int rvcx_weights_adopt(rvcx_ctx* ctx) {
+  API_BEGIN(ctx)
+  RVCX_HIP(hipDeviceSynchronize());
+  for (WeightRegion* r : all_regions(*C, nullptr)) r->adopt();
+  API_END
+}
 
 int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                      const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
@@ -456,7 +502,6 @@ int rvcx_op_layernorm_c(rvcx_ctx* ctx, const float* x, const float* gamma, const
 
 int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor* tbl, int n) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
   TensorTable t = make_table(tbl, n);
   C->rmvpe = rmvpe_load(*C, *cfg, t);
   API_END
@@ -464,7 +509,6 @@ int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor*
 
 int rvcx_load_hubert(rvcx_ctx* ctx, const rvcx_hubert_cfg* cfg, const rvcx_tensor* tbl, int n) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
   TensorTable t = make_table(tbl, n);
   C->hubert = hubert_load(*C, *cfg, t);
   API_END
@@ -516,7 +560,7 @@ int rvcx_op_bigru(rvcx_ctx* ctx, const float* x, const float* w_ih, const float*
                   const float* b_hh, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
                   const float* b_hh_r, float* y, int B, int T, int I, int H) {
   API_BEGIN(ctx)
-  ensure_slab(*C);
+  TEMP_REGION(C);
   const int H3 = 3 * H;
   C->arena.reserve(((size_t)B * T * (2 * I + 2 * H3 + 4 * H)) * 4 + (64 << 20));
   C->arena.reset();
@@ -560,8 +604,7 @@ int rvcx_load_index(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim) {
   if (!big_npy || n == 0) {
     C->index.reset();
   } else {
-    ensure_slab(*C);
-    C->index = index_load(*C, big_npy, n, dim);
+      C->index = index_load(*C, big_npy, n, dim);
   }
   API_END
 }
@@ -597,41 +640,57 @@ int64_t rvcx_noise_len(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params
   return noise_len_for(ctx->c, *ctx->c.synths[model_id], n, *p);
 }
 
+static int convert_impl(rvcx_ctx* ctx, int model_id, int B, const float* const* wav32, const double* const* wav64,
+                        const int64_t* n, const rvcx_params* p, const float* const* noise, int16_t* const* out,
+                        float* const* out_f32, int64_t* out_n) {
+  API_BEGIN(ctx)
+  (void)get_synth(*C, model_id);
+  if (B < 0 || (B > 0 && (!n || !p || !out || (!wav32 && !wav64)))) fail("convert_batch: null argument");
+  std::vector<UttIO> ios((size_t)B);
+  for (int i = 0; i < B; ++i) {
+    UttIO& u = ios[i];
+    u.wav = wav32 ? wav32[i] : nullptr;
+    u.wav64 = wav64 ? wav64[i] : nullptr;
+    u.n = n[i];
+    u.noise = noise ? noise[i] : nullptr;
+    u.out = out[i];
+    u.out_f32 = out_f32 ? out_f32[i] : nullptr;
+    u.seed_offset = i;
+    if (!(u.wav || u.wav64) || !u.out) fail("convert_batch: null buffer for utterance " + std::to_string(i));
+  }
+  static const bool timing = !getenv("RVCX_STAGE_TIMING") || atoi(getenv("RVCX_STAGE_TIMING")) != 0;
+  float ms[9] = {0};
+  convert_batch(*C, model_id, ios, *p, timing ? ms : nullptr);
+  C->check_dev_err();
+  for (int k = 0; k < 9; ++k) C->timing[k] = ms[k];
+  if (out_n)
+    for (int i = 0; i < B; ++i) out_n[i] = ios[i].out_n;
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_convert_batch(rvcx_ctx* ctx, int model_id, int B, const float* const* wav16k, const int64_t* n,
                        const rvcx_params* p, const float* const* noise, int16_t* const* out, float* const* out_f32,
                        int64_t* out_n) {
-  API_BEGIN(ctx)
-  SynthModel& M = get_synth(*C, model_id);
-  size_t need = 0;
-  for (int i = 0; i < B; ++i) {
-    size_t b = convert_arena_bytes(*C, model_id, n[i], *p) + (size_t)n[i] * 4;
-    if (noise && noise[i]) b += (size_t)noise_len_for(*C, M, n[i], *p) * 4;
-    need = std::max(need, b);
+  return convert_impl(ctx, model_id, B, wav16k, nullptr, n, p, noise, out, out_f32, out_n);
+}
+
+int rvcx_convert_batch_f64(rvcx_ctx* ctx, int model_id, int B, const double* const* wav16k, const int64_t* n,
+                           const rvcx_params* p, const float* const* noise, int16_t* const* out,
+                           float* const* out_f32, int64_t* out_n) {
+  return convert_impl(ctx, model_id, B, nullptr, wav16k, n, p, noise, out, out_f32, out_n);
+}
+
+int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  if (!ctx || !p || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id] ||
+      !ctx->c.hubert || !ctx->c.rmvpe)
+    return -1;
+  try {
+    return convert_micro_batch(ctx->c, model_id, n, *p);
+  } catch (const std::exception& e) {
+    ctx->c.last_error = e.what();
+    return -1;
   }
-  C->arena.reserve(need);
-  float tsum[9] = {0};
-  for (int i = 0; i < B; ++i) {
-    C->arena.reset();
-    const long cap = out_capacity(M, n[i], *p);
-    float* dw = any_to_dev(*C, wav16k[i], (size_t)n[i]);
-    const float* dn = nullptr;
-    if (noise && noise[i]) dn = any_to_dev(*C, noise[i], (size_t)noise_len_for(*C, M, n[i], *p));
-    short* dpcm = C->arena.alloc<short>((size_t)cap);
-    float* df32 = (out_f32 && out_f32[i]) ? C->arena.alloc<float>((size_t)cap) : nullptr;
-    float ms[9];
-    static const bool timing = !getenv("RVCX_STAGE_TIMING") || atoi(getenv("RVCX_STAGE_TIMING")) != 0;
-    for (float& v : ms) v = 0.f;
-    const long got = convert_one(*C, model_id, dw, n[i], *p, dn, dpcm, df32, timing ? ms : nullptr);
-    for (int k = 0; k < 9; ++k) tsum[k] += ms[k];
-    RVCX_HIP(hipMemcpyAsync(out[i], dpcm, (size_t)got * sizeof(short), hipMemcpyDefault, C->stream));
-    if (df32) RVCX_HIP(hipMemcpyAsync(out_f32[i], df32, (size_t)got * sizeof(float), hipMemcpyDefault, C->stream));
-    RVCX_HIP(hipStreamSynchronize(C->stream));
-    C->check_dev_err();
-    if (out_n) out_n[i] = got;
-  }
-  for (int k = 0; k < 9; ++k) C->timing[k] = tsum[k];
-  C->arena.reset();
-  API_END
 }
 
 int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0,
@@ -660,10 +719,105 @@ int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params
   API_END
 }
 
+int rvcx_get_f0_x(rvcx_ctx* ctx, const float* x, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0) {
+  API_BEGIN(ctx)
+  if (!C->rmvpe) fail("rmvpe not loaded");
+  const long F = 1 + n / 160;
+  C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, 1, n) + (size_t)n * 8 + (size_t)F * 32 + (64 << 20));
+  C->arena.reset();
+  float* dx = any_to_dev(*C, x, (size_t)n);
+  float* fraw = C->arena.alloc<float>((size_t)F);
+  int* dc = C->arena.alloc<int>((size_t)F);
+  float* df = C->arena.alloc<float>((size_t)F);
+  rmvpe_forward(*C, *C->rmvpe, 1, dx, n, 0.03f, p->f0_min, p->f0_max, fraw, nullptr, C->stream);
+  launch_f0_coarse(fraw, df, dc, (int)F, p->pitch, p->f0_min, p->f0_max, C->stream);
+  RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)F * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)F * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->check_dev_err();
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_vc_frames(rvcx_ctx* ctx, int64_t n) {
+  if (!ctx || !ctx->c.hubert) return -1;
+  const int Th = hubert_frames(*ctx->c.hubert, n);
+  if (Th <= 0) return -1;
+  return (int)std::min<long>(n / 160, 2L * Th);
+}
+
+int rvcx_vc(rvcx_ctx* ctx, int model_id, const float* audio0, int64_t n, const int32_t* pitch, const float* pitchf,
+            int n_pitch, int sid, float index_rate, float protect, const float* z_noise, const float* src_noise,
+            uint64_t seed, float* out, int64_t* out_n) {
+  API_BEGIN(ctx)
+  SynthModel& M = get_synth(*C, model_id);
+  if (!C->hubert) fail("hubert not loaded");
+  if (!pitch || !pitchf) fail("vc: non-f0 models cannot run in the reference either (generators.py:57-77)");
+  const int E = C->hubert->cfg.embed_dim, inter = M.cfg.inter_channels;
+  RVCX_CHECK(E == M.cfg.input_dim, "hubert embed dim != synthesizer input_dim");
+  const int Th = hubert_frames(*C->hubert, n);
+  RVCX_CHECK(Th > 0, "vc: chunk too short");
+  const int T = (int)std::min<long>(n / 160, 2L * Th);       // p_len clamp, pipeline.py:257-262
+  RVCX_CHECK(n_pitch >= T, "vc: pitch / pitchf shorter than the chunk's frame count");
+  const size_t nz = (size_t)inter * T, nsrc = (size_t)T * M.upp;
+  const bool use_index = C->index && index_rate != 0.f, use_protect = protect < 0.5f;
+  size_t need = hubert_arena_bytes(*C->hubert, 1, n) + synth_arena_bytes(M, 1, T) + (size_t)n * 4 +
+                ((size_t)T * ((size_t)3 * E + inter + 3 * M.upp + 16)) * 4;
+  if (use_index) need += index_arena_bytes(*C->index, Th);
+  C->arena.reserve(need);
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  float* dw = any_to_dev(*C, audio0, (size_t)n);
+  int* dp = any_to_dev<int>(*C, pitch, (size_t)T);
+  float* dpf = any_to_dev(*C, pitchf, (size_t)T);
+  float* feats = C->arena.alloc<float>((size_t)E * Th);
+  {
+    const size_t mk = C->arena.mark();
+    hubert_forward(*C, *C->hubert, 1, dw, n, 12, feats, s);
+    C->arena.reset(mk);
+  }
+  const float* feats0 = feats;
+  if (use_index) {
+    if (use_protect) {
+      float* keep = C->arena.alloc<float>((size_t)E * Th);
+      RVCX_HIP(hipMemcpyAsync(keep, feats, (size_t)E * Th * 4, hipMemcpyDeviceToDevice, s));
+      feats0 = keep;
+    }
+    const size_t mk = C->arena.mark();
+    index_blend(*C, *C->index, feats, Th, index_rate, nullptr, nullptr, s);
+    C->arena.reset(mk);
+  }
+  float* phone = C->arena.alloc<float>((size_t)E * T);
+  launch_upsample_protect(feats, feats0, dpf, phone, E, Th, T, protect, use_protect ? 1 : 0, s);
+  float* zn = C->arena.alloc<float>(nz);
+  float* sn = C->arena.alloc<float>(nsrc);
+  if (z_noise) RVCX_HIP(hipMemcpyAsync(zn, z_noise, nz * 4, hipMemcpyDefault, s));
+  else launch_randn(zn, nz, seed, 0, s);
+  if (src_noise) RVCX_HIP(hipMemcpyAsync(sn, src_noise, nsrc * 4, hipMemcpyDefault, s));
+  else launch_randn(sn, nsrc, seed, (uint64_t)1 << 35, s);
+  float* wavout = C->arena.alloc<float>(nsrc);
+  SynthIO io;
+  io.B = 1;
+  io.T = T;
+  io.phone_ct = phone;
+  io.pitch = dp;
+  io.pitchf = dpf;
+  io.sid_host = &sid;
+  io.z_noise = zn;
+  io.src_noise = sn;
+  io.out = wavout;
+  synth_forward(*C, M, io, nullptr);
+  RVCX_HIP(hipMemcpyAsync(out, wavout, nsrc * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  if (out_n) *out_n = (int64_t)nsrc;
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
                       int32_t* bn, int32_t* kind, int cap) {
   API_BEGIN(ctx)
-  C->serial = begin != 0;
+  C->serial = begin != 0 || C->serial_env;
   if (begin) {
     conv_profile_begin();
   } else {

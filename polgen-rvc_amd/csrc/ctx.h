@@ -13,32 +13,106 @@ struct RmvpeModel;
 struct HubertModel;
 struct IndexData;
 
-// contiguous slab for folded/packed weights (so the whole set can be RCCL-broadcast)
-class WeightSlab {
+// Folded/packed weights live in per-model REGIONS (one per HuBERT, RMVPE, voice model, index): a region is a
+// short list of device chunks filled by bump allocation and freed when its model is unloaded.  The chunk
+// sequence, every offset and the region's layout hash depend on tensor SHAPES only -- never on values -- so
+// every rank of a multi-GPU job builds the same layout and rank 0 can RCCL-broadcast the chunks
+// (rvcx_weights_regions).  Value-dependent facts (may a layer use its fp16 hi/lo image?) are flag bytes in a
+// header at the start of chunk 0: they travel with the broadcast and are re-read by rvcx_weights_adopt.
+class WeightRegion {
  public:
-  ~WeightSlab() {
-    if (base_) (void)hipFree(base_);
+  static constexpr size_t kChunkBytes = (size_t)32 << 20;
+  static constexpr int kMaxFlags = 4096;
+  static constexpr size_t kHeaderBytes = kMaxFlags;
+  WeightRegion() {
+    flags_.reset(new uint8_t[kMaxFlags]);
+    std::memset(flags_.get(), 0, kMaxFlags);
   }
-  void init(size_t bytes) {
-    if (base_) return;
-    RVCX_HIP(hipMalloc(&base_, bytes));
-    cap_ = bytes;
+  ~WeightRegion() {
+    for (auto& c : chunks_) (void)hipFree(c.base);
   }
+  WeightRegion(const WeightRegion&) = delete;
+  WeightRegion& operator=(const WeightRegion&) = delete;
   float* upload(const std::vector<float>& h) { return upload(h.data(), h.size()); }
   float* upload(const float* h, size_t n) {
-    size_t bytes = (std::max<size_t>(n, 1) * sizeof(float) + 255) & ~size_t(255);
-    if (off_ + bytes > cap_) fail("weight slab exhausted");
-    float* d = reinterpret_cast<float*>(static_cast<char*>(base_) + off_);
-    if (n) RVCX_HIP(hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
-    off_ += bytes;
+    float* d = static_cast<float*>(reserve(std::max<size_t>(n, 1) * sizeof(float)));
+    if (n && h) RVCX_HIP(hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
     return d;
   }
-  void* base() const { return base_; }
-  size_t used() const { return off_; }
+  // bytes of device memory, 256-byte aligned, contents undefined
+  void* reserve(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (chunks_.empty()) {
+      new_chunk(std::max(kChunkBytes, bytes + kHeaderBytes));
+      chunks_[0].off = kHeaderBytes;    // flag header
+    }
+    if (chunks_.back().off + bytes > chunks_.back().cap) new_chunk(std::max(kChunkBytes, bytes));
+    Chunk& c = chunks_.back();
+    void* d = static_cast<char*>(c.base) + c.off;
+    mix(chunks_.size() - 1);
+    mix(c.off);
+    mix(bytes);
+    c.off += bytes;
+    return d;
+  }
+  // a value-dependent yes/no that must agree on every rank after a broadcast; the returned pointer stays valid
+  // for the life of the region and is what kernels' launchers consult
+  const uint8_t* new_flag(bool v) {
+    if (nflags_ >= kMaxFlags) fail("weight region: flag table full");
+    flags_[nflags_] = v ? 1 : 0;
+    return &flags_[nflags_++];
+  }
+  void seal() {     // publish the host flags into the device header (end of a load)
+    if (chunks_.empty()) reserve(256);
+    RVCX_HIP(hipMemcpy(chunks_[0].base, flags_.get(), kMaxFlags, hipMemcpyHostToDevice));
+  }
+  void adopt() {    // re-read the flags from the device header (after a broadcast wrote it)
+    if (chunks_.empty()) return;
+    RVCX_HIP(hipMemcpy(flags_.get(), chunks_[0].base, kMaxFlags, hipMemcpyDeviceToHost));
+  }
+  int n_chunks() const { return (int)chunks_.size(); }
+  void* chunk_base(int i) const { return chunks_[i].base; }
+  size_t chunk_used(int i) const { return chunks_[i].off; }
+  size_t used() const {
+    size_t t = 0;
+    for (auto& c : chunks_) t += c.off;
+    return t;
+  }
+  uint64_t layout_hash() const { return hash_; }
 
  private:
-  void* base_ = nullptr;
-  size_t cap_ = 0, off_ = 0;
+  struct Chunk {
+    void* base;
+    size_t cap, off;
+  };
+  void new_chunk(size_t bytes) {
+    Chunk c{nullptr, bytes, 0};
+    RVCX_HIP(hipMalloc(&c.base, bytes));
+    chunks_.push_back(c);
+  }
+  void mix(uint64_t v) {
+    for (int i = 0; i < 8; ++i) {
+      hash_ ^= (v >> (8 * i)) & 0xff;
+      hash_ *= 1099511628211ull;
+    }
+  }
+  std::vector<Chunk> chunks_;
+  std::unique_ptr<uint8_t[]> flags_;
+  int nflags_ = 0;
+  uint64_t hash_ = 1469598103934665603ull;
+};
+
+// what the loaders call: uploads go to the region currently being filled (RegionScope)
+class WeightSlab {
+ public:
+  float* upload(const std::vector<float>& h) { return cur().upload(h); }
+  float* upload(const float* h, size_t n) { return cur().upload(h, n); }
+  const uint8_t* new_flag(bool v) { return cur().new_flag(v); }
+  WeightRegion& cur() {
+    if (!cur_) fail("internal: weight upload outside a RegionScope");
+    return *cur_;
+  }
+  WeightRegion* cur_ = nullptr;
 };
 
 struct StageTimer {
@@ -60,6 +134,10 @@ struct Ctx {
   hipStream_t aux[2] = {nullptr, nullptr};   // the three ResBlocks of an NSF stage run side by side
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream_io = nullptr;             // finished PCM leaves here while the next micro-batch computes
+  hipEvent_t ev_io = nullptr;
+  hipEvent_t ev_front[2] = {nullptr, nullptr}; // front end (high-pass .. reflect pad) of micro-batch k is ready
+  hipEvent_t ev_done[2] = {nullptr, nullptr};  // main stream is done with micro-batch k's front set
   hipEvent_t ev_src[2] = {nullptr, nullptr};   // NSF source branch (sine + noise convs) beside TextEncoder/flow
   Arena arena;
   Arena arena_f0;                 // RMVPE workspace: lives on stream2 across the main stream's arena resets
@@ -68,6 +146,7 @@ struct Ctx {
   double flops = 0.0;
   bool resblock_streams = false;  // run the ResBlocks of an NSF stage on 3 streams
   bool serial = false;            // profiling: keep every launch on the main stream (true per-kernel times)
+  bool serial_env = false;        // RVCX_SERIAL=1: serial for the whole life of the context
   int* dev_err = nullptr;         // device flag: a kernel gave up waiting (checked after each API call)
   void check_dev_err();
   float timing[9] = {0};
@@ -92,10 +171,19 @@ struct Ctx {
   }
 };
 
-// packed conv layer living in the weight slab
+// fills `r` for the duration of a load call
+struct RegionScope {
+  Ctx& c;
+  WeightRegion* prev;
+  RegionScope(Ctx& cc, WeightRegion& r) : c(cc), prev(cc.slab.cur_) { cc.slab.cur_ = &r; }
+  ~RegionScope() { c.slab.cur_ = prev; }
+};
+
+// packed conv layer living in a weight region
 struct ConvW {
   const float* w = nullptr;
-  const void* w_h3 = nullptr;     // fp16 hi/lo split image (layers that may run on conv_h3_kernel)
+  const void* w_h3 = nullptr;     // fp16 hi/lo split image (space is reserved whenever the SHAPE allows it)
+  const uint8_t* h3_ok = nullptr; // region flag: the image is usable (no weight overflowed fp16 at scale S)
   const float* bias = nullptr;
   int cin = 0, cout = 0, k = 1, groups = 1;
   int cin_gp = 0, cout_gp = 0;
@@ -107,7 +195,7 @@ ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, 
 // fill the channel/pad fields of ConvArgs from a packed layer
 inline void conv_set_weights(ConvArgs& a, const ConvW& w) {
   a.w = w.w;
-  a.w_h3 = w.w_h3;
+  a.w_h3 = (w.w_h3 && w.h3_ok && *w.h3_ok) ? w.w_h3 : nullptr;
   a.bias = w.bias;
   a.groups = w.groups;
   a.Cin_g = w.cin / w.groups;

@@ -80,6 +80,12 @@ Ctx::~Ctx() {
   for (auto e : ev_src)
     if (e) (void)hipEventDestroy(e);
   if (ev_join) (void)hipEventDestroy(ev_join);
+  if (ev_io) (void)hipEventDestroy(ev_io);
+  for (auto e : ev_front)
+    if (e) (void)hipEventDestroy(e);
+  for (auto e : ev_done)
+    if (e) (void)hipEventDestroy(e);
+  if (stream_io) (void)hipStreamDestroy(stream_io);
   for (auto e : ev_aux)
     if (e) (void)hipEventDestroy(e);
   for (auto s : aux)
@@ -134,6 +140,16 @@ static std::vector<float> pack_h3(const std::vector<float>& wp, int k, int cin_g
   return out;
 }
 
+// The image's space is reserved from the layer's shape alone (same bytes as the fp32 weights); whether it may be
+// used is a region flag, so ranks that load placeholder values build the same layout and learn the flag from
+// the broadcast (zero-filled weight-norm tensors fold to NaN and used to shrink the layout).
+static void upload_h3(Ctx& c, ConvW& L, const std::vector<float>& wp, int k) {
+  const std::vector<float> hp = pack_h3(wp, k, L.cin_gp, L.cout_gp);
+  const size_t n = (size_t)k * (L.cin_gp / 16) * 4 * L.cout_gp * 4;
+  L.w_h3 = hp.empty() ? c.slab.cur().reserve(n * sizeof(float)) : c.slab.upload(hp);
+  L.h3_ok = c.slab.new_flag(!hp.empty());
+}
+
 ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups, bool h3) {
   ConvW L;
   L.cin = cin_g * groups;
@@ -144,10 +160,7 @@ ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, 
   L.cout_gp = conv_cout_pad(cout / groups);
   const std::vector<float> wp = pack_conv_weight(w, cout, cin_g, k, groups);
   L.w = c.slab.upload(wp);
-  if (h3 && groups == 1 && L.cin_gp % 16 == 0 && conv_h3_enabled()) {
-    const std::vector<float> hp = pack_h3(wp, k, L.cin_gp, L.cout_gp);
-    if (!hp.empty()) L.w_h3 = c.slab.upload(hp);
-  }
+  if (h3 && groups == 1 && L.cin_gp % 16 == 0 && conv_h3_enabled()) upload_h3(c, L, wp, k);
   L.bias = bias ? c.slab.upload(bias, (size_t)cout) : nullptr;
   return L;
 }
@@ -162,10 +175,7 @@ ConvT1dW make_convT1d(Ctx& c, const float* w, const float* bias, int cin, int co
   L.w.cin_gp = conv_cin_pad(cin);
   L.w.cout_gp = conv_cout_pad(pp.cout_total);
   L.w.w = c.slab.upload(pp.w);
-  if (L.w.cin_gp % 16 == 0 && conv_h3_enabled()) {   // polyphase taps are an ordinary dense stride-1 conv
-    const std::vector<float> hp = pack_h3(pp.w, pp.taps, L.w.cin_gp, L.w.cout_gp);
-    if (!hp.empty()) L.w.w_h3 = c.slab.upload(hp);
-  }
+  if (L.w.cin_gp % 16 == 0 && conv_h3_enabled()) upload_h3(c, L.w, pp.w, pp.taps);   // polyphase taps: a dense stride-1 conv
   L.w.bias = c.slab.upload(pp.bias);
   L.stride = s;
   L.pad_t = p;

@@ -13,6 +13,7 @@ namespace rvcx {
 
 std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, const TensorTable& t) {
   auto M = std::make_unique<HubertModel>();
+  RegionScope scope(c, *M->region);
   M->cfg = cfg;
   const int E = cfg.embed_dim;
   for (int i = 0; i < cfg.n_conv; ++i) {
@@ -63,6 +64,7 @@ std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, con
     L.ln2_b = c.slab.upload(t.f32(p + ".final_layer_norm.bias"));
     M->layers.push_back(L);
   }
+  M->region->seal();
   return M;
 }
 
@@ -81,7 +83,7 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
 }
 
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
-                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor) {
+                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor, long wav_bs) {
   Arena& A = c.arena;
   const auto& cf = m.cfg;
   const int C = cf.conv_dim, E = cf.embed_dim;
@@ -97,6 +99,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     const int64_t Tout = (Tin - cf.conv_kernels[i]) / cf.conv_strides[i] + 1;
     RVCX_CHECK(Tout > 0, "hubert: input too short");
     ConvArgs a = conv1d_args(m.convs[i], x, y, B, (int)Tin, (int)Tout, cf.conv_strides[i], 1, 0);
+    if (i == 0 && wav_bs > 0) a.x_bs = wav_bs;      // the B signals are slices of longer rows
     if (i > 0) a.act = ACT_GELU;
     c.conv_on(a, s);
     if (i == 0) {

@@ -11,6 +11,7 @@ constexpr int TOPK = 8;
 
 std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim) {
   auto ix = std::make_unique<IndexData>();
+  RegionScope scope(c, *ix->region);
   ix->n = n;
   ix->dim = dim;
   ix->mat = make_conv(c, big_npy, nullptr, (int)n, dim, 1, 1, false);   // exact fp32 products: neighbour ids are bit-exact
@@ -22,6 +23,7 @@ std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, i
     norms[(size_t)i] = s;
   }
   ix->norms = c.slab.upload(norms);
+  ix->region->seal();
   return ix;
 }
 

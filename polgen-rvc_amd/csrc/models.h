@@ -10,6 +10,7 @@ namespace rvcx {
 
 // ------------------------------------------------------------------------------ Synthesizer
 struct SynthModel {
+  std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model
   rvcx_synth_cfg cfg{};
   int upp = 1;
   // TextEncoder (rvc/lib/algorithm/encoders.py:76-126)
@@ -58,10 +59,12 @@ struct SynthIO {
   float* z_out = nullptr;             // (B, inter, T)
 };
 size_t synth_arena_bytes(const SynthModel& m, int B, int T);
-void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_ms /*3 or null*/);
+// stage_ev (optional): 4 caller-created events recorded at {start, enc_p done, flow done, decoder done} -- no sync
+void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* stage_ev /*4 or null*/);
 
 // ------------------------------------------------------------------------------ RMVPE
 struct RmvpeModel {
+  std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model
   rvcx_rmvpe_cfg cfg{};
   ConvW stft;        // (1026, 1, 1024) Hann-windowed Fourier basis, stride 160
   ConvW melfb;       // (128, 513) as a 1x1 conv
@@ -92,6 +95,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
 
 // ------------------------------------------------------------------------------ HuBERT
 struct HubertModel {
+  std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model
   rvcx_hubert_cfg cfg{};
   std::vector<ConvW> convs;
   const float *gn_g = nullptr, *gn_b = nullptr, *ln0_g = nullptr, *ln0_b = nullptr;
@@ -110,10 +114,12 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n);
 // `after_extractor` (optional) runs on the host right after the conv feature extractor has been enqueued:
 // the pipeline uses it to enqueue RMVPE's ~330 small launches while those long convs keep the GPU busy.
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
-                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor = nullptr);
+                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor = nullptr,
+                    long wav_bs = 0 /* element stride between the B signals, 0 = n */);
 
 // ------------------------------------------------------------------------------ retrieval index
 struct IndexData {
+  std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model
   ConvW mat;                    // big_npy (N, dim) packed as a 1x1 conv (N out channels)
   const float* rows = nullptr;  // (N, dim) row-major for the gather
   const float* norms = nullptr; // |b|^2 (N)

@@ -17,18 +17,28 @@ std::vector<Chunk> plan_chunks(long n, const std::vector<long>& opt_ts, const Ge
 long out_capacity(const SynthModel& m, long n, const rvcx_params& p);
 long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params& p);
 
-size_t highpass_ext_doubles(long n);   // scratch the caller provides as `ext`
+size_t highpass_ext_doubles(long n);   // scratch per signal the caller provides as `ext`
+// B equal-length signals (element stride xs, 0 = n); y64 / y32 are written densely (B, n)
 void launch_highpass(const float* x32, const double* x64, double* ext, double* y64, float* y32, long n,
-                     hipStream_t s);
+                     hipStream_t s, int B = 1, long xs = 0);
 
-// One utterance, everything on the device.  wav: device f32 (n).  noise: device packed parity noise or
-// null (Philox).  out_pcm: device int16 (capacity out_capacity), out_f32 optional.  Returns samples.
-long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_params& p, const float* noise,
-                 short* out_pcm, float* out_f32, float* stage_ms /*9 or null*/);
-size_t convert_arena_bytes(Ctx& c, int model_id, long n, const rvcx_params& p);
+// one utterance of a rvcx_convert_batch call.  wav / wav64 / noise / out / out_f32 may be host or device memory.
+struct UttIO {
+  const float* wav = nullptr;      // 16 kHz mono float32 ...
+  const double* wav64 = nullptr;   // ... or float64 (what load_audio returns in the reference, my_utils.py:16)
+  long n = 0;
+  const float* noise = nullptr;    // packed parity noise (rvcx_noise_len floats) or null (Philox)
+  short* out = nullptr;            // capacity out_capacity()
+  float* out_f32 = nullptr;        // optional, same capacity
+  long out_n = 0;                  // produced samples (result)
+  int seed_offset = 0;             // Philox stream of this utterance = params.seed + seed_offset
+};
+// VC.pipeline for a list of utterances: equal-length utterances run as micro-batches (B > 1 through every network).
+void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& utts, const rvcx_params& p, float* stage_ms /*9 or null*/);
+int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p);   // utterances per micro-batch at this length
 
-// VC.get_f0 on device for one utterance: coarse/f0 device arrays of p_len frames
+// VC.get_f0 on device for B equal-length reflect-padded signals: coarse/f0 rows of out_stride elements
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s);
+                   hipStream_t s, int B = 1, long out_stride = 0);
 
 }  // namespace rvcx

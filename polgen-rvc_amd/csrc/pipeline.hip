@@ -1,7 +1,11 @@
 // VC.pipeline (rvc/infer/pipeline.py:289-467) on the device: zero-phase high-pass, silence-aligned
 // chunking, F0 once per utterance, per-chunk HuBERT -> (index blend) -> x2 upsample / protect ->
 // Synthesizer.infer, trim, RMS envelope, peak normalise, int16.
+#include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdlib>
+#include <functional>
 
 #include "models.h"
 #include "ops.h"
@@ -53,11 +57,15 @@ struct IirCoef {
 constexpr int IIR_CHUNK = 256;
 constexpr int IIR_WARM = 3072;   // slice error vs the full recursion: 2.7e-8 at 3072 (= the 4096 floor), 7e-8 at 2560, 1.3e-6 at 2048
 
-// scipy filtfilt(method="pad", padtype="odd"): odd extension by PADLEN samples on both sides
-__global__ void odd_ext_kernel(const float* __restrict__ x32, const double* __restrict__ x64, double* ext, long n) {
+// scipy filtfilt(method="pad", padtype="odd"): odd extension by PADLEN samples on both sides.
+// All highpass kernels take a batch of equal-length signals: blockIdx.y = item, element strides xs / es / ys.
+__global__ void odd_ext_kernel(const float* __restrict__ x32, const double* __restrict__ x64, double* ext, long n,
+                               long xs, long es) {
   const long m = n + 2 * PADLEN;
+  const long b = blockIdx.y;
+  ext += b * es;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
-    auto X = [&](long j) -> double { return x64 ? x64[j] : (double)x32[j]; };
+    auto X = [&](long j) -> double { return x64 ? x64[b * xs + j] : (double)x32[b * xs + j]; };
     double v;
     if (i < PADLEN) v = 2.0 * X(0) - X(PADLEN - i);
     else if (i >= PADLEN + n) v = 2.0 * X(n - 1) - X(n - 2 - (i - PADLEN - n));
@@ -79,10 +87,12 @@ __device__ __forceinline__ double iir_step(const IirCoef& cf, double (&z)[5], do
 
 // one lane per slice; `rev` walks the buffers backwards (filtfilt's second, time-reversed pass)
 __global__ void iir_slice_kernel(const double* __restrict__ in, double* __restrict__ out, long m, int rev,
-                                 IirCoef cf) {
+                                 long es, IirCoef cf) {
   const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long s = p * IIR_CHUNK;
   if (s >= m) return;
+  in += blockIdx.y * es;
+  out += blockIdx.y * es;
   const long e = min(m, s + IIR_CHUNK);
   const long w0 = max(0L, s - IIR_WARM);
   double z[5];
@@ -109,36 +119,45 @@ __global__ void iir_slice_kernel(const double* __restrict__ in, double* __restri
   for (; i < e; ++i) out[rev ? m - 1 - i : i] = iir_step(cf, z, in[rev ? m - 1 - i : i]);
 }
 
-__global__ void crop_ext_kernel(const double* ext, double* y64, float* y32, long n) {
+__global__ void crop_ext_kernel(const double* ext, double* y64, float* y32, long n, long es, long ys) {
+  const long b = blockIdx.y;
+  ext += b * es;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const double v = ext[PADLEN + i];
-    if (y64) y64[i] = v;
-    if (y32) y32[i] = (float)v;
+    if (y64) y64[b * ys + i] = v;
+    if (y32) y32[b * ys + i] = (float)v;
   }
 }
 
-// ext: highpass_ext_doubles(n) doubles of scratch
-void launch_highpass(const float* x32, const double* x64, double* ext, double* y64, float* y32, long n,
-                     hipStream_t s) {
-  RVCX_CHECK(n > PADLEN, "highpass: input shorter than filtfilt's pad length");
-  static IirCoef cf;
-  static bool ready = false;
-  if (!ready) {
+static const IirCoef& iir_coef() {
+  // function-local static: initialised exactly once, also when several contexts start on different threads
+  static const IirCoef cf = [] {
+    IirCoef c;
     for (int i = 0; i < 6; ++i) {
-      cf.b[i] = BH[i];
-      cf.a[i] = AH[i];
+      c.b[i] = BH[i];
+      c.a[i] = AH[i];
     }
-    lfilter_zi(cf.zi);
-    ready = true;
-  }
+    lfilter_zi(c.zi);
+    return c;
+  }();
+  return cf;
+}
+
+// B equal-length signals (element stride xs in, n out); ext: B * highpass_ext_doubles(n) doubles of scratch
+void launch_highpass(const float* x32, const double* x64, double* ext, double* y64, float* y32, long n,
+                     hipStream_t s, int B, long xs) {
+  RVCX_CHECK(n > PADLEN, "highpass: input shorter than filtfilt's pad length");
+  const IirCoef& cf = iir_coef();
+  if (xs == 0) xs = n;
   const long m = n + 2 * PADLEN;
+  const long es = (long)highpass_ext_doubles(n);
   double* tmp = ext + m;
   const unsigned g = (unsigned)std::min<long>(cdiv64(m, 256), 65535);
   const int nslices = (int)cdiv64(m, IIR_CHUNK);
-  hipLaunchKernelGGL(odd_ext_kernel, dim3(g), dim3(256), 0, s, x32, x64, ext, n);
-  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64)), dim3(64), 0, s, ext, tmp, m, 0, cf);
-  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64)), dim3(64), 0, s, tmp, ext, m, 1, cf);
-  hipLaunchKernelGGL(crop_ext_kernel, dim3(g), dim3(256), 0, s, ext, y64, y32, n);
+  hipLaunchKernelGGL(odd_ext_kernel, dim3(g, B), dim3(256), 0, s, x32, x64, ext, n, xs, es);
+  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, ext, tmp, m, 0, es, cf);
+  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, tmp, ext, m, 1, es, cf);
+  hipLaunchKernelGGL(crop_ext_kernel, dim3(g, B), dim3(256), 0, s, ext, y64, y32, n, es, n);
 }
 
 size_t highpass_ext_doubles(long n) { return 2 * ((size_t)n + 2 * PADLEN) + 16; }
@@ -255,6 +274,8 @@ __global__ void f64_to_f32_kernel(const double* x, float* y, long n) {
 
 // ---------------------------------------------------------------- geometry helpers
 Geometry make_geometry(const rvcx_params& p, int tgt_sr) {
+  RVCX_CHECK(p.x_pad > 0 && p.x_query > 0 && p.x_center > 0 && p.x_max > 0,
+             "chunk geometry: x_pad, x_query, x_center and x_max must be positive (Config, infer.py:36-43)");
   Geometry g;
   g.t_pad = 16000L * p.x_pad;
   g.t_pad_tgt = (long)tgt_sr * p.x_pad;
@@ -279,27 +300,38 @@ std::vector<Chunk> plan_chunks(long n, const std::vector<long>& opt_ts, const Ge
   return plan;
 }
 
-static long chunk_frames(const HubertModel& h, long samples) {
-  return std::min<long>(samples / 160, 2L * hubert_frames(h, samples));
+// number of cut points VC.pipeline places in an n-sample clip: len(range(t_center, n, t_center)) when the clip
+// (plus the half-window pad) exceeds t_max, else none  (pipeline.py:330-344)
+static long cut_count(long n, const Geometry& g) {
+  if (n + 160 <= g.t_max) return 0;
+  return (n - 1) / g.t_center;
 }
 
 long out_capacity(const SynthModel& m, long n, const rvcx_params& p) {
   // samples VC.pipeline can return at most: every chunk yields <= (its frames)*upp - 2*t_pad_tgt and
   // consecutive chunks overlap by 2*t_pad + one window (pipeline.py:385-397)
   const Geometry g = make_geometry(p, m.cfg.sr);
-  const long nc = (g.t_center > 0 ? n / g.t_center : 0) + 2;
-  return (n / 160 + nc + 2) * m.upp;
+  return (n / 160 + cut_count(n, g) + 4) * m.upp;
+}
+
+long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params& p) {
+  // Upper bound for any placement of the cut points: the chunks tile the padded clip and every cut adds one
+  // overlap of 2*t_pad + window samples (pipeline.py:385-397); each frame draws inter + upp Gaussians.
+  (void)c;
+  const Geometry g = make_geometry(p, m.cfg.sr);
+  const long n_pad = n + 2 * g.t_pad;
+  const long cap_frames = n_pad / 160 + cut_count(n, g) * (2 * g.t_pad / 160 + 1) + 2;
+  return cap_frames * (long)(m.cfg.inter_channels + m.upp);
 }
 
 namespace {
 
 struct StageClock {
-  Ctx& c;
-  float* ms;
+  bool on;
   std::vector<hipEvent_t> ev;
-  StageClock(Ctx& cc, float* m) : c(cc), ms(m) {}
+  explicit StageClock(bool enabled) : on(enabled) {}
   int mark(hipStream_t s) {
-    if (!ms) return -1;
+    if (!on) return -1;
     hipEvent_t e;
     RVCX_HIP(hipEventCreate(&e));
     RVCX_HIP(hipEventRecord(e, s));
@@ -307,6 +339,7 @@ struct StageClock {
     return (int)ev.size() - 1;
   }
   float between(int a, int b) {
+    if (a < 0 || b < 0) return 0.f;
     float t = 0.f;
     RVCX_HIP(hipEventElapsedTime(&t, ev[a], ev[b]));
     return t;
@@ -316,246 +349,496 @@ struct StageClock {
   }
 };
 
-// chunk cut points (pipeline.py:330-344).  Needs a device->host copy of a few indices.
-std::vector<long> find_cut_points(Ctx& c, const double* audio64, long n, const Geometry& g) {
-  std::vector<long> opt;
-  if (n + 160 <= g.t_max) return opt;   // audio_pad (window/2 each side) length vs t_max
-  Arena& A = c.arena;
-  double* asum = A.alloc<double>((size_t)n);
-  hipLaunchKernelGGL(window_abs_sum_kernel, dim3((unsigned)std::min<long>(cdiv64(n, 256), 65535)), dim3(256), 0,
-                     c.stream, audio64, asum, n);
-  std::vector<long> ts;
-  for (long t = g.t_center; t < n; t += g.t_center) ts.push_back(t);
-  long* dres = A.alloc<long>(ts.size() + 1);
-  for (size_t i = 0; i < ts.size(); ++i) {
-    const long lo = std::max<long>(0, ts[i] - g.t_query), hi = std::min<long>(n, ts[i] + g.t_query);
-    hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(256), 0, c.stream, asum, lo, hi, dres + i);
-  }
-  opt.resize(ts.size());
-  RVCX_HIP(hipMemcpyAsync(opt.data(), dres, ts.size() * sizeof(long), hipMemcpyDeviceToHost, c.stream));
-  RVCX_HIP(hipStreamSynchronize(c.stream));
-  return opt;
-}
+// one utterance of the call, with everything the stages exchange (device pointers)
+struct Utt {
+  int io = 0;                 // index into the caller's arrays
+  long n = 0, n_pad = 0, p_len = 0, cap = 0;
+  const float* noise = nullptr;   // packed parity noise on the device (or null)
+  long noise_cap = 0;
+  short* pcm = nullptr;
+  float* outf = nullptr;
+  long out_n = 0;
+  // front-end products (live in the micro-batch's front set)
+  const double* a64 = nullptr;
+  const float* apad = nullptr;
+  const int* coarse = nullptr;
+  const float* f0 = nullptr;
+  std::vector<Chunk> plan;
+};
+
+struct Job {                  // one vc() call of the reference: chunk `ci` of utterance `u` (index in the micro-batch)
+  int u, ci;
+  long s, e, f0_off, out_off, noise_off;
+  int Th, T;
+};
 
 }  // namespace
 
-size_t convert_arena_bytes(Ctx& c, int model_id, long n, const rvcx_params& p) {
+size_t convert_item_bytes(Ctx& c, int model_id, long n, const rvcx_params& p) {
+  // arena bytes one utterance of a micro-batch needs beyond the call-long buffers (front set x2 + work area)
   const SynthModel& M = *c.synths[model_id];
   const Geometry g = make_geometry(p, M.cfg.sr);
   const long n_pad = n + 2 * g.t_pad;
   const long max_chunk = std::min<long>(n_pad, g.t_center + 2 * g.t_query + 2 * g.t_pad + 320);
   const int Tmax = (int)(max_chunk / 160 + 2);
-  size_t b = (size_t)n_pad * 40 + ((size_t)64 << 20);
-  b += rmvpe_arena_bytes(*c.rmvpe, 1, n_pad);
-  b += hubert_arena_bytes(*c.hubert, 1, max_chunk);
-  b += synth_arena_bytes(M, 1, Tmax) + (size_t)Tmax * (M.cfg.input_dim * 3 + M.upp * 3 + M.cfg.inter_channels) * 4;
-  b += (size_t)out_capacity(M, n, p) * 8;
+  size_t b = 2 * ((size_t)n_pad * 40 + (1 << 16));                    // two front sets
+  b += hubert_arena_bytes(*c.hubert, 1, max_chunk) - ((size_t)64 << 20) + (size_t)max_chunk * 4;
+  b += synth_arena_bytes(M, 1, Tmax) - ((size_t)64 << 20) +
+       (size_t)Tmax * ((size_t)M.cfg.input_dim * 3 + (size_t)M.upp * 3 + M.cfg.inter_channels + 8) * 4;
   if (c.index) b += index_arena_bytes(*c.index, Tmax);
   return b;
 }
 
-long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params& p) {
-  // only defined for the un-chunked case (cut points are data dependent); callers with long audio
-  // hand in a generous buffer (capacity below)
-  const Geometry g = make_geometry(p, m.cfg.sr);
-  const long cap_frames = n / 160 + (g.t_center > 0 ? n / g.t_center : 0) * 202 + 2 * (g.t_pad / 160) + 4;
-  (void)c;
-  return cap_frames * (long)(m.cfg.inter_channels + m.upp);
+size_t convert_call_bytes(Ctx& c, int model_id, long n, const rvcx_params& p, bool f64, bool noise) {
+  // call-long buffers of one utterance: staged input, parity noise, float + int16 output
+  const SynthModel& M = *c.synths[model_id];
+  size_t b = (size_t)n * (f64 ? 8 : 4) + (size_t)out_capacity(M, n, p) * 6 + 1024;
+  if (noise) b += (size_t)noise_len_for(c, M, n, p) * 4 + 256;
+  return b;
+}
+
+int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p) {
+  static const int env_max = getenv("RVCX_MAX_BATCH") ? std::max(1, atoi(getenv("RVCX_MAX_BATCH"))) : 8;
+  static const size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 64) << 30;
+  const size_t per = convert_item_bytes(c, model_id, n, p) +
+                     rmvpe_arena_bytes(*c.rmvpe, 1, n + 32000L * p.x_pad);
+  return (int)std::max<size_t>(1, std::min<size_t>((size_t)env_max, budget / std::max<size_t>(per, 1)));
 }
 
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s) {
-  // VC.get_f0 (pipeline.py:132-201) on the already reflect-padded signal
+                   hipStream_t s, int B, long out_stride) {
+  // VC.get_f0 (pipeline.py:132-201) on already reflect-padded signals (B, n_pad); coarse / f0 rows of out_stride
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
-  float* f0raw = c.arena.alloc<float>((size_t)F);
-  rmvpe_forward(c, *c.rmvpe, 1, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s);
-  launch_f0_coarse(f0raw, f0, coarse, (int)p_len, p.pitch, p.f0_min, p.f0_max, s);
+  float* f0raw = c.arena.alloc<float>((size_t)B * F);
+  rmvpe_forward(c, *c.rmvpe, B, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s);
+  for (int b = 0; b < B; ++b)
+    launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)p_len,
+                     p.pitch, p.f0_min, p.f0_max, s);
   return p_len;
 }
 
-long convert_one(Ctx& c, int model_id, const float* wav, long n, const rvcx_params& p, const float* noise,
-                 short* out_pcm, float* out_f32, float* stage_ms) {
+// VC.pipeline for a list of utterances (pipeline.py:289-467).
+//
+// Utterances of equal length form micro-batches that go through every network as one launch sequence with B > 1
+// (chunks of cut utterances are batch items too when their lengths agree): the serial BiGRU recurrence, the ~600
+// small launches of the front end and the TextEncoder/flow section are paid once per micro-batch instead of once
+// per clip.  Three streams: `sf` runs the front end (upload, float64 zero-phase high-pass, cut search, reflect
+// pad, RMVPE F0) of micro-batch k+1 while the main stream is still in the NSF decoder of micro-batch k; HuBERT keeps
+// its CU-masked stream; finished PCM leaves on the copy stream.  No host synchronisation inside the loop except
+// the cut-point read-back of clips longer than x_max seconds.
+void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_params& p, float* stage_ms) {
   RVCX_CHECK(c.hubert && c.rmvpe, "convert: hubert / rmvpe not loaded");
   RVCX_CHECK(model_id >= 0 && model_id < (int)c.synths.size() && c.synths[model_id], "convert: bad model id");
   const SynthModel& M = *c.synths[model_id];
   const Geometry g = make_geometry(p, M.cfg.sr);
   RVCX_CHECK(M.cfg.sr == 100 * M.upp, "synth sample rate must be 100 * prod(upsample_rates)");
-  RVCX_CHECK(n > g.t_pad, "convert: clip shorter than the reflect padding");
+  const int E = c.hubert->cfg.embed_dim, inter = M.cfg.inter_channels;
+  RVCX_CHECK(E == M.cfg.input_dim, "hubert embed dim != synthesizer input_dim");
+  const int NB = (int)ios.size();
+  if (NB == 0) return;
   hipStream_t s = c.stream;
-  Arena& A = c.arena;
-  StageClock clk(c, stage_ms);
-  const int e0 = clk.mark(s);
-  // ---- 1. zero-phase high-pass in float64 (pipeline.py:329)
-  const long n_pad = n + 2 * g.t_pad;
-  double* ext = A.alloc<double>(highpass_ext_doubles(n));
-  double* a64 = A.alloc<double>((size_t)n);
-  float* a32 = A.alloc<float>((size_t)n);
-  launch_highpass(wav, nullptr, ext, a64, a32, n, s);
-  const int e1 = clk.mark(s);
-  // ---- 2. chunk plan
-  std::vector<long> opt_ts = find_cut_points(c, a64, n, g);
-  std::vector<Chunk> plan = plan_chunks(n, opt_ts, g);
-  // ---- 3. reflect pad, F0 once per utterance (pipeline.py:348-380)
-  float* apad = A.alloc<float>((size_t)n_pad);
-  launch_reflect_pad(a32, apad, 1, (int)n, (int)g.t_pad, n_pad, s);
-  const long p_len = n_pad / 160;
-  int* coarse = A.alloc<int>((size_t)p_len + 8);
-  float* f0 = A.alloc<float>((size_t)p_len + 8);
-  // F0 runs on the second stream beside HuBERT (they only share the padded signal) out of its own arena, so
-  // the main stream's arena resets cannot recycle its workspace.  One host thread feeds both streams: RMVPE's
-  // ~330 small launches are enqueued right after the first chunk's HuBERT conv extractor (7 long kernels),
-  // otherwise HuBERT would sit idle for the milliseconds the host needs to enqueue RMVPE.
   hipStream_t sf = c.serial ? s : c.stream2;
-  RVCX_HIP(hipEventRecord(c.ev_fork, s));
+  hipStream_t sio = c.serial ? s : c.stream_io;
+  Arena& A = c.arena;
+  StageClock clk(stage_ms != nullptr);
+
+  // ---- micro-batches: utterances sorted by length (stable), equal lengths grouped, at most `mb_max` per group
+  std::vector<int> order(NB);
+  for (int i = 0; i < NB; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ios[a].n < ios[b].n; });
+  struct MB {
+    int first, count;
+  };
+  std::vector<MB> mbs;
+  long n_max = 0;
+  bool any_f64 = false, any_noise = false;
+  for (int i = 0; i < NB;) {
+    const long n = ios[order[i]].n;
+    RVCX_CHECK(n > g.t_pad, "convert: clip shorter than the reflect padding");
+    const int cap = convert_micro_batch(c, model_id, n, p);
+    int j = i;
+    while (j < NB && ios[order[j]].n == n && j - i < cap) ++j;
+    mbs.push_back({i, j - i});
+    i = j;
+  }
+  size_t call_bytes = 0, mb_bytes = 0, f0_bytes = 0;
+  for (const auto& u : ios) {
+    any_f64 |= u.wav64 != nullptr;
+    any_noise |= u.noise != nullptr;
+    n_max = std::max(n_max, u.n);
+    call_bytes += convert_call_bytes(c, model_id, u.n, p, u.wav64 != nullptr, u.noise != nullptr);
+  }
+  for (const auto& mb : mbs) {
+    const long n = ios[order[mb.first]].n;
+    mb_bytes = std::max(mb_bytes, (size_t)mb.count * convert_item_bytes(c, model_id, n, p));
+    f0_bytes = std::max(f0_bytes, rmvpe_arena_bytes(*c.rmvpe, mb.count, n + 2 * g.t_pad));
+  }
+  (void)any_f64;
+  (void)any_noise;
+  A.reserve(call_bytes + mb_bytes + ((size_t)96 << 20));
+  A.reset();
   c.arena_f0.reset();
-  c.arena_f0.reserve(rmvpe_arena_bytes(*c.rmvpe, 1, n_pad) + ((size_t)64 << 20));
-  int r0 = -1, r1 = -1;
-  bool f0_enqueued = false;
-  const std::function<void()> enqueue_f0 = [&]() {
-    if (f0_enqueued) return;
-    f0_enqueued = true;
-    RVCX_HIP(hipStreamWaitEvent(sf, c.ev_fork, 0));
-    r0 = clk.mark(sf);
+  c.arena_f0.reserve(f0_bytes + ((size_t)64 << 20));
+
+  // ---- call-long buffers
+  std::vector<Utt> utts(NB);
+  for (int i = 0; i < NB; ++i) {
+    Utt& u = utts[i];
+    u.io = i;
+    u.n = ios[i].n;
+    u.n_pad = u.n + 2 * g.t_pad;
+    u.p_len = u.n_pad / 160;
+    u.cap = out_capacity(M, u.n, p);
+    u.pcm = A.alloc<short>((size_t)u.cap);
+    u.outf = A.alloc<float>((size_t)u.cap);
+    if (ios[i].noise) {
+      u.noise_cap = noise_len_for(c, M, u.n, p);
+      u.noise = A.alloc<float>((size_t)u.noise_cap);
+    }
+  }
+  // two front sets (micro-batch k+1's front end runs while k is in the synthesizer)
+  struct Front {
+    void* wav = nullptr;
+    double *ext = nullptr, *a64 = nullptr, *asum = nullptr;
+    float *a32 = nullptr, *apad = nullptr, *f0 = nullptr;
+    int* coarse = nullptr;
+    long* cuts = nullptr;
+  } fr[2];
+  size_t front_items = 0;
+  for (const auto& mb : mbs) front_items = std::max(front_items, (size_t)mb.count);
+  {
+    size_t wmax = 0, emax = 0, nmax = 0, pmax = 0, fmax = 0, cmax = 0;
+    for (const auto& mb : mbs) {
+      const long n = ios[order[mb.first]].n;
+      const size_t k = (size_t)mb.count;
+      wmax = std::max(wmax, k * (size_t)n * 8);
+      emax = std::max(emax, k * highpass_ext_doubles(n));
+      nmax = std::max(nmax, k * (size_t)n);
+      pmax = std::max(pmax, k * (size_t)(n + 2 * g.t_pad));
+      fmax = std::max(fmax, k * (size_t)((n + 2 * g.t_pad) / 160 + 8));
+      cmax = std::max(cmax, k * (size_t)(cut_count(n, g) + 1));
+    }
+    for (auto& f : fr) {
+      f.wav = A.alloc<char>(wmax);
+      f.ext = A.alloc<double>(emax);    // also the |window sum| scratch of the cut search (same size class)
+      f.a64 = A.alloc<double>(nmax);
+      f.a32 = A.alloc<float>(nmax);
+      f.apad = A.alloc<float>(pmax);
+      f.f0 = A.alloc<float>(fmax);
+      f.coarse = A.alloc<int>(fmax);
+      f.cuts = A.alloc<long>(cmax);
+    }
+  }
+  const size_t work_mark = A.mark();
+
+  // ---- front end of one micro-batch on `sf`: upload, high-pass, cut search, reflect pad.  Returns after the
+  // (rare) cut-point read-back, so the chunk plan is known to the host.
+  auto front = [&](int k) {
+    const MB& mb = mbs[k];
+    Front& f = fr[k & 1];
+    const long n = ios[order[mb.first]].n, n_pad = n + 2 * g.t_pad;
+    const int Bm = mb.count;
+    if (sf != s && k >= 2) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_done[k & 1], 0));   // set k&1 was micro-batch k-2's
+    const bool f64 = ios[order[mb.first]].wav64 != nullptr;
+    for (int b = 0; b < Bm; ++b) {
+      const UttIO& io = ios[order[mb.first + b]];
+      RVCX_CHECK((io.wav64 != nullptr) == f64, "convert: float32 and float64 inputs mixed in one call");
+      if (f64) RVCX_HIP(hipMemcpyAsync(static_cast<double*>(f.wav) + (size_t)b * n, io.wav64, (size_t)n * 8, hipMemcpyDefault, sf));
+      else RVCX_HIP(hipMemcpyAsync(static_cast<float*>(f.wav) + (size_t)b * n, io.wav, (size_t)n * 4, hipMemcpyDefault, sf));
+      Utt& u = utts[order[mb.first + b]];
+      if (io.noise) RVCX_HIP(hipMemcpyAsync(const_cast<float*>(u.noise), io.noise, (size_t)u.noise_cap * 4, hipMemcpyDefault, sf));
+    }
+    launch_highpass(f64 ? nullptr : static_cast<const float*>(f.wav), f64 ? static_cast<const double*>(f.wav) : nullptr,
+                    f.ext, f.a64, f.a32, n, sf, Bm, n);
+    // chunk cut points (pipeline.py:330-344): only clips longer than t_max are cut
+    const long ncut = cut_count(n, g);
+    std::vector<long> cuts((size_t)Bm * ncut);
+    if (ncut > 0) {
+      for (int b = 0; b < Bm; ++b) {
+        double* asum = f.ext + (size_t)b * highpass_ext_doubles(n);   // the filter scratch is free again
+        hipLaunchKernelGGL(window_abs_sum_kernel, dim3((unsigned)std::min<long>(cdiv64(n, 256), 65535)), dim3(256), 0,
+                           sf, f.a64 + (size_t)b * n, asum, n);
+        long i = 0;
+        for (long t = g.t_center; t < n; t += g.t_center, ++i) {
+          const long lo = std::max<long>(0, t - g.t_query), hi = std::min<long>(n, t + g.t_query);
+          hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(256), 0, sf, asum, lo, hi, f.cuts + (size_t)b * ncut + i);
+        }
+        RVCX_CHECK(i == ncut, "internal: cut count");
+      }
+      RVCX_HIP(hipMemcpyAsync(cuts.data(), f.cuts, cuts.size() * sizeof(long), hipMemcpyDeviceToHost, sf));
+    }
+    launch_reflect_pad(f.a32, f.apad, Bm, (int)n, (int)g.t_pad, n_pad, sf);
+    if (sf != s) RVCX_HIP(hipEventRecord(c.ev_front[k & 1], sf));
+    if (ncut > 0) RVCX_HIP(hipStreamSynchronize(sf));
+    const long stride = n_pad / 160 + 8;
+    for (int b = 0; b < Bm; ++b) {
+      Utt& u = utts[order[mb.first + b]];
+      u.a64 = f.a64 + (size_t)b * n;
+      u.apad = f.apad + (size_t)b * n_pad;
+      u.coarse = f.coarse + (size_t)b * stride;
+      u.f0 = f.f0 + (size_t)b * stride;
+      std::vector<long> opt(cuts.begin() + (size_t)b * ncut, cuts.begin() + (size_t)(b + 1) * ncut);
+      u.plan = plan_chunks(n, opt, g);
+    }
+  };
+
+  // ---- F0 of one micro-batch on `sf` out of its own arena (pipeline.py:362-380: once per utterance)
+  std::vector<int> f0_ev0(mbs.size(), -1), f0_ev1(mbs.size(), -1);
+  auto enqueue_f0 = [&](int k) {
+    const MB& mb = mbs[k];
+    Front& f = fr[k & 1];
+    const long n_pad = ios[order[mb.first]].n + 2 * g.t_pad;
+    f0_ev0[k] = clk.mark(sf);
+    c.arena_f0.reset();
     c.arena.swap(c.arena_f0);
     try {
-      get_f0_device(c, apad, n_pad, p, coarse, f0, sf);
+      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8);
     } catch (...) {
       c.arena.swap(c.arena_f0);
       throw;
     }
     c.arena.swap(c.arena_f0);
-    r1 = clk.mark(sf);
-    RVCX_HIP(hipEventRecord(c.ev_join, sf));
+    f0_ev1[k] = clk.mark(sf);
+    if (sf != s) RVCX_HIP(hipEventRecord(c.ev_join, sf));
   };
-  bool joined = false;
-  const int e2 = clk.mark(s);
-  // ---- 4. per-chunk vc() (pipeline.py:203-287)
-  const long cap = out_capacity(M, n, p);
-  float* outf = out_f32 ? out_f32 : A.alloc<float>((size_t)cap);
-  long out_n = 0;
-  const float* np = noise;
-  float t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0};
-  const int E = c.hubert->cfg.embed_dim;
-  RVCX_CHECK(E == M.cfg.input_dim, "hubert embed dim != synthesizer input_dim");
-  for (const Chunk& ch : plan) {
-    const size_t mk = A.mark();
-    const long ns = ch.e - ch.s;
-    const int Th = hubert_frames(*c.hubert, ns);
-    const int T = (int)std::min<long>(ns / 160, 2L * Th);
-    RVCX_CHECK(Th > 0 && T > 0, "convert: chunk too short");
-    RVCX_CHECK((long)T * M.upp > 2 * g.t_pad_tgt, "convert: chunk shorter than its padding");
-    const int h0 = clk.mark(s);
-    float* feats = A.alloc<float>((size_t)E * Th);
-    {
-      const size_t mk2 = A.mark();
-      hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;
-      if (sh != s) {
-        RVCX_HIP(hipEventRecord(c.ev_hub, s));
-        RVCX_HIP(hipStreamWaitEvent(sh, c.ev_hub, 0));
-      }
-      hubert_forward(c, *c.hubert, 1, apad + ch.s, ns, 12, feats, sh, &enqueue_f0);
-      if (sh != s) {
-        RVCX_HIP(hipEventRecord(c.ev_hub, sh));
-        RVCX_HIP(hipStreamWaitEvent(s, c.ev_hub, 0));
-      }
-      A.reset(mk2);
-    }
-    const int h1 = clk.mark(s);
-    const float* feats0 = feats;
-    float* blended = feats;
-    const bool use_protect = p.protect < 0.5f;
-    if (c.index && p.index_rate != 0.f) {
-      if (use_protect) {
-        float* keep = A.alloc<float>((size_t)E * Th);
-        RVCX_HIP(hipMemcpyAsync(keep, feats, (size_t)E * Th * sizeof(float), hipMemcpyDeviceToDevice, s));
-        feats0 = keep;
-      }
-      const size_t mk2 = A.mark();
-      index_blend(c, *c.index, blended, Th, p.index_rate, nullptr, nullptr, s);
-      A.reset(mk2);
-    }
-    const int h2 = clk.mark(s);
-    if (!joined) {   // first consumer of f0 / coarse
-      RVCX_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
-      joined = true;
-    }
-    float* phone = A.alloc<float>((size_t)E * T);
-    launch_upsample_protect(blended, feats0, f0 + ch.f0_off, phone, E, Th, T, p.protect, use_protect ? 1 : 0, s);
-    // noise (parity: packed [z (inter*T) | src (T*upp)] per chunk in draw order; else Philox)
-    const size_t nz = (size_t)M.cfg.inter_channels * T, nsrc = (size_t)T * M.upp;
-    float *zn, *sn;
-    if (np) {
-      zn = const_cast<float*>(np);
-      sn = const_cast<float*>(np) + nz;
-      np += nz + nsrc;
-    } else {
-      zn = A.alloc<float>(nz);
-      sn = A.alloc<float>(nsrc);
-      const uint64_t off = (uint64_t)(&ch - &plan[0]) << 36;
-      launch_randn(zn, nz, p.seed, off, s);
-      launch_randn(sn, nsrc, p.seed, off + ((uint64_t)1 << 35), s);
-    }
-    float* wavout = A.alloc<float>(nsrc);
-    SynthIO io;
-    io.B = 1;
-    io.T = T;
-    io.phone_ct = phone;
-    io.pitch = coarse + ch.f0_off;
-    io.pitchf = f0 + ch.f0_off;
-    int sid = p.sid;
-    io.sid_host = &sid;
-    io.z_noise = zn;
-    io.src_noise = sn;
-    io.out = wavout;
-    float ms3[3] = {0, 0, 0};
-    synth_forward(c, M, io, stage_ms ? ms3 : nullptr);
-    const long keep_n = (long)nsrc - 2 * g.t_pad_tgt;
-    RVCX_CHECK(out_n + keep_n <= cap, "convert: output capacity exceeded");
-    RVCX_HIP(hipMemcpyAsync(outf + out_n, wavout + g.t_pad_tgt, (size_t)keep_n * sizeof(float),
-                            hipMemcpyDeviceToDevice, s));
-    out_n += keep_n;
-    if (stage_ms) {
-      RVCX_HIP(hipStreamSynchronize(s));
-      t_hub += clk.between(h0, h1);
-      t_idx += clk.between(h1, h2);
-      for (int i = 0; i < 3; ++i) t_syn[i] += ms3[i];
-    }
-    A.reset(mk);   // stream-ordered reuse: later launches on the same stream see the finished chunk
+
+  const int e_begin = clk.mark(s);
+  float t_hp = 0, t_f0 = 0, t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0}, t_post = 0;
+  struct Span {
+    int a, b;
+    float* acc;
+  };
+  std::vector<Span> spans;
+  std::vector<std::array<hipEvent_t, 4>> syn_ev;   // synth_forward's own stage events (resolved after the final sync)
+
+  {
+    const int h0 = clk.mark(sf);
+    front(0);
+    spans.push_back({h0, clk.mark(sf), &t_hp});
   }
-  const int e3 = clk.mark(s);
-  // ---- 5. RMS envelope, peak normalise, int16 (pipeline.py:449-461)
-  if (p.volume_envelope != 1.f) {
-    const int tgt = M.cfg.sr;
-    const int f1 = 16000 / 2 * 2, h1 = 16000 / 2, f2 = tgt / 2 * 2, h2 = tgt / 2;
-    const int n1 = (int)(1 + (n + 2 * (f1 / 2) - f1) / h1), n2 = (int)(1 + (out_n + 2 * (f2 / 2) - f2) / h2);
-    float* r1 = A.alloc<float>((size_t)n1);
-    float* r2 = A.alloc<float>((size_t)n2);
-    hipLaunchKernelGGL(frame_rms_kernel<double>, dim3(n1), dim3(256), 0, s, a64, r1, n, f1, h1, n1);
-    hipLaunchKernelGGL(frame_rms_kernel<float>, dim3(n2), dim3(256), 0, s, outf, r2, out_n, f2, h2, n2);
-    hipLaunchKernelGGL(envelope_kernel, dim3((unsigned)std::min<long>(cdiv64(out_n, 256), 65535)), dim3(256), 0, s,
-                       outf, r1, n1, r2, n2, out_n, p.volume_envelope);
+  const bool use_protect = p.protect < 0.5f;
+  const bool use_index = c.index && p.index_rate != 0.f;
+  for (int k = 0; k < (int)mbs.size(); ++k) {
+    const MB& mb = mbs[k];
+    const int Bm = mb.count;
+    A.reset(work_mark);
+    if (sf != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_front[k & 1], 0));   // apad of this micro-batch is ready
+    // ---- jobs of this micro-batch, grouped by chunk length (order of first appearance)
+    std::vector<Job> jobs;
+    for (int b = 0; b < Bm; ++b) {
+      Utt& u = utts[order[mb.first + b]];
+      long out_off = 0, noise_off = 0;
+      for (size_t ci = 0; ci < u.plan.size(); ++ci) {
+        const Chunk& ch = u.plan[ci];
+        const long ns = ch.e - ch.s;
+        const int Th = hubert_frames(*c.hubert, ns);
+        const int T = (int)std::min<long>(ns / 160, 2L * Th);
+        RVCX_CHECK(Th > 0 && T > 0, "convert: chunk too short");
+        RVCX_CHECK((long)T * M.upp > 2 * g.t_pad_tgt, "convert: chunk shorter than its padding");
+        jobs.push_back({b, (int)ci, ch.s, ch.e, ch.f0_off, out_off, noise_off, Th, T});
+        out_off += (long)T * M.upp - 2 * g.t_pad_tgt;
+        noise_off += (long)T * (inter + M.upp);
+      }
+      RVCX_CHECK(out_off <= u.cap, "convert: output capacity exceeded");
+      RVCX_CHECK(!u.noise || noise_off <= u.noise_cap, "convert: parity noise buffer shorter than the chunk plan needs");
+      u.out_n = out_off;
+    }
+    std::vector<std::vector<int>> groups;
+    for (int j = 0; j < (int)jobs.size(); ++j) {
+      size_t gi = 0;
+      for (; gi < groups.size(); ++gi)
+        if (jobs[groups[gi][0]].e - jobs[groups[gi][0]].s == jobs[j].e - jobs[j].s) break;
+      if (gi == groups.size()) groups.emplace_back();
+      groups[gi].push_back(j);
+    }
+    bool joined = false, f0_enqueued = false;
+    const std::function<void()> after_extractor = [&]() {
+      // One host thread feeds both branches: RMVPE's small launches are enqueued right after the first HuBERT conv
+      // extractor of the micro-batch (long kernels), otherwise HuBERT would idle while the host enqueues RMVPE.
+      if (f0_enqueued) return;
+      f0_enqueued = true;
+      enqueue_f0(k);
+    };
+    for (const auto& grp : groups) {
+      const size_t mk = A.mark();
+      const int G = (int)grp.size();
+      const Job& j0 = jobs[grp[0]];
+      const long ns = j0.e - j0.s;
+      const int Th = j0.Th, T = j0.T;
+      const size_t nz = (size_t)inter * T, nsrc = (size_t)T * M.upp;
+      // chunk audio (G, ns): strided view of apad when the items are consecutive utterances cut at the same place
+      const float* wav = utts[order[mb.first + j0.u]].apad + j0.s;
+      long wav_bs = ns;
+      bool uniform = true;
+      for (int q = 1; q < G; ++q) uniform &= jobs[grp[q]].s == j0.s && jobs[grp[q]].u == j0.u + q;
+      if (G > 1 && uniform) {
+        wav_bs = utts[order[mb.first + j0.u]].n_pad;
+      } else if (G > 1) {
+        float* wg = A.alloc<float>((size_t)G * ns);
+        for (int q = 0; q < G; ++q)
+          RVCX_HIP(hipMemcpyAsync(wg + (size_t)q * ns, utts[order[mb.first + jobs[grp[q]].u]].apad + jobs[grp[q]].s,
+                                  (size_t)ns * 4, hipMemcpyDeviceToDevice, s));
+        wav = wg;
+      }
+      const int h0 = clk.mark(s);
+      float* feats = A.alloc<float>((size_t)G * E * Th);
+      {
+        const size_t mk2 = A.mark();
+        hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;
+        if (sh != s) {
+          RVCX_HIP(hipEventRecord(c.ev_hub, s));
+          RVCX_HIP(hipStreamWaitEvent(sh, c.ev_hub, 0));
+        }
+        hubert_forward(c, *c.hubert, G, wav, ns, 12, feats, sh, &after_extractor, wav_bs);
+        if (sh != s) {
+          RVCX_HIP(hipEventRecord(c.ev_hub, sh));
+          RVCX_HIP(hipStreamWaitEvent(s, c.ev_hub, 0));
+        }
+        A.reset(mk2);
+      }
+      const int h1 = clk.mark(s);
+      spans.push_back({h0, h1, &t_hub});
+      const float* feats0 = feats;
+      if (use_index) {
+        if (use_protect) {
+          float* keep = A.alloc<float>((size_t)G * E * Th);
+          RVCX_HIP(hipMemcpyAsync(keep, feats, (size_t)G * E * Th * sizeof(float), hipMemcpyDeviceToDevice, s));
+          feats0 = keep;
+        }
+        for (int q = 0; q < G; ++q) {
+          const size_t mk2 = A.mark();
+          index_blend(c, *c.index, feats + (size_t)q * E * Th, Th, p.index_rate, nullptr, nullptr, s);
+          A.reset(mk2);
+        }
+      }
+      const int h2 = clk.mark(s);
+      spans.push_back({h1, h2, &t_idx});
+      if (!joined) {   // first consumer of f0 / coarse
+        if (!f0_enqueued) after_extractor();
+        if (sf != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
+        joined = true;
+      }
+      float* phone = A.alloc<float>((size_t)G * E * T);
+      int* pitch = A.alloc<int>((size_t)G * T);
+      float* pitchf = A.alloc<float>((size_t)G * T);
+      float* zn = A.alloc<float>((size_t)G * nz);
+      float* sn = A.alloc<float>((size_t)G * nsrc);
+      std::vector<int> sids(G, p.sid);
+      for (int q = 0; q < G; ++q) {
+        const Job& j = jobs[grp[q]];
+        const Utt& u = utts[order[mb.first + j.u]];
+        launch_upsample_protect(feats + (size_t)q * E * Th, feats0 + (size_t)q * E * Th, u.f0 + j.f0_off,
+                                phone + (size_t)q * E * T, E, Th, T, p.protect, use_protect ? 1 : 0, s);
+        RVCX_HIP(hipMemcpyAsync(pitch + (size_t)q * T, u.coarse + j.f0_off, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
+        RVCX_HIP(hipMemcpyAsync(pitchf + (size_t)q * T, u.f0 + j.f0_off, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
+        // noise: parity = packed [z (inter*T) | src (T*upp)] per chunk in draw order; else Philox with the
+        // utterance's own stream (seed + position in the call) so that a batch item equals its single run
+        if (u.noise) {
+          RVCX_HIP(hipMemcpyAsync(zn + (size_t)q * nz, u.noise + j.noise_off, nz * 4, hipMemcpyDeviceToDevice, s));
+          RVCX_HIP(hipMemcpyAsync(sn + (size_t)q * nsrc, u.noise + j.noise_off + nz, nsrc * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+          const uint64_t seed = p.seed + (uint64_t)ios[u.io].seed_offset;
+          const uint64_t off = (uint64_t)j.ci << 36;
+          launch_randn(zn + (size_t)q * nz, nz, seed, off, s);
+          launch_randn(sn + (size_t)q * nsrc, nsrc, seed, off + ((uint64_t)1 << 35), s);
+        }
+      }
+      float* wavout = A.alloc<float>((size_t)G * nsrc);
+      SynthIO io;
+      io.B = G;
+      io.T = T;
+      io.phone_ct = phone;
+      io.pitch = pitch;
+      io.pitchf = pitchf;
+      io.sid_host = sids.data();
+      io.z_noise = zn;
+      io.src_noise = sn;
+      io.out = wavout;
+      if (stage_ms) {
+        syn_ev.emplace_back();
+        for (auto& e : syn_ev.back()) RVCX_HIP(hipEventCreate(&e));
+      }
+      synth_forward(c, M, io, stage_ms ? syn_ev.back().data() : nullptr);
+      const long keep_n = (long)nsrc - 2 * g.t_pad_tgt;
+      for (int q = 0; q < G; ++q) {
+        const Job& j = jobs[grp[q]];
+        const Utt& u = utts[order[mb.first + j.u]];
+        RVCX_HIP(hipMemcpyAsync(u.outf + j.out_off, wavout + (size_t)q * nsrc + g.t_pad_tgt, (size_t)keep_n * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+      }
+      A.reset(mk);   // stream-ordered reuse: later launches on the same stream see the finished group
+    }
+    // ---- RMS envelope, peak normalise, int16 (pipeline.py:449-461), then the PCM leaves on the copy stream
+    const int e3 = clk.mark(s);
+    for (int b = 0; b < Bm; ++b) {
+      Utt& u = utts[order[mb.first + b]];
+      const size_t mk = A.mark();
+      if (p.volume_envelope != 1.f) {
+        const int tgt = M.cfg.sr;
+        const int f1 = 16000 / 2 * 2, h1 = 16000 / 2, f2 = tgt / 2 * 2, h2 = tgt / 2;
+        const int n1 = (int)(1 + (u.n + 2 * (f1 / 2) - f1) / h1), n2 = (int)(1 + (u.out_n + 2 * (f2 / 2) - f2) / h2);
+        float* r1 = A.alloc<float>((size_t)n1);
+        float* r2 = A.alloc<float>((size_t)n2);
+        hipLaunchKernelGGL(frame_rms_kernel<double>, dim3(n1), dim3(256), 0, s, u.a64, r1, u.n, f1, h1, n1);
+        hipLaunchKernelGGL(frame_rms_kernel<float>, dim3(n2), dim3(256), 0, s, u.outf, r2, u.out_n, f2, h2, n2);
+        hipLaunchKernelGGL(envelope_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 65535)), dim3(256), 0, s,
+                           u.outf, r1, n1, r2, n2, u.out_n, p.volume_envelope);
+      }
+      unsigned int* amax = A.alloc<unsigned int>(1);
+      RVCX_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned int), s));
+      hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 1024)), dim3(256), 0, s, u.outf,
+                         u.out_n, amax);
+      hipLaunchKernelGGL(to_int16_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 65535)), dim3(256), 0, s,
+                         u.outf, u.pcm, u.out_n, amax);
+      (void)mk;   // amax / rms buffers stay allocated until the micro-batch's work area is reset
+    }
+    RVCX_HIP(hipGetLastError());
+    const int e4 = clk.mark(s);
+    spans.push_back({e3, e4, &t_post});
+    if (sio != s) {
+      RVCX_HIP(hipEventRecord(c.ev_io, s));
+      RVCX_HIP(hipStreamWaitEvent(sio, c.ev_io, 0));
+    }
+    for (int b = 0; b < Bm; ++b) {
+      Utt& u = utts[order[mb.first + b]];
+      UttIO& io = ios[u.io];
+      RVCX_HIP(hipMemcpyAsync(io.out, u.pcm, (size_t)u.out_n * sizeof(short), hipMemcpyDefault, sio));
+      if (io.out_f32) RVCX_HIP(hipMemcpyAsync(io.out_f32, u.outf, (size_t)u.out_n * sizeof(float), hipMemcpyDefault, sio));
+      io.out_n = u.out_n;
+    }
+    if (sf != s) RVCX_HIP(hipEventRecord(c.ev_done[k & 1], s));
+    // ---- front end of the next micro-batch (the main stream still has this one's synthesizer queued)
+    if (k + 1 < (int)mbs.size()) {
+      const int h0 = clk.mark(sf);
+      front(k + 1);
+      spans.push_back({h0, clk.mark(sf), &t_hp});
+    }
   }
-  unsigned int* amax = A.alloc<unsigned int>(1);
-  RVCX_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>(cdiv64(out_n, 256), 1024)), dim3(256), 0, s, outf,
-                     out_n, amax);
-  hipLaunchKernelGGL(to_int16_kernel, dim3((unsigned)std::min<long>(cdiv64(out_n, 256), 65535)), dim3(256), 0, s,
-                     outf, out_pcm, out_n, amax);
-  const int e4 = clk.mark(s);
-  RVCX_HIP(hipGetLastError());
+  const int e_end = clk.mark(s);
+  RVCX_HIP(hipStreamSynchronize(s));
+  if (sf != s) RVCX_HIP(hipStreamSynchronize(sf));
+  if (sio != s) RVCX_HIP(hipStreamSynchronize(sio));
   if (stage_ms) {
-    RVCX_HIP(hipStreamSynchronize(s));
-    stage_ms[0] = clk.between(e0, e1);
-    stage_ms[1] = r0 >= 0 ? clk.between(r0, r1) : 0.f;   // on stream2, overlapped with the HuBERT stage
+    for (const auto& sp : spans) *sp.acc += clk.between(sp.a, sp.b);
+    for (size_t k = 0; k < mbs.size(); ++k) t_f0 += clk.between(f0_ev0[k], f0_ev1[k]);
+    for (auto& ev : syn_ev) {
+      for (int i = 0; i < 3; ++i) {
+        float t = 0.f;
+        RVCX_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+        t_syn[i] += t;
+      }
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    stage_ms[0] = t_hp;
+    stage_ms[1] = t_f0;     // on the front stream, overlapped with HuBERT / the previous micro-batch's decoder
     stage_ms[2] = t_hub;
     stage_ms[3] = t_idx;
     stage_ms[4] = t_syn[0];
     stage_ms[5] = t_syn[1];
     stage_ms[6] = t_syn[2];
-    stage_ms[7] = clk.between(e3, e4);
-    stage_ms[8] = clk.between(e0, e4);
+    stage_ms[7] = t_post;
+    stage_ms[8] = clk.between(e_begin, e_end);
   }
-  return out_n;
 }
 
 }  // namespace rvcx

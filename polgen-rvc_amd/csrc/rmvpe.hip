@@ -97,6 +97,7 @@ RmvpeModel::Block load_block(Ctx& c, const TensorTable& t, const std::string& p)
 
 std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const TensorTable& t) {
   auto M = std::make_unique<RmvpeModel>();
+  RegionScope scope(c, *M->region);
   M->cfg = cfg;
   {
     // The strided STFT conv (Cin=1, k=1024, stride 160) is re-indexed k = 160*a + r so that it
@@ -176,6 +177,7 @@ std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const 
     const auto shp = t.shape("fc.1.weight");
     M->fc = make_conv(c, w.data(), b.data(), (int)shp[0], (int)shp[1], 1, 1);
   }
+  M->region->seal();
   return M;
 }
 

@@ -55,6 +55,7 @@ static ConvW load_conv(Ctx& c, const TensorTable& t, const std::string& p, bool 
 
 std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const TensorTable& t) {
   auto M = std::make_unique<SynthModel>();
+  RegionScope scope(c, *M->region);
   M->cfg = cfg;
   M->upp = 1;
   for (int i = 0; i < cfg.n_ups; ++i) M->upp *= cfg.up_rates[i];
@@ -136,6 +137,7 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
     ch = co;
   }
   M->emb_g = c.slab.upload(t.f32("emb_g.weight"));
+  M->region->seal();
   return M;
 }
 
@@ -157,22 +159,12 @@ size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
 
 namespace {
 
-struct Timer3 {
+struct Timer3 {      // records the caller's 4 stage events on the main stream; never synchronises
   Ctx& c;
-  float* ms;
-  hipEvent_t e[4];
-  Timer3(Ctx& cc, float* m) : c(cc), ms(m) {
-    if (ms)
-      for (auto& x : e) RVCX_HIP(hipEventCreate(&x));
-  }
+  hipEvent_t* e;
+  Timer3(Ctx& cc, hipEvent_t* ev) : c(cc), e(ev) {}
   void mark(int i) {
-    if (ms) RVCX_HIP(hipEventRecord(e[i], c.stream));
-  }
-  void finish() {
-    if (!ms) return;
-    RVCX_HIP(hipEventSynchronize(e[3]));
-    for (int i = 0; i < 3; ++i) RVCX_HIP(hipEventElapsedTime(&ms[i], e[i], e[i + 1]));
-    for (auto& x : e) (void)hipEventDestroy(x);
+    if (e) RVCX_HIP(hipEventRecord(e[i], c.stream));
   }
 };
 
@@ -184,13 +176,13 @@ int* upload_ints(Ctx& c, const std::vector<int>& v) {
 
 }  // namespace
 
-void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_ms) {
+void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* stage_ev) {
   const auto& cf = m.cfg;
   const int B = io.B, T = io.T, hid = cf.hidden_channels, inter = cf.inter_channels, filt = cf.filter_channels;
   const int heads = cf.n_heads, kc = hid / heads, half = inter / 2, gin = cf.gin_channels;
   hipStream_t s = c.stream;
   Arena& A = c.arena;
-  Timer3 tm(c, stage_ms);
+  Timer3 tm(c, stage_ev);
   tm.mark(0);
 
   // per-stage valid lengths (ragged batches); null when every item spans the full T
@@ -439,7 +431,6 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, float* stage_
     c.conv(a);
   }
   tm.mark(3);
-  tm.finish();
 }
 
 }  // namespace rvcx

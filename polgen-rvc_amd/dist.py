@@ -43,38 +43,57 @@ def broadcast_tensor(t: torch.Tensor, src: int = 0) -> torch.Tensor:
     return t
 
 
-_hip = None
+class _DevBytes:
+    """zero-copy uint8 view of raw device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def _hip_memcpy_d2d(dst: int, src: int, n: int):
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-    rc = _hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(n), 3)
-    if rc != 0:
-        raise RuntimeError(f"hipMemcpy D2D failed: {rc}")
+def _view(ptr: int, nbytes: int, dev) -> torch.Tensor:
+    """uint8 tensor aliasing [ptr, ptr + nbytes): device memory under nccl, host memory under gloo."""
+    if dev.type == "cuda":
+        return torch.as_tensor(_DevBytes(ptr, nbytes), device=dev)
+    import numpy as np
+    return torch.from_numpy(np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(ptr)))
 
 
-def broadcast_weights(ctx, device_index: int, src: int = 0) -> int:
-    """RCCL-broadcast the contiguous folded-weight slab of ``ctx`` from rank ``src``.  Every rank must
-    have loaded models with identical layouts (non-source ranks may load zero-filled tensors).
+def broadcast_weights(ctx, device_index: int = 0, src: int = 0) -> int:
+    """Broadcast the folded weights of ``ctx`` from rank ``src`` (RCCL over xGMI under backend "nccl"): every
+    chunk of every weight region (``ctx.weights_regions()``) is broadcast in place, then ``ctx.weights_adopt()``
+    re-reads the value-dependent layer flags that travel in the region headers.
+
+    Every rank must have loaded the same model configurations -- non-source ranks with placeholder (zero)
+    tensors.  The layouts are compared first (shape-only hash + chunk sizes, all ranks gather all ranks'
+    signatures), so a mismatch raises on EVERY rank instead of leaving rank ``src`` blocked in the collective.
     Returns the number of bytes broadcast."""
-    ptr, nbytes = ctx.weights_blob()
+    regions, layout = ctx.weights_regions()
+    nbytes = sum(n for _, n in regions)
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return nbytes
-    dev = torch.device("cuda", device_index)
-    sizes = torch.tensor([nbytes], dtype=torch.int64, device=dev)
-    dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
-    if int(sizes.item()) != nbytes:
-        raise RuntimeError("weight slab layouts differ across ranks")
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if dist.get_rank() == src:
-        _hip_memcpy_d2d(buf.data_ptr(), ptr, nbytes)
-    torch.cuda.synchronize(dev)
-    dist.broadcast(buf, src)
-    torch.cuda.synchronize(dev)
-    if dist.get_rank() != src:
-        _hip_memcpy_d2d(ptr, buf.data_ptr(), nbytes)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")
+    sizes_hash = 1469598103934665603
+    for _, n in regions:
+        sizes_hash = ((sizes_hash ^ n) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    sig = torch.tensor([layout & 0xFFFFFFFF, layout >> 32, sizes_hash & 0xFFFFFFFF, sizes_hash >> 32, len(regions),
+                        nbytes], dtype=torch.int64, device=dev)
+    sigs = [torch.empty_like(sig) for _ in range(dist.get_world_size())]
+    dist.all_gather(sigs, sig)
+    mine = sig.cpu().tolist()
+    bad = [r for r, t in enumerate(sigs) if t.cpu().tolist() != sigs[src].cpu().tolist()]
+    if bad:
+        raise RuntimeError(f"weight layouts differ across ranks (ranks {bad} disagree with rank {src}; this rank: "
+                           f"{len(regions)} chunks, {nbytes} bytes, hash {layout:#x}): load the same model "
+                           f"configurations on every rank before broadcasting ({mine})")
+    for ptr, n in regions:
+        if n == 0:
+            continue
+        t = _view(ptr, n, dev)
+        dist.broadcast(t, src)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
+    ctx.weights_adopt()
     return nbytes
 
 

@@ -12,45 +12,24 @@ import numpy as np
 from .. import _lib, weights
 from .pipeline import VC
 
-_CTX = {}
+from . import _state
+from ._state import _CTX, _RESIDENT, _SYNTHS   # noqa: F401  (tests reach in)
 
 # ---- resident-asset cache -------------------------------------------------------------
 # The reference's scripts reload HuBERT, the voice model and RMVPE on every request
 # (rvc/scripts/voice_conversion.py:71-75,98-100).  Here a checkpoint path that was loaded before, and whose
 # (realpath, mtime, size) has not changed, maps to the models already folded and resident in HBM.
-_RESIDENT = {}            # (device index, kind) -> (file key, handle)      kind in {"hubert", "rmvpe"}
-_SYNTHS = {}              # (device index, file key) -> (light cpt, SynthHandle); insertion order = LRU order
-MAX_RESIDENT_SYNTHS = 8   # voice models kept per process (a 48 k model is ~115 MB of folded fp32 weights)
+MAX_RESIDENT_SYNTHS = 8   # voice models kept per process (a 48 k model is ~230 MB of folded weights incl. fp16 images)
 
-
-def _file_key(path):
-    import os
-    st = os.stat(path)
-    return (os.path.realpath(path), st.st_mtime_ns, st.st_size)
-
-
-def _dev_index(device) -> int:
-    if isinstance(device, str) and ":" in device:
-        return int(device.split(":")[1])
-    return device if isinstance(device, int) else 0
+_file_key = _state.file_key
+_dev_index = _state.dev_index
+_context = _state.context
 
 
 def clear_cache():
     """Drop every cached handle (voice models are unloaded once their callers released them too)."""
     _RESIDENT.clear()
     _SYNTHS.clear()
-
-
-def _context(device) -> "_lib.Context":
-    """One rvcx context per GPU, created on first use."""
-    idx = 0
-    if isinstance(device, str) and ":" in device:
-        idx = int(device.split(":")[1])
-    elif isinstance(device, int):
-        idx = device
-    if idx not in _CTX:
-        _CTX[idx] = _lib.Context(idx)
-    return _CTX[idx]
 
 
 class Config:
@@ -99,7 +78,7 @@ def load_hubert(device, is_half, model_path, state=None, cfg=None):
             return _RESIDENT[slot][1]
         from ..ckpt_io import load_fairseq_hubert
         state = load_fairseq_hubert(model_path)
-    cfg = cfg or synthetic.HUBERT_CFG_BASE
+    cfg = cfg or weights.hubert_cfg_from_state(state)
     ctx.load_hubert(weights.hubert_cfg_struct(cfg), state)
     handle = HubertHandle(ctx, cfg)
     _RESIDENT.pop(slot, None)
@@ -116,10 +95,11 @@ def load_rmvpe(device, model_path=None, state=None, cfg=None):
     slot, key = (_dev_index(device), "rmvpe"), None
     if state is None:
         key = _file_key(model_path)
-        if slot in _RESIDENT and _RESIDENT[slot][0] == key:
+        if slot in _RESIDENT and _RESIDENT[slot][0] == key and getattr(ctx, "rmvpe_loaded", False):
             return
         state = _torch_load(model_path)
-    ctx.load_rmvpe(weights.rmvpe_cfg_struct(cfg or synthetic.RMVPE_CFG_FULL), state)
+    ctx.load_rmvpe(weights.rmvpe_cfg_struct(cfg or weights.rmvpe_cfg_from_state(state)), state)
+    ctx.rmvpe_loaded = True
     _RESIDENT.pop(slot, None)
     if key is not None:
         _RESIDENT[slot] = (key, True)

@@ -6,7 +6,10 @@ Differences that are deliberate and documented:
   * ``f0_method``: only "rmvpe+" (and its BASELINE alias "rmvpe") is implemented; anything else
     raises ValueError (the reference hits an accidental UnboundLocalError, pipeline.py:152-183).
   * ``filter_radius`` / ``hop_length`` are accepted and unused, as in the reference for rmvpe+.
-  * ``model`` / ``net_g`` are opaque handles (``HubertHandle`` / ``SynthHandle`` from .infer).
+  * ``model`` / ``net_g`` are opaque handles (``HubertHandle`` / ``SynthHandle`` from .infer); ``index`` is
+    the handle ``_load_index`` returns (the vectors live in HBM), ``big_npy`` the matrix or ``True``.
+  * keyword-only extras after the reference's parameters (``noise`` / ``z_noise`` / ``src_noise`` replace the
+    two ``randn_like`` draws for parity runs; ``return_f32``) never change positional calls.
 """
 from __future__ import annotations
 
@@ -15,10 +18,28 @@ import os
 import numpy as np
 
 from .. import _lib
+from . import _state
+from ._state import _INDEX_RESIDENT
 
-_INDEX_RESIDENT = {}   # id(context) -> (realpath, mtime_ns, size) of the FAISS index whose vectors are in HBM
+# rvc/infer/pipeline.py:14-16 -- resolved against the working directory at import, like the reference
+RMVPE_DIR = os.path.join(os.getcwd(), "rvc", "models", "predictors", "rmvpe.pt")
 
 F0_METHODS = ("rmvpe+", "rmvpe")
+
+
+def _np(a, dtype=None):
+    """numpy view of numpy / torch / list input (torch tensors may live on any device)."""
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    a = np.asarray(a)
+    return a if dtype is None else a.astype(dtype, copy=False)
+
+
+class IndexHandle:
+    """Stands for ``faiss.read_index(file_index)``: the stored vectors are resident in the context."""
+
+    def __init__(self, ctx, key, ntotal, dim):
+        self.ctx, self.key, self.ntotal, self.d = ctx, key, ntotal, dim
 
 
 class VC:
@@ -40,16 +61,19 @@ class VC:
         self.time_step = self.window / self.sample_rate * 1000
         self.device = config.device
         self.tgt_sr = tgt_sr
-        self.seed = 0
+        self.seed = None        # None: fresh Philox seed per call (the reference uses torch's global RNG)
 
     # ------------------------------------------------------------------------------------
+    def _ctx(self):
+        return _state.context(self.device)
+
     def _params(self, pitch, index_rate, volume_envelope, protect, f0_min, f0_max, sid=0):
         p = _lib.Params()
         p.pitch, p.f0_min, p.f0_max = float(pitch), float(f0_min), float(f0_max)
         p.index_rate, p.protect, p.volume_envelope = float(index_rate), float(protect), float(volume_envelope)
         p.sid = int(sid)
         p.x_pad, p.x_query, p.x_center, p.x_max = self.x_pad, self.x_query, self.x_center, self.x_max
-        p.seed = int(self.seed)
+        p.seed = _state.next_seed() if self.seed is None else int(self.seed)
         return p
 
     @staticmethod
@@ -57,60 +81,153 @@ class VC:
         if f0_method not in F0_METHODS:
             raise ValueError(f"f0_method={f0_method!r} is not implemented by rvcx (supported: {F0_METHODS})")
 
+    def _ensure_rmvpe(self, ctx=None):
+        """pipeline.py:123-126: the predictor is created on first use from rvc/models/predictors/rmvpe.pt."""
+        ctx = ctx or self._ctx()
+        if not getattr(ctx, "rmvpe_loaded", False):
+            from . import infer
+            infer.load_rmvpe(self.device, RMVPE_DIR)
+        self.model_rmvpe = True
+        return ctx
+
+    # ------------------------------------------------------------------------------------
+    def get_f0_crepe(self, x, f0_min, f0_max, p_len, hop_length, model="full"):
+        """pipeline.py:86-117 (torchcrepe): not on the north-star path."""
+        raise ValueError("f0_method='mangio-crepe' is not implemented by rvcx (SURVEY.md §8 f4)")
+
+    def get_f0_rmvpe(self, x, f0_min=1, f0_max=40000, *args, **kwargs):
+        """pipeline.py:119-130 -> f0 in Hz, 1 + len(x)//160 frames; out-of-range frames are 0 (rmvpe+)."""
+        ctx = self._ensure_rmvpe()
+        f0 = ctx.rmvpe_f0(_np(x, np.float32), 0.03, f0_min, f0_max)[0]
+        return f0.astype(np.float64)
+
     def get_f0(self, input_audio_path, x, p_len, pitch, f0_method, filter_radius, hop_length, inp_f0=None,
-               f0_min=50, f0_max=1100, ctx=None):
-        """pipeline.py:132-201.  ``x`` is the reflect-padded, high-passed signal in the reference; here
-        the un-padded 16 kHz clip is passed and the library pads/filters it (rvcx_get_f0)."""
+               f0_min=50, f0_max=1100):
+        """pipeline.py:132-201.  ``x`` is the reflect-padded, high-passed signal, as in the reference; returns
+        (f0_coarse int array, f0 float array) of 1 + len(x)//160 frames (the caller truncates to p_len)."""
         self._check_method(f0_method)
-        if inp_f0 is not None:
-            raise ValueError("f0 files are not supported (the reference's rvc_infer always passes None)")
-        coarse, f0 = ctx.get_f0(np.asarray(x, np.float32), self._params(pitch, 0, 1, 0.5, f0_min, f0_max))
-        return coarse[:p_len], f0[:p_len]
+        ctx = self._ensure_rmvpe()
+        x = _np(x, np.float32)
+        if inp_f0 is None:
+            coarse, f0 = ctx.get_f0_x(x, self._params(pitch, 0, 1, 0.5, f0_min, f0_max))
+            return coarse.astype(np.int64), f0.astype(np.float64)
+        # f0 file (pipeline.py:185-191): the estimate is patched on the host, then quantised exactly as the
+        # reference does (numpy float64).  rvc_infer never takes this branch (f0_file=None, infer.py:149).
+        f0 = self.get_f0_rmvpe(x, f0_min=f0_min, f0_max=f0_max)
+        f0 *= pow(2, pitch / 12)
+        tf0 = self.sample_rate // self.window
+        inp_f0 = np.asarray(inp_f0, dtype=np.float64)
+        delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
+        replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
+        shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
+        f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
+        f0_mel_min = 1127 * np.log(1 + f0_min / 700)
+        f0_mel_max = 1127 * np.log(1 + f0_max / 700)
+        f0bak = f0.copy()
+        f0_mel = 1127 * np.log(1 + f0 / 700)
+        f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - f0_mel_min) * 254 / (f0_mel_max - f0_mel_min) + 1
+        f0_mel[f0_mel <= 1] = 1
+        f0_mel[f0_mel > 255] = 255
+        return np.rint(f0_mel).astype(int), f0bak
+
+    def vc(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect, *,
+           z_noise=None, src_noise=None):
+        """pipeline.py:203-287: one chunk of audio_pad -> np.float32 waveform (un-trimmed)."""
+        if version != "v2":
+            raise ValueError("only RVC v2 voice models are supported")
+        if pitch is None or pitchf is None:
+            raise ValueError("non-f0 models cannot run in the reference either (generators.py:57-77)")
+        ctx = net_g.ctx
+        if model.ctx is not ctx:
+            raise ValueError("hubert and voice model live on different rvcx contexts")
+        rate = 0.0
+        if index is not None and big_npy is not None and index_rate != 0:
+            self._make_resident(ctx, index, big_npy)
+            rate = float(index_rate)
+        audio0 = _np(audio0)
+        if audio0.ndim == 2:
+            audio0 = audio0.mean(-1)
+        sid = int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid
+        seed = _state.next_seed() if self.seed is None else int(self.seed)
+        return ctx.vc(net_g.model_id, audio0.astype(np.float32), _np(pitch).ravel(), _np(pitchf).ravel(), sid, rate,
+                      float(protect), z_noise, src_noise, seed)
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _make_resident(ctx, index, big_npy):
+        """vc() was handed an index the context may not hold (callers other than pipeline())."""
+        key = index.key if isinstance(index, IndexHandle) else ("array", id(big_npy))
+        if _INDEX_RESIDENT.get(id(ctx)) == key:
+            return
+        if isinstance(big_npy, np.ndarray):
+            ctx.load_index(big_npy)
+            _INDEX_RESIDENT[id(ctx)] = key
+        else:
+            raise ValueError("index vectors are not resident in this context and no matrix was given")
 
     def _load_index(self, ctx, file_index, index_rate):
-        """pipeline.py:315-328: index + big_npy, failures swallowed (print, continue without index)."""
+        """pipeline.py:315-328: index + big_npy, failures swallowed (print, continue without index).
+        Returns (index handle, big_npy stand-in) or (None, None)."""
         # residency is per context (a new VC is built per request): keyed by (realpath, mtime, size)
         if not (file_index is not None and file_index != "" and os.path.exists(file_index) and index_rate != 0):
             if _INDEX_RESIDENT.get(id(ctx)) is not None:
                 ctx.load_index(None)
                 _INDEX_RESIDENT[id(ctx)] = None
-            return
+            return None, None
         try:
-            st = os.stat(file_index)
-            key = (os.path.realpath(file_index), st.st_mtime_ns, st.st_size)
-            if _INDEX_RESIDENT.get(id(ctx)) == key:
-                return
-            from ..index_io import read_index_vectors
-            big_npy = read_index_vectors(file_index)
-            ctx.load_index(big_npy)
-            _INDEX_RESIDENT[id(ctx)] = key
+            key = _state.file_key(file_index)
+            if _INDEX_RESIDENT.get(id(ctx)) != key:
+                from ..index_io import read_index_vectors
+                big_npy = read_index_vectors(file_index)
+                ctx.load_index(big_npy)
+                _INDEX_RESIDENT[id(ctx)] = key
+                ctx._index_shape = big_npy.shape
+            n, d = getattr(ctx, "_index_shape", (0, 0))
+            return IndexHandle(ctx, key, n, d), True
         except Exception as e:  # noqa: BLE001 -- same degrade-to-None behaviour as the reference
             print(f"Error reading the FAISS index: {e}")
             ctx.load_index(None)
             _INDEX_RESIDENT[id(ctx)] = None
+            return None, None
 
     def pipeline(self, model, net_g, sid, audio, input_audio_path, pitch, f0_method, file_index, index_rate,
                  pitch_guidance, filter_radius, tgt_sr, resample_sr, volume_envelope, version, protect,
-                 hop_length, f0_file, f0_min=50, f0_max=1100, noise=None, return_f32=False):
+                 hop_length, f0_file, f0_min=50, f0_max=1100, *, noise=None, return_f32=False):
         """pipeline.py:289-467 -> np.ndarray[int16]."""
+        if noise is None:
+            noise = getattr(self, "parity_noise", None)      # test hook for callers that cannot pass `noise`
+        return self.pipeline_batch(model, net_g, sid, [audio], pitch, f0_method, file_index, index_rate,
+                                   pitch_guidance, tgt_sr, resample_sr, volume_envelope, version, protect, f0_file,
+                                   f0_min, f0_max, noise=None if noise is None else [noise],
+                                   return_f32=return_f32, _single=True)
+
+    def pipeline_batch(self, model, net_g, sid, audios, pitch, f0_method, file_index, index_rate, pitch_guidance,
+                       tgt_sr, resample_sr, volume_envelope, version, protect, f0_file=None, f0_min=50, f0_max=1100,
+                       *, noise=None, return_f32=False, _single=False):
+        """VC.pipeline over a list of utterances in one call (the reference lists batch conversion as not
+        done, TODO.md:11): equal-length clips run through the networks together."""
         self._check_method(f0_method)
         if not pitch_guidance:
             raise ValueError("non-f0 models cannot run in the reference either (generators.py:57-77)")
         if version != "v2":
             raise ValueError("only RVC v2 voice models are supported")
         if f0_file is not None:
-            raise ValueError("f0 files are not supported")
+            raise ValueError("f0 files are not supported by pipeline() (rvc_infer always passes None, infer.py:149); "
+                             "use get_f0(inp_f0=...) + vc()")
         if resample_sr >= self.sample_rate and tgt_sr != resample_sr:
             raise ValueError("resample_sr is hard-wired to 0 by rvc_infer (infer.py:144)")
         ctx = net_g.ctx
         if model.ctx is not ctx:
             raise ValueError("hubert and voice model live on different rvcx contexts")
-        self._load_index(ctx, file_index, index_rate)
-        p = self._params(pitch, index_rate if _INDEX_RESIDENT.get(id(ctx)) else 0.0, volume_envelope, protect, f0_min, f0_max,
-                         sid)
-        audio = np.asarray(audio, dtype=np.float32)
-        res = ctx.convert_batch(net_g.model_id, [audio], p, None if noise is None else [noise],
-                                want_f32=return_f32)
-        if return_f32:
-            return res[0][0], res[1][0]
-        return res[0]
+        self._ensure_rmvpe(ctx)
+        index, _ = self._load_index(ctx, file_index, index_rate)
+        p = self._params(pitch, index_rate if index is not None else 0.0, volume_envelope, protect, f0_min, f0_max,
+                         int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid)
+        # float64 stays float64 across the ABI (filtfilt then sees what the reference's sees); else float32
+        clips = [a if _np(a).dtype == np.float64 else _np(a, np.float32) for a in map(_np, audios)]
+        if not all(c.dtype == clips[0].dtype for c in clips):
+            clips = [c.astype(np.float64) for c in clips]
+        res = ctx.convert_batch(net_g.model_id, clips, p, noise, want_f32=return_f32)
+        if _single:
+            return (res[0][0], res[1][0]) if return_f32 else res[0]
+        return res

@@ -52,3 +52,40 @@ def hubert_cfg_struct(cfg: Dict) -> _lib.HubertCfg:
 def strip_enc_q(state: Dict) -> Dict:
     """get_vc deletes enc_q before loading (rvc/infer/infer.py:99-100)."""
     return {k: v for k, v in state.items() if not k.startswith("enc_q.")}
+
+
+def _shape(t):
+    return tuple(int(v) for v in t.shape)
+
+
+def hubert_cfg_from_state(state: Dict) -> Dict:
+    """HuBERT geometry read off a fairseq-named state dict (custom HuBERTs, tabs/install/install_huberts.py:11-18,
+    share the architecture but need not share the sizes).  Strides are not recoverable from weights: fairseq's
+    default extractor "[(512,10,5)] + [(512,3,2)]*4 + [(512,2,2)]*2" is assumed."""
+    convs = []
+    while f"feature_extractor.conv_layers.{len(convs)}.0.weight" in state:
+        convs.append(_shape(state[f"feature_extractor.conv_layers.{len(convs)}.0.weight"]))
+    layers = 0
+    while f"encoder.layers.{layers}.fc1.weight" in state:
+        layers += 1
+    embed = _shape(state["post_extract_proj.weight"])[0]
+    wv = _shape(state["encoder.pos_conv.0.weight_v"])
+    kernels = [c[2] for c in convs]
+    if len(kernels) != 7:
+        raise ValueError(f"unsupported HuBERT feature extractor ({len(kernels)} conv layers)")
+    return dict(conv_dim=convs[0][0], conv_kernels=kernels, conv_strides=[5, 2, 2, 2, 2, 2, 2], embed_dim=embed,
+                ffn_dim=_shape(state["encoder.layers.0.fc1.weight"])[0], heads=max(1, embed // 64), layers=layers,
+                pos_kernel=wv[2], pos_groups=embed // wv[1],
+                final_dim=_shape(state["final_proj.weight"])[0] if "final_proj.weight" in state else 256)
+
+
+def rmvpe_cfg_from_state(state: Dict) -> Dict:
+    """E2E(n_blocks, n_gru, (2,2), en_de_layers, inter_layers, 1, en_out_channels) read off rmvpe.pt's keys."""
+    def count(fmt):
+        n = 0
+        while any(k.startswith(fmt.format(n)) for k in state):
+            n += 1
+        return n
+    return dict(n_blocks=count("unet.encoder.layers.0.conv.{}."), n_gru=1,
+                en_de_layers=count("unet.encoder.layers.{}."), inter_layers=count("unet.intermediate.layers.{}."),
+                in_channels=1, en_out_channels=_shape(state["unet.encoder.layers.0.conv.0.conv.0.weight"])[0])

@@ -48,3 +48,78 @@ def test_two_rank_gloo():
     assert res[0][1] == res[1][1] == float(sum(range(1000)))
     assert sorted(res[0][2] + res[1][2]) == list(range(7))
     assert res[0][3] == res[1][3] == 2.0
+
+
+class _HostCtx:
+    """Stands in for a _lib.Context on CPU: weight chunks are host arrays, weights_regions() hands out their
+    addresses exactly like the device pointers of rvcx_weights_regions."""
+
+    def __init__(self, sizes, fill, layout):
+        import numpy as np
+        self.chunks = [np.full(n, fill, np.uint8) if fill is not None else
+                       (np.arange(n, dtype=np.int64) * (i + 3) % 251).astype(np.uint8) for i, n in enumerate(sizes)]
+        self.layout, self.adopted = layout, 0
+
+    def weights_regions(self):
+        return [(c.ctypes.data, c.nbytes) for c in self.chunks], self.layout
+
+    def weights_adopt(self):
+        self.adopted += 1
+
+
+def _bcast_worker(rank, world, port, q, mismatch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    import polgen_rvc_amd  # noqa: F401
+    from polgen_rvc_amd import dist as D
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D.init("gloo")
+    sizes = [4096, 1 << 20, 12345, 256]
+    layout = 0xDEADBEEFCAFEF00D
+    if mismatch and rank == world - 1:
+        sizes = [4096, 1 << 20, 12345 + 256, 256]        # a layer more on one rank
+    # rank 0 holds the folded weights, the others loaded placeholders (zeros)
+    ctx = _HostCtx(sizes, None if rank == 0 else 0, layout)
+    try:
+        n = D.broadcast_weights(ctx, rank, 0)
+        want = _HostCtx(sizes, None, layout)
+        ok = all(np.array_equal(a, b) for a, b in zip(ctx.chunks, want.chunks))
+        q.put((rank, "ok", n, ok, ctx.adopted))
+    except RuntimeError as e:
+        q.put((rank, "raised", str(e)[:60], False, ctx.adopted))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _run_bcast(world, mismatch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bcast_worker, args=(r, world, port, q, mismatch)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_broadcast_weights_two_and_four_ranks():
+    """dist.broadcast_weights itself (the only collective of the path): ranks that start zero-filled end equal to
+    rank 0, chunk by chunk, and re-read the region flags afterwards."""
+    for world in (2, 4):
+        res = _run_bcast(world, mismatch=False)
+        assert [r[1] for r in res] == ["ok"] * world
+        assert all(r[3] for r in res) and all(r[4] == 1 for r in res)
+        assert len({r[2] for r in res}) == 1 and res[0][2] == 4096 + (1 << 20) + 12345 + 256
+
+
+def test_broadcast_weights_layout_mismatch_fails_on_every_rank():
+    """a rank whose layout differs must make ALL ranks raise before the collective (nobody blocks in
+    dist.broadcast, nothing is scrambled)."""
+    res = _run_bcast(2, mismatch=True)
+    assert [r[1] for r in res] == ["raised", "raised"]
+    assert all(r[4] == 0 for r in res)

@@ -37,9 +37,11 @@ def test_ragged_batch_with_index_equals_single(ctx):
         clips = [S.make_clip(40, 1.7), S.make_clip(41, 5.3), S.make_clip(42, 2.9)]
         p = _params(index_rate=0.75, volume_envelope=0.25)
         batch = ctx.convert_batch(mid, clips, p)
-        assert [len(b) for b in batch] == [len(ctx.convert_batch(mid, [c], p)[0]) for c in clips]
-        for c, b in zip(clips, batch):
-            alone = ctx.convert_batch(mid, [c], p)[0]
+        # utterance i of a call draws from Philox(seed + i): its single run uses that seed
+        singles = [ctx.convert_batch(mid, [c], _params(index_rate=0.75, volume_envelope=0.25, seed=5 + i))[0]
+                   for i, c in enumerate(clips)]
+        assert [len(b) for b in batch] == [len(a) for a in singles]
+        for alone, b in zip(singles, batch):
             assert np.array_equal(alone, b)
         # the blend is live: without the index the output differs
         p0 = _params(index_rate=0.0, volume_envelope=0.25)

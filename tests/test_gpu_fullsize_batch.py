@@ -1,0 +1,163 @@
+"""BASELINE configs C3 / C5 at full model size (HuBERT-base, RMVPE E2E(4,1,(2,2)), 48 k and 40 k synthesizers):
+the micro-batched conversion path against single runs (bit-exact), the retrieval op at 65 536 x 768 against
+float64 brute force, weight regions after a simulated broadcast, and two resident voice models interleaved."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+SEED = 1900          # the C2 fixture's model seed (tests/golden/pipeline_c2_30s_48k.npz)
+
+
+@pytest.fixture(scope="module")
+def full(ctx):
+    """Full-size HuBERT + RMVPE + 48 k voice model resident in the session context."""
+    from polgen_rvc_amd import synthetic as S, weights as W
+    ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), S.hubert_state(S.HUBERT_CFG_BASE, SEED))
+    ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), S.rmvpe_state(S.RMVPE_CFG_FULL, SEED))
+    mid = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), S.synth_state(S.SYNTH_CFG_48K, SEED))
+    yield mid
+    from polgen_rvc_amd import _lib
+    _lib.lib().rvcx_unload_synth(ctx._h, mid)
+
+
+def _params(index_rate=0.0, seed=5, volume_envelope=1.0):
+    from polgen_rvc_amd import _lib
+    return _lib.Params(0.0, 50.0, 1100.0, index_rate, 0.33, volume_envelope, 0, 1, 6, 38, 41, seed)
+
+
+def _padded(ctx, clip):
+    return np.pad(ctx.highpass(clip.astype(np.float64)), (16000, 16000), mode="reflect").astype(np.float32)
+
+
+def test_index_ids_vs_float64_bruteforce_65536x768(ctx, full):
+    """C3's retrieval at its real size: 1599 HuBERT frames of a 30 s clip against 65 536 x 768 stored vectors.
+    Neighbour ids bit-exact vs the oracle's float64 brute force, blended features <= 1e-5 relative."""
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import synthetic as S
+    feats = ctx.hubert_features(_padded(ctx, S.make_clip(0, 30.0)), 768)[0]
+    assert feats.shape == (1599, 768)
+    big = S.make_index_from_feats(feats, 65536, 0)
+    ctx.load_index(big)
+    try:
+        out, ids, dist = ctx.index_blend(feats, 0.75)
+        ref, rids, rdist = OP.index_blend(feats, big, 0.75)
+        assert (ids == rids).all()
+        assert rms(out - ref) / rms(ref) < 1e-5
+        assert np.abs(dist - rdist).max() / rdist.max() < 1e-4
+        # a query far from every planted neighbour still agrees (random rows only): ids exact where the float64
+        # gap between the 8th and 9th neighbour exceeds the fp32 distance noise
+        g = np.random.Generator(np.random.PCG64(9))
+        q = g.standard_normal((64, 768)).astype(np.float32)
+        out2, ids2, _ = ctx.index_blend(q, 0.75)
+        d2 = ((q.astype(np.float64) ** 2).sum(1)[:, None] - 2.0 * q.astype(np.float64) @ big.astype(np.float64).T
+              + (big.astype(np.float64) ** 2).sum(1)[None, :])
+        srt = np.sort(d2, axis=1)
+        safe = (srt[:, 8] - srt[:, 7]) > 1e-2
+        _, rids2, _ = OP.index_blend(q, big, 0.75)
+        assert safe.sum() >= 48 and (np.sort(ids2[safe], 1) == np.sort(rids2[safe], 1)).all()
+    finally:
+        ctx.load_index(None)
+
+
+def test_c3_batch_of_8_equals_single_runs(ctx, full):
+    """B = 8 x 30 s, full-size models, index 65 536 x 768, index_rate 0.75: every utterance of the batched call is
+    bit-identical to converting it alone (same Philox stream seed + i), and the batch really ran as one."""
+    from polgen_rvc_amd import synthetic as S
+    clips = [S.make_clip(i, 30.0) for i in range(8)]
+    feats = ctx.hubert_features(_padded(ctx, clips[0]), 768)[0]
+    ctx.load_index(S.make_index_from_feats(feats, 65536, 0))
+    try:
+        p = _params(index_rate=0.75)
+        assert ctx.micro_batch(full, len(clips[0]), p) >= 2
+        pcm, f32 = ctx.convert_batch(full, clips, p, want_f32=True)
+        t_batch = ctx.last_timing()["total"]
+        assert all(len(x) == 1439040 for x in pcm)
+        t_single = 0.0
+        for i, c in enumerate(clips):
+            a_pcm, a_f32 = ctx.convert_batch(full, [c], _params(index_rate=0.75, seed=5 + i), want_f32=True)
+            t_single += ctx.last_timing()["total"]
+            assert np.array_equal(a_f32[0], f32[i]), i
+            assert np.array_equal(a_pcm[0], pcm[i]), i
+        print(f"8 x 30 s: batched {t_batch:.1f} ms, one at a time {t_single:.1f} ms")
+        assert np.isfinite(f32[0]).all() and rms(f32[0]) > 1e-3
+        # the blend is live
+        p0, _ = ctx.convert_batch(full, [clips[0]], _params(index_rate=0.0), want_f32=True)
+        assert not np.array_equal(p0[0], pcm[0])
+    finally:
+        ctx.load_index(None)
+
+
+def test_ragged_full_size_batch_equals_single_runs(ctx, full):
+    """C5's shape of traffic: utterances of different lengths in one call (two share a length and form a
+    micro-batch, one is long enough to be cut into chunks): each equals its single run."""
+    from polgen_rvc_amd import synthetic as S
+    clips = [S.make_clip(20, 4.0), S.make_clip(21, 7.5), S.make_clip(22, 4.0), S.make_clip(23, 43.0)]
+    p = _params(volume_envelope=0.5)
+    pcm = ctx.convert_batch(full, clips, p)
+    for i, c in enumerate(clips):
+        alone = ctx.convert_batch(full, [c], _params(volume_envelope=0.5, seed=5 + i))[0]
+        assert np.array_equal(alone, pcm[i]), i
+    assert len(pcm[3]) > 42 * 48000 - 4800
+
+
+def test_weight_regions_survive_a_simulated_broadcast(ctx, full):
+    """the weight layout must depend on shapes only.  A second context loads ZERO-filled
+    tensors of the same configurations (weight-norm folds of zeros are NaN), must report the same chunk sizes
+    and layout hash, receives the first context's chunks (device-to-device copies stand in for the RCCL
+    broadcast on this 1-GPU box), adopts the flags -- and then converts bit-identically."""
+    import ctypes as C
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    other = _lib.Context(0)
+    try:
+        z = lambda st: {k: np.zeros_like(v) for k, v in st.items()}
+        other.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, SEED)))
+        other.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, SEED)))
+        mid2 = other.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, SEED)))
+        # the session context may hold more voice models than `full`: compare a fresh source context instead
+        src = _lib.Context(0)
+        src.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), S.hubert_state(S.HUBERT_CFG_BASE, SEED))
+        src.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), S.rmvpe_state(S.RMVPE_CFG_FULL, SEED))
+        mid1 = src.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), S.synth_state(S.SYNTH_CFG_48K, SEED))
+        ra, ha = src.weights_regions()
+        rb, hb = other.weights_regions()
+        assert ha == hb and [n for _, n in ra] == [n for _, n in rb] and len(ra) > 3
+        hip = C.CDLL("libamdhip64.so")
+        for (pa, n), (pb, _) in zip(ra, rb):
+            assert hip.hipMemcpy(C.c_void_p(pb), C.c_void_p(pa), C.c_size_t(n), 3) == 0
+        other.weights_adopt()
+        clip = S.make_clip(3, 6.0)
+        a = src.convert_batch(mid1, [clip], _params(seed=2))[0]
+        b = other.convert_batch(mid2, [clip], _params(seed=2))[0]
+        assert np.array_equal(a, b) and len(a) > 0 and np.abs(a.astype(np.int32)).max() > 100
+        src.close()
+    finally:
+        other.close()
+
+
+def test_voice_model_regions_are_freed_on_unload(ctx):
+    """loading and unloading voice models / indices repeatedly must not exhaust anything."""
+    import ctypes as C
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    hip = C.CDLL("libamdhip64.so")
+    free0, tot = C.c_size_t(0), C.c_size_t(0)
+
+    def free_bytes():
+        hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
+        return free0.value
+    st = S.synth_state(S.SYNTH_CFG_48K, 3)
+    cfg = W.synth_cfg_struct(S.SYNTH_CFG_48K, 768)
+    mid = ctx.load_synth(cfg, st)
+    _lib.lib().rvcx_unload_synth(ctx._h, mid)
+    base = free_bytes()
+    for _ in range(12):                    # 12 x ~230 MB would be visible
+        mid = ctx.load_synth(cfg, st)
+        _lib.lib().rvcx_unload_synth(ctx._h, mid)
+    big = S.make_index(65536, 768, 0)
+    for _ in range(4):                     # 4 x ~400 MB
+        ctx.load_index(big)
+    ctx.load_index(None)
+    assert base - free_bytes() < (64 << 20)

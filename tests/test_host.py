@@ -44,6 +44,29 @@ def test_mirror_signatures_match_reference():
           "index_rate", "pitch_guidance", "filter_radius", "tgt_sr", "resample_sr", "volume_envelope", "version",
           "protect", "hop_length", "f0_file", "f0_min", "f0_max"]
     assert list(inspect.signature(P.VC.pipeline).parameters)[:len(pp)] == pp
+    # every public method of the reference's VC (rvc/infer/pipeline.py:65-467), positional part identical; extras
+    # must be keyword-only so that positional calls keep their meaning
+    ref_vc = {
+        "__init__": ["self", "tgt_sr", "config"],
+        "get_f0_crepe": ["self", "x", "f0_min", "f0_max", "p_len", "hop_length", "model"],
+        "get_f0_rmvpe": ["self", "x", "f0_min", "f0_max", "args", "kwargs"],
+        "get_f0": ["self", "input_audio_path", "x", "p_len", "pitch", "f0_method", "filter_radius", "hop_length",
+                   "inp_f0", "f0_min", "f0_max"],
+        "vc": ["self", "model", "net_g", "sid", "audio0", "pitch", "pitchf", "index", "big_npy", "index_rate",
+               "version", "protect"],
+        "pipeline": pp,
+    }
+    for name, want in ref_vc.items():
+        params = inspect.signature(getattr(P.VC, name)).parameters
+        got = list(params)
+        assert got[:len(want)] == want, (name, got)
+        for extra in got[len(want):]:
+            assert params[extra].kind is inspect.Parameter.KEYWORD_ONLY, (name, extra)
+    sig = inspect.signature(P.VC.get_f0).parameters
+    assert (sig["inp_f0"].default, sig["f0_min"].default, sig["f0_max"].default) == (None, 50, 1100)
+    sig = inspect.signature(P.VC.get_f0_rmvpe).parameters
+    assert (sig["f0_min"].default, sig["f0_max"].default) == (1, 40000)
+    assert P.RMVPE_DIR == os.path.join(os.getcwd(), "rvc", "models", "predictors", "rmvpe.pt")   # pipeline.py:14-16
     assert list(inspect.signature(I.get_vc).parameters)[:4] == ["device", "is_half", "config", "model_path"]
     assert list(inspect.signature(I.load_hubert).parameters)[:3] == ["device", "is_half", "model_path"]
     cfg = I.Config()
@@ -69,6 +92,27 @@ def test_fairseq_checkpoint_without_fairseq(tmp_path):
     got = ckpt_io.load_fairseq_hubert(path)
     assert set(got) == set(state)
     assert torch.equal(got["encoder.pos_conv.0.weight_g"], state["encoder.pos_conv.0.weight_g"])
+
+
+def test_restricted_unpickler_stubs_dangerous_globals(tmp_path):
+    """a crafted hubert_base.pt must not reach builtins.eval / exec / getattr / __import__ or arbitrary
+    torch / numpy callables through find_class -- only the exact tensor-rebuild allow-list resolves."""
+    import io
+
+    class Evil:
+        def __reduce__(self):
+            return (eval, ("__import__('os').environ.__setitem__('RVCX_PWNED', '1')",))
+    buf = io.BytesIO()
+    pickle.dump({"model": {"encoder.pos_conv.0.weight_g": Evil()}}, buf)
+    buf.seek(0)
+    os.environ.pop("RVCX_PWNED", None)
+    out = ckpt_io._StubUnpickler(buf).load()
+    assert "RVCX_PWNED" not in os.environ
+    assert isinstance(out["model"]["encoder.pos_conv.0.weight_g"], ckpt_io._Stub)
+    for mod, name in [("builtins", "eval"), ("builtins", "exec"), ("builtins", "getattr"), ("builtins", "__import__"),
+                      ("os", "system"), ("torch", "load"), ("numpy", "load"), ("torch.hub", "load")]:
+        assert issubclass(ckpt_io._StubUnpickler(io.BytesIO(b"")).find_class(mod, name), ckpt_io._Stub)
+    assert ckpt_io._StubUnpickler(io.BytesIO(b"")).find_class("collections", "OrderedDict").__name__ == "OrderedDict"
 
 
 def test_index_io_npy_and_flat(tmp_path):
@@ -126,6 +170,8 @@ def test_resident_asset_cache_is_keyed_by_path_and_mtime(tmp_path, monkeypatch):
     monkeypatch.setattr(W, "hubert_cfg_struct", lambda cfg: None)
     monkeypatch.setattr(W, "rmvpe_cfg_struct", lambda cfg: None)
     monkeypatch.setattr(W, "synth_cfg_struct", lambda cfg, d: None)
+    monkeypatch.setattr(W, "hubert_cfg_from_state", lambda st: {})
+    monkeypatch.setattr(W, "rmvpe_cfg_from_state", lambda st: {})
     monkeypatch.setattr(ckpt_io, "load_fairseq_hubert", lambda p: {})
     cpt = S.synth_checkpoint(S.SYNTH_CFG_TINY, 0)
     cpt["weight"] = {"emb_g.weight": np.zeros((5, 4), np.float32),
