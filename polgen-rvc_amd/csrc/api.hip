@@ -72,7 +72,6 @@ int rvcx_create(int device, rvcx_ctx** out) {
     for (auto& e : h->c.ev_src) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_hub, hipEventDisableTiming));
-    RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream_io, hipStreamNonBlocking));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_io, hipEventDisableTiming));
     for (auto& e : h->c.ev_front) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : h->c.ev_done) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -434,6 +433,7 @@ int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* l
   SynthModel& M = get_synth(*C, model_id);
   const int D = M.cfg.input_dim, inter = M.cfg.inter_channels;
   const size_t Tupp = (size_t)T * M.upp;
+  C->ensure_splitk(B);
   C->arena.reserve(synth_arena_bytes(M, B, T) + (size_t)B * T * D * 8 + (size_t)B * Tupp * 8);
   C->arena.reset();
   float* ph = any_to_dev(*C, phone, (size_t)B * T * D);
@@ -518,6 +518,7 @@ int rvcx_rmvpe_f0(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float thr
                   float* f0, float* hidden) {
   API_BEGIN(ctx)
   if (!C->rmvpe) fail("rmvpe not loaded");
+  C->ensure_splitk(B);
   const int F = (int)(1 + n / 160);
   C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, B, n) + (size_t)B * (n + (size_t)F * 362) * 4);
   C->arena.reset();
@@ -543,6 +544,7 @@ int rvcx_hubert_features(rvcx_ctx* ctx, int B, const float* wav, int64_t n, int 
   if (!C->hubert) fail("hubert not loaded");
   const int T = hubert_frames(*C->hubert, n), E = C->hubert->cfg.embed_dim;
   if (T <= 0) fail("hubert: input too short");
+  C->ensure_splitk(B);
   C->arena.reserve(hubert_arena_bytes(*C->hubert, B, n) + (size_t)B * (n + (size_t)2 * T * E) * 4);
   C->arena.reset();
   float* dw = any_to_dev(*C, wav, (size_t)B * n);

@@ -591,7 +591,10 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
   }
   const int DT = cdiv(D, 32);
   // split the key range over several workgroups when the (query block, head, batch) grid is too small
-  const long blocks = (long)cdiv(T, 128) * H * B;
+  // decided per batch item: the number of key splits changes the softmax merge order, and a batched conversion
+  // must reproduce its single-utterance runs bit for bit
+  const long blocks = (long)cdiv(T, 128) * H;
+  (void)B;
   int nsplit = 1;
   while (nsplit < 8 && blocks * nsplit < 384 && T / (nsplit * 2) >= 256) nsplit *= 2;
   float* opart = nullptr;

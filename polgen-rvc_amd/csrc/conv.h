@@ -54,6 +54,7 @@ struct ConvArgs {
   // split-K scratch offered by the caller (per stream); the launcher decides whether to use it
   float* part = nullptr;
   long part_cap = 0;             // floats
+  long part_cap_item = 0;        // floats per batch item the split-K DECISION may count on (see launch_conv_h3)
   // filled by the launcher
   int ci_chunk = 0, kk_chunk = 0, wrow = 0, off_min = 0;
   int splitk = 1;

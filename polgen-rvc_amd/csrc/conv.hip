@@ -242,7 +242,7 @@ void launch_conv(ConvArgs a, hipStream_t stream) {
     ConvArgs c = a;
     if (!plan_lds(c, kTiles[t].bm, kTiles[t].bn)) continue;
     long mt = cdiv(a.Cout_gp, kTiles[t].bm), nt = cdiv(a.Nout, kTiles[t].bn);
-    long blocks = mt * nt * a.groups * a.B;
+    long blocks = mt * nt * a.groups;   // per batch item: the choice must not depend on the batch size
     long rounds = (blocks + 511) / 512;  // 256 CUs x 2 resident blocks
     double tm = (double)rounds * kTiles[t].bm * kTiles[t].bn / kTiles[t].eff;
     if (tm < best_t) {

@@ -667,38 +667,52 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
   static const TileFit kFit[15] = {{0.964f, 201.f}, {0.922f, 129.f}, {0.968f, 231.f}, {0.954f, 150.f}, {0.964f, 169.f},
                                    {1.00f, 184.f},  {0.93f, 260.f},  {0.95f, 180.f},  {1.00f, 150.f},  {1.00f, 213.f},
                                    {0.95f, 150.f},  {0.95f, 120.f},  {0.964f, 201.f}, {0.922f, 129.f}, {0.964f, 169.f}};
-  int best = -1, S = 1;
-  double best_t = 1e300;
   const bool lin = a.ksize == 1 && a.Cin_gp % 32 == 0;
   const double kdepth = (double)a.ksize * a.Cin_gp;
-  for (int t = 0; t < kNumFast; ++t) {
-    const FastCfg& F = kFast[t];
-    if ((F.halo < 0) != (a.stride == 2)) continue;
-    if (a.stride == 2) {
-      if (halo > -F.halo) continue;
-    } else {
-      if ((F.cic == 32) != lin) continue;   // Linear layers go to the k=1 variants
-      if (halo > F.halo) continue;
-      if (F.halo == 320 && halo <= 64) continue;
-    }
-    if (g_conv_override.tile >= 0 && g_conv_override.tile != t) continue;
-    const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * a.B;
-    const int nci = a.Cin_gp / F.cic;
-    for (int s = 1; s <= 8; s *= 2) {
-      if (s > 1 && (!a.part || nci / s < 1 || kdepth / s < 128.0 ||
-                    (long)s * a.B * a.Cout_g * a.Nout > a.part_cap))
-        break;
-      if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
-      const double c = (double)blocks * s / 256.0;
-      const double f = std::min(1.0, 0.45 + 0.55 * (std::max(c, 1.0) - 1.0) / 3.0);
-      double us = std::ceil(c) * 2.0 * F.bm * F.bn * (kdepth / s + kFit[t].ovh) / (577e3 * kFit[t].eff * f);
-      if (s > 1) us += 3.0 + (double)(s + 1) * a.B * a.Cout_g * a.Nout * 4.0 / 3e6;
-      if (us < best_t) {
-        best_t = us;
-        best = t;
-        S = s;
+  // batch invariance (see launch_conv_h3): split-K is decided for one batch item, the tile for the real batch
+  const long cap_item = a.part_cap_item > 0 ? a.part_cap_item : a.part_cap;
+  auto select = [&](int Bsel, int forcedS, int* tile_out, int* s_out) {
+    int best = -1, S = 1;
+    double best_t = 1e300;
+    for (int t = 0; t < kNumFast; ++t) {
+      const FastCfg& F = kFast[t];
+      if ((F.halo < 0) != (a.stride == 2)) continue;
+      if (a.stride == 2) {
+        if (halo > -F.halo) continue;
+      } else {
+        if ((F.cic == 32) != lin) continue;   // Linear layers go to the k=1 variants
+        if (halo > F.halo) continue;
+        if (F.halo == 320 && halo <= 64) continue;
+      }
+      if (g_conv_override.tile >= 0 && g_conv_override.tile != t) continue;
+      const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * Bsel;
+      const int nci = a.Cin_gp / F.cic;
+      for (int s = 1; s <= 8; s *= 2) {
+        if (s > 1 && (!a.part || nci / s < 1 || kdepth / s < 128.0 || (long)s * a.Cout_g * a.Nout > cap_item ||
+                      (long)s * a.B * a.Cout_g * a.Nout > a.part_cap))
+          break;
+        if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
+        if (forcedS > 0 && s != forcedS) continue;
+        const double c = (double)blocks * s / 256.0;
+        const double f = std::min(1.0, 0.45 + 0.55 * (std::max(c, 1.0) - 1.0) / 3.0);
+        double us = std::ceil(c) * 2.0 * F.bm * F.bn * (kdepth / s + kFit[t].ovh) / (577e3 * kFit[t].eff * f);
+        if (s > 1) us += 3.0 + (double)(s + 1) * Bsel * a.Cout_g * a.Nout * 4.0 / 3e6;
+        if (us < best_t) {
+          best_t = us;
+          best = t;
+          S = s;
+        }
       }
     }
+    *tile_out = best;
+    *s_out = S;
+  };
+  int best = -1, S = 1;
+  select(1, 0, &best, &S);
+  if (best >= 0 && a.B > 1) {
+    int b2 = -1, s2 = 1;
+    select(a.B, S, &b2, &s2);
+    if (b2 >= 0 && s2 == S) best = b2;
   }
   if (best < 0) return -1;
   const FastCfg& F = kFast[best];

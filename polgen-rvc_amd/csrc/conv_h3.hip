@@ -352,26 +352,20 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 #pragma unroll
       for (int n = 0; n < WN; ++n) store_tile_split(a, b, c_t + m * 32, nn_w + n * 32, h, acc[m][n], len_out);
   } else if (fast_epilogue_ok(a)) {
-    store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
-    if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
-    if constexpr (WM > 1) {
-      store_tile_fast(a, b, co_w + 32, nn_w, acc[1][0], len_out);
-      if constexpr (WN > 1) store_tile_fast(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
-    }
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) store_tile_fast(a, b, co_w + m * 32, nn_w + n * 32, acc[m][n], len_out);
   } else if (a.out_mode == OUT_SHUF1D) {
-    store_tile_shuf1d(a, b, co_w, nn_w, acc[0][0], len_out);
-    if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w, nn_w + 32, acc[0][1], len_out);
-    if constexpr (WM > 1) {
-      store_tile_shuf1d(a, b, co_w + 32, nn_w, acc[1][0], len_out);
-      if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
-    }
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) store_tile_shuf1d(a, b, co_w + m * 32, nn_w + n * 32, acc[m][n], len_out);
   } else {
-    store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
-    if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
-    if constexpr (WM > 1) {
-      store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
-      if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
-    }
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) store_tile(a, b, 0, co_w + m * 32, nn_w + n * 32, acc[m][n], len_out);
   }
 }
 
@@ -447,29 +441,53 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   // cost model in the shape of conv_fast's: the three fp16 MFMAs of a (tap, 16-channel) k-step cost 96 matrix-pipe
   // cycles for 32x32x16 MACs; fitted on the NSF shapes: a CU retires ~39 k-steps of a 32x32 tile per microsecond with
   // >= 4 blocks resident, a block's prologue + epilogue cost ~18 k-steps per 32x32 tile
-  int best = -1, S = 1;
-  double best_t = 1e300;
-  for (int t = 0; t < kNumH3; ++t) {
-    const H3Cfg& F = kH3[t];
-    if (g_conv_override.tile >= 100 && g_conv_override.tile - 100 != t) continue;
-    if (F.lin != lin || F.stride != a.stride) continue;
-    if (a.x_split && !F.kern_xs) continue;
-    if (!lin && (halo > F.halo || (F.halo == 320 && halo <= 64))) continue;
-    const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * a.B;
-    const double ksteps = (double)a.ksize * nchunk;
-    for (int s = 1; s <= (split ? 1 : 8); s *= 2) {
-      if (s > 1 && (!a.part || nchunk / s < 1 || ksteps / s < 8.0 || (long)s * a.B * a.Cout_g * a.Nout > a.part_cap)) break;
-      if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
-      const double c = (double)blocks * s / 256.0;
-      const double f = std::min(1.0, 0.45 + 0.55 * (std::max(c, 1.0) - 1.0) / 3.0);
-      double us = std::ceil(c) * (F.bm / 32) * (F.bn / 32) * (ksteps / s + F.ovh) / (39.0 * F.eff * f);
-      if (s > 1) us += 3.0 + (double)(s + 1) * a.B * a.Cout_g * a.Nout * 4.0 / 3e6;
-      if (us < best_t) {
-        best_t = us;
-        best = t;
-        S = s;
+  // Batch invariance: the split-K factor changes the fp32 summation order, so it is decided for ONE batch item
+  // (exactly the decision a single-utterance run takes); the tile -- which does not change the order of the k-loop
+  // -- is then chosen for the real batch under that factor.  A batched conversion is therefore bit-identical to
+  // converting its utterances one by one.
+  const long cap_item = a.part_cap_item > 0 ? a.part_cap_item : a.part_cap;
+  auto select = [&](int Bsel, int forcedS, int* tile_out, int* s_out) {
+    int best = -1, S = 1;
+    double best_t = 1e300;
+    for (int t = 0; t < kNumH3; ++t) {
+      const H3Cfg& F = kH3[t];
+      if (g_conv_override.tile >= 100 && g_conv_override.tile - 100 != t) continue;
+      if (F.lin != lin || F.stride != a.stride) continue;
+      if (a.x_split && !F.kern_xs) continue;
+      if (!lin && (halo > F.halo || (F.halo == 320 && halo <= 64))) continue;
+      const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * Bsel;
+      const double ksteps = (double)a.ksize * nchunk;
+      for (int s = 1; s <= (split ? 1 : 8); s *= 2) {
+        if (s > 1 && (!a.part || nchunk / s < 1 || ksteps / s < 8.0 || (long)s * a.Cout_g * a.Nout > cap_item ||
+                      (long)s * a.B * a.Cout_g * a.Nout > a.part_cap))
+          break;
+        if (g_conv_override.splitk > 0 && g_conv_override.splitk != s) continue;
+        if (forcedS > 0 && s != forcedS) continue;
+        const double c = (double)blocks * s / 256.0;
+        const double f = std::min(1.0, 0.45 + 0.55 * (std::max(c, 1.0) - 1.0) / 3.0);
+        double us = std::ceil(c) * (F.bm / 32) * (F.bn / 32) * (ksteps / s + F.ovh) / (39.0 * F.eff * f);
+        if (s > 1) us += 3.0 + (double)(s + 1) * Bsel * a.Cout_g * a.Nout * 4.0 / 3e6;
+        if (us < best_t) {
+          best_t = us;
+          best = t;
+          S = s;
+        }
       }
     }
+    *tile_out = best;
+    *s_out = S;
+  };
+  int best = -1, S = 1;
+  select(1, 0, &best, &S);
+  static const int tile2_mask = getenv("RVCX_TILE2_MASK") ? atoi(getenv("RVCX_TILE2_MASK")) : 255;
+  const int cls = (a.out_mode != OUT_NORMAL) ? 8 : (lin ? 2 : (halo > 64 ? 1 : 4));
+  int cls2 = cls;
+  if (a.x_split || a.y_split) cls2 |= 16;
+  const bool tile_for_batch = (tile2_mask & cls) && (!(cls2 & 16) || (tile2_mask & 16));
+  if (best >= 0 && a.B > 1 && tile_for_batch) {
+    int b2 = -1, s2 = 1;
+    select(a.B, S, &b2, &s2);
+    if (b2 >= 0 && s2 == S) best = b2;
   }
   if (best < 0) return -1;
   const H3Cfg& F = kH3[best];
@@ -482,6 +500,13 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
     a.dbg = dbg;
   }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
+  {
+    static const bool log = getenv("RVCX_CONV_LOG") != nullptr;
+    if (log)
+      fprintf(stderr, "h3 tile %d (%dx%d halo %d) S %d grid %u %u %u B %d Cin %d Cout %d k %d Nout %d xs %d ys %d\n", best,
+              F.bm, F.bn, F.halo, S, grid.x, grid.y, grid.z, a.B, a.Cin_g, a.Cout_g, a.ksize, a.Nout, a.x_split != nullptr,
+              a.y_split != nullptr);
+  }
   hipLaunchKernelGGL(a.x_split ? F.kern_xs : F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());

@@ -134,7 +134,9 @@ struct Ctx {
   hipStream_t aux[2] = {nullptr, nullptr};   // the three ResBlocks of an NSF stage run side by side
   hipEvent_t ev_aux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipStream_t stream_io = nullptr;             // finished PCM leaves here while the next micro-batch computes
+  // NOTE: no further streams.  HIP multiplexes streams onto 4 hardware queues per process; a fifth stream made the
+  // RMVPE stream share a queue (RMVPE 10.8 -> 16.4 ms, the whole clip 31.6 -> 42.3 ms).  D2H copies ride the main stream.
+  hipStream_t stream_io = nullptr;             // always null: see above
   hipEvent_t ev_io = nullptr;
   hipEvent_t ev_front[2] = {nullptr, nullptr}; // front end (high-pass .. reflect pad) of micro-batch k is ready
   hipEvent_t ev_done[2] = {nullptr, nullptr};  // main stream is done with micro-batch k's front set
@@ -159,14 +161,28 @@ struct Ctx {
   ~Ctx();
   // split-K partial-sum scratch, one per stream (RMVPE and HuBERT run concurrently)
   float* splitk_buf[4] = {nullptr, nullptr, nullptr, nullptr};
-  static constexpr long kSplitKFloats = 32L << 20;   // 128 MiB each
+  static constexpr long kSplitKFloats = 32L << 20;   // 128 MiB per batch item each
+  int splitk_items = 1;                              // batch items the buffers are sized for (ensure_splitk)
+  // Called before a micro-batch is enqueued: the split-K decision is taken per item (batch invariance), so the
+  // scratch must hold `items` times what one item may use.  Re-allocates (after a device sync) when it grows.
+  void ensure_splitk(int items) {
+    if (items <= splitk_items) return;
+    RVCX_HIP(hipDeviceSynchronize());
+    for (auto& p : splitk_buf)
+      if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+      }
+    splitk_items = items;
+  }
   void conv(const ConvArgs& a) { conv_on(a, stream); }
   void conv_on(ConvArgs a, hipStream_t s) {
     flops += conv_flops(a);
     const int si = (s == stream2) ? 1 : (s == aux[0] ? 2 : (s == aux[1] ? 3 : 0));
-    if (!splitk_buf[si]) RVCX_HIP(hipMalloc(&splitk_buf[si], kSplitKFloats * sizeof(float)));
+    if (!splitk_buf[si]) RVCX_HIP(hipMalloc(&splitk_buf[si], kSplitKFloats * splitk_items * sizeof(float)));
     a.part = splitk_buf[si];
-    a.part_cap = kSplitKFloats;
+    a.part_cap = kSplitKFloats * splitk_items;
+    a.part_cap_item = kSplitKFloats;
     launch_conv(a, s);
   }
 };

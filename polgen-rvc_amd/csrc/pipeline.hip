@@ -424,7 +424,7 @@ long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, 
 // small launches of the front end and the TextEncoder/flow section are paid once per micro-batch instead of once
 // per clip.  Three streams: `sf` runs the front end (upload, float64 zero-phase high-pass, cut search, reflect
 // pad, RMVPE F0) of micro-batch k+1 while the main stream is still in the NSF decoder of micro-batch k; HuBERT keeps
-// its CU-masked stream; finished PCM leaves on the copy stream.  No host synchronisation inside the loop except
+// its CU-masked stream; finished PCM leaves behind its micro-batch on the main stream.  No host synchronisation inside the loop except
 // the cut-point read-back of clips longer than x_max seconds.
 void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_params& p, float* stage_ms) {
   RVCX_CHECK(c.hubert && c.rmvpe, "convert: hubert / rmvpe not loaded");
@@ -438,7 +438,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   if (NB == 0) return;
   hipStream_t s = c.stream;
   hipStream_t sf = c.serial ? s : c.stream2;
-  hipStream_t sio = c.serial ? s : c.stream_io;
+  hipStream_t sio = (c.serial || !c.stream_io) ? s : c.stream_io;   // copy-out stream (the main stream: see ctx.h)
   Arena& A = c.arena;
   StageClock clk(stage_ms != nullptr);
 
@@ -475,6 +475,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   }
   (void)any_f64;
   (void)any_noise;
+  c.ensure_splitk((int)std::max<size_t>(1, [&] {
+    int m = 1;
+    for (const auto& mb : mbs) m = std::max(m, mb.count);
+    return (size_t)m;
+  }()));
   A.reserve(call_bytes + mb_bytes + ((size_t)96 << 20));
   A.reset();
   c.arena_f0.reset();
@@ -634,7 +639,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         const int Th = hubert_frames(*c.hubert, ns);
         const int T = (int)std::min<long>(ns / 160, 2L * Th);
         RVCX_CHECK(Th > 0 && T > 0, "convert: chunk too short");
-        RVCX_CHECK((long)T * M.upp > 2 * g.t_pad_tgt, "convert: chunk shorter than its padding");
+        // a cut may land within x_pad seconds of the clip's end: the reference then trims that chunk's output to
+        // nothing (audio1[t_pad_tgt:-t_pad_tgt], pipeline.py:441-447) but still runs it -- so do we
+        RVCX_CHECK((long)T * M.upp >= 2 * g.t_pad_tgt, "convert: chunk shorter than its padding");
         jobs.push_back({b, (int)ci, ch.s, ch.e, ch.f0_off, out_off, noise_off, Th, T});
         out_off += (long)T * M.upp - 2 * g.t_pad_tgt;
         noise_off += (long)T * (inter + M.upp);
@@ -763,8 +770,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       for (int q = 0; q < G; ++q) {
         const Job& j = jobs[grp[q]];
         const Utt& u = utts[order[mb.first + j.u]];
-        RVCX_HIP(hipMemcpyAsync(u.outf + j.out_off, wavout + (size_t)q * nsrc + g.t_pad_tgt, (size_t)keep_n * sizeof(float),
-                                hipMemcpyDeviceToDevice, s));
+        if (keep_n > 0)
+          RVCX_HIP(hipMemcpyAsync(u.outf + j.out_off, wavout + (size_t)q * nsrc + g.t_pad_tgt,
+                                  (size_t)keep_n * sizeof(float), hipMemcpyDeviceToDevice, s));
       }
       A.reset(mk);   // stream-ordered reuse: later launches on the same stream see the finished group
     }

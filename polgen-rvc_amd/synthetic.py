@@ -299,10 +299,11 @@ def make_index(n: int, dim: int = 768, seed: int = 0) -> np.ndarray:
 def make_index_from_feats(feats: np.ndarray, n_rows: int, seed: int = 0) -> np.ndarray:
     """Retrieval matrix with UNAMBIGUOUS neighbours for the queries ``feats`` (T, dim) ("queries
     perturbed copies so neighbours are unambiguous"): for every query 8 stored vectors at squared distances
-    ~ dim * (0.10 + 0.03 k)^2, k = 1..8 (13 .. 89 at dim 768: far below the ~2 dim of unrelated rows, and large
-    enough that the float32 |q|^2 + |b|^2 - 2 q.b form keeps 5 digits); the remaining rows are N(0,1)
-    filler; rows are shuffled by a fixed permutation so that ids are not trivially ordered.  A real RVC index
-    is built from the training set's HuBERT features, i.e. exactly "features plus small perturbations"."""
+    ~ dim * (0.005 k)^2, k = 1..8 (0.02 .. 1.2 at dim 768).  HuBERT frames of one clip lie as close as d ~ 2 to
+    each other, so the planted copies must stay below that for the top-8 of a query to be its own 8 copies, in
+    order, with gaps (>= 0.05) far above the float32 noise of the |q|^2 + |b|^2 - 2 q.b form (~1e-4).  The
+    remaining rows are N(0,1) filler; rows are shuffled by a fixed permutation.  A real RVC index is built from
+    the training set's HuBERT features, i.e. exactly "features plus small perturbations"."""
     feats = np.asarray(feats, np.float32)
     T, dim = feats.shape
     if 8 * T > n_rows:
@@ -310,7 +311,7 @@ def make_index_from_feats(feats: np.ndarray, n_rows: int, seed: int = 0) -> np.n
     rows = _normal(f"index.filler.{n_rows}.{dim}", (n_rows, dim), 1.0, seed)
     eps = _normal(f"index.eps.{T}.{dim}", (8, T, dim), 1.0, seed)
     for k in range(8):
-        rows[k * T:(k + 1) * T] = feats + np.float32(0.10 + 0.03 * (k + 1)) * eps[k]
+        rows[k * T:(k + 1) * T] = feats + np.float32(0.005 * (k + 1)) * eps[k]
     perm = _rng(f"index.perm.{n_rows}", seed).permutation(n_rows)
     return np.ascontiguousarray(rows[perm])
 

@@ -155,3 +155,28 @@ def test_conv1d_h3_falls_back_when_weights_overflow_fp16(ctx):
     ref = F.conv1d(x.double(), w.double(), b.double(), padding=1).numpy()
     got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), pad_left=1, Tout=20000)
     assert np.isfinite(got).all() and rms(got - ref) / rms(ref) < 1e-6
+
+
+@pytest.mark.parametrize("tile", [103, 104, 109, 110])
+def test_every_3x3_tile_stores_every_subtile(ctx, tile):
+    """Batched (B = 3) 3x3 conv on a U-Net level-0 sized map with each tile of the conv_h3 3x3 family forced: every
+    output element is written (the destination is NaN-filled by hipMemset in the op) and equals the B = 1 result
+    bit for bit.  Regression for the 32x512 tile whose epilogue stored only two of its four 32x32 sub-tiles --
+    a latent bug the batched path's tile choice exposed in round 2."""
+    import torch
+    g = torch.Generator().manual_seed(0)
+    B, C, H, W = 3, 16, 808, 128
+    x = torch.randn(B, C, H, W, generator=g).numpy()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).numpy()
+    res = torch.randn(B, C, H, W, generator=g).numpy()
+    try:
+        ctx.conv_override(109, -1, -1)
+        ref = np.concatenate([ctx.conv2d3x3(x[b:b + 1], w, None, res=res[b:b + 1], act=2) for b in range(B)])
+        # poison the arena region the next call will reuse for its output
+        ctx.conv2d3x3(np.full_like(x, np.nan), w, None, act=0)
+        ctx.conv_override(tile, -1, -1)
+        got = ctx.conv2d3x3(x, w, None, res=res, act=2)
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, ref)
+    finally:
+        ctx.conv_override(-1, -1, -1)

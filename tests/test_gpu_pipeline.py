@@ -198,7 +198,7 @@ def test_full_size_pipeline_vs_reference_golden(ctx, tag):
     assert diff.max() <= 8 and np.mean(diff > 1) < 0.02
     # every sample is covered: RMS of each 4096-sample block of the reference's output vs ours
     nblk = _check_blocks(f32, d, tgt_sr)
-    assert nblk >= (len(d["block_rms"]) * 8) // 10
+    assert nblk >= (len(pcm) // 4096) - 1          # every block that lies inside the trimmed region
     if diff.max() == 0 and len(pcm) % 997 == 0:
         pass
     x = np.pad(ctx.highpass(audio.astype(np.float64)), (vc.t_pad, vc.t_pad), mode="reflect")

@@ -38,6 +38,32 @@ sys.modules["torchaudio.transforms"] = ta
 sys.modules["torchaudio"].transforms = ta
 sys.modules["local_attention"].LocalAttention = object
 
+
+
+class _FlatIndex:
+    """Stand-in for ``faiss.read_index`` (faiss-cpu 1.7.3 is not installed): exact squared-L2 top-k, the
+    IndexFlatL2 semantics.  Only ``search`` / ``reconstruct_n`` / ``ntotal`` are restated -- the blend arithmetic
+    around them (pipeline.py:239-250) is the REFERENCE's own code.  Parity with real faiss stays unpinned."""
+
+    def __init__(self, big):
+        self.big = np.ascontiguousarray(big, np.float32)
+        self.ntotal, self.d = self.big.shape
+        self.searches = []
+
+    def reconstruct_n(self, i0, n):
+        return self.big[i0:i0 + n]
+
+    def search(self, x, k):
+        q, b = x.astype(np.float64), self.big.astype(np.float64)
+        d2 = (q * q).sum(1)[:, None] - 2.0 * q @ b.T + (b * b).sum(1)[None, :]
+        ix = np.argsort(d2, axis=1, kind="stable")[:, :k]
+        self.searches.append(ix.copy())
+        return np.take_along_axis(d2, ix, axis=1).astype(np.float32), ix.astype(np.int64)
+
+
+_INDEX_FILES = {}
+sys.modules["faiss"].read_index = lambda path: _INDEX_FILES[path]
+
 import polgen_rvc_amd  # noqa: E402
 from polgen_rvc_amd import synthetic as S  # noqa: E402
 from oracle import synth as O_synth, rmvpe as O_rmvpe, hubert as O_hubert, pipeline as O_pipe  # noqa: E402
@@ -175,9 +201,10 @@ def gold_synth(tag, cfg, T, seed):
                         z_p=z_p.numpy(), z=z.numpy(), audio=o.numpy())
 
 
-def stable_seed(rcfg, audio_pad_f32, seed, f0_min=50, f0_max=1100, pitch=0.0):
-    """First seed >= `seed` (step 100) for which every frame's f0 decision is well-conditioned."""
-    for k in range(40):
+def stable_seed(rcfg, audio_pad_f32, seed, f0_min=50, f0_max=1100, pitch=0.0, tries=40):
+    """First seed >= `seed` (step 100) for which every frame's f0 decision is well-conditioned (None if `tries`
+    seeds were not enough)."""
+    for k in range(tries):
         sd_ = S.to_torch(S.rmvpe_state(rcfg, seed + 100 * k))
         f0_, hid_, _ = O_rmvpe.infer_f0(sd_, rcfg, audio_pad_f32, 0.03, f0_min, f0_max, return_hidden=True)
         bad = O_rmvpe.unstable_frames(hid_, 0.03, f0_min, f0_max)
@@ -190,6 +217,8 @@ def stable_seed(rcfg, audio_pad_f32, seed, f0_min=50, f0_max=1100, pitch=0.0):
         print(f"  seed {seed + 100 * k}: unstable frames {len(bad)}, coarse ties {int(tie.sum())}, voiced {vf:.2f}")
         if len(bad) == 0 and not tie.any() and 0.15 < vf < 0.995:
             return seed + 100 * k
+    if tries < 40:
+        return None
     raise RuntimeError("no stable seed found")
 
 
@@ -229,11 +258,12 @@ def gold_hubert(tag, cfg, seconds, seed):
 
 
 def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0_min, f0_max, seed,
-                     tgt_sr):
+                     tgt_sr, file_index=None, index_rate=0, prebuilt=None):
     (hcfg, hsd), (rcfg, rsd), (scfg, ssd) = models_cfg
     vc = P.VC(tgt_sr, Cfg(geo))
-    vc.model_rmvpe = ref_rmvpe(rcfg, rsd)
-    hub = HubertAdapter(hf_hubert(hcfg, hsd))
+    if prebuilt is None:
+        prebuilt = (ref_rmvpe(rcfg, rsd), HubertAdapter(hf_hubert(hcfg, hsd)))
+    vc.model_rmvpe, hub = prebuilt
     net = ref_synth(scfg, ssd)
     draws = []
     orig = torch.randn_like
@@ -257,8 +287,8 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
     torch.randn_like = cap
     torch.manual_seed(seed)
     try:
-        pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, "rmvpe+", None, 0, 1, 3,
-                          tgt_sr, 0, volume_envelope, "v2", protect, 128, None, f0_min, f0_max)
+        pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, "rmvpe+", file_index, index_rate,
+                          1, 3, tgt_sr, 0, volume_envelope, "v2", protect, 128, None, f0_min, f0_max)
     finally:
         torch.randn_like = orig
     noises = [(draws[2 * i], draws[2 * i + 1]) for i in range(len(draws) // 2)]
@@ -307,6 +337,95 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
             store[f"src_noise_{i}"] = sn.numpy()
     else:
         store.update(pcm_samples=pcm[::997], raw_samples=rawcat[::997].astype(np.float32), noise_seed=seed)
+    np.savez_compressed(os.path.join(GOLD, f"pipeline_{tag}.npz"), **store)
+
+
+def _full_store(pcm, raw, parts, stride):
+    rawcat = np.concatenate(raw)
+    return dict(n_chunks=len(raw), chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
+                coarse=parts["coarse"].astype(np.int16), sha256=hashlib.sha256(pcm.tobytes()).hexdigest(),
+                block_rms=np.array([rms(rawcat[i:i + 4096]) for i in range(0, len(rawcat), 4096)], np.float32),
+                pcm_samples=pcm[::stride], raw_samples=rawcat[::stride].astype(np.float32), stride=stride)
+
+
+def gold_pipeline_c3(tag="c3_30s_48k_index", seconds=30.0, clip=0, seed=1900, n_rows=65536, index_rate=0.75):
+    """BASELINE configs[2] for one utterance of the batch: full-size models, retrieval blend at index_rate 0.75 over
+    a 65 536 x 768 index (S.make_index_from_feats of the reference-side HuBERT features: unambiguous neighbours).
+    The reference's own VC.vc blend code runs; only faiss' search is the exact-L2 stand-in above."""
+    cfgs = (S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL, S.SYNTH_CFG_48K)
+    hcfg, rcfg, scfg = cfgs
+    geo = (1, 6, 38, 41)
+    print(f"[pipeline {tag}] {seconds}s index {n_rows}x768 rate {index_rate}")
+    audio = S.make_clip(clip, seconds)
+    a_ = np.pad(O_pipe.highpass(audio.astype(np.float64)), (16000, 16000), mode="reflect").astype(np.float32)
+    assert stable_seed(rcfg, a_, seed) == seed
+    hsd, rsd, ssd = (S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.rmvpe_state(rcfg, seed)),
+                     S.to_torch(S.synth_state(scfg, seed)))
+    hub = HubertAdapter(hf_hubert(hcfg, hsd))
+    feats = hub.extract_features(torch.from_numpy(a_)[None], None, 12)[0][0].numpy()
+    big = S.make_index_from_feats(feats, n_rows, 0)
+    idx = _FlatIndex(big)
+    path = os.path.join("/tmp", f"rvcx_{tag}.index")
+    open(path, "wb").close()
+    _INDEX_FILES[path] = idx
+    t0 = time.time()
+    pcm, raw, noises = run_ref_pipeline(((hcfg, hsd), (rcfg, rsd), (scfg, ssd)), geo, audio, 0, 1.0, 0.33, 50, 1100,
+                                        seed, 48000, file_index=path, index_rate=index_rate,
+                                        prebuilt=(ref_rmvpe(rcfg, rsd), hub))
+    t_ref = time.time() - t0
+    assert len(idx.searches) == 1, "the reference did not search the index"
+    models = O_pipe.Models(hsd, hcfg, rsd, rcfg, ssd, scfg)
+    opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(48000, *geo), audio, 0, 0, big, index_rate, 1.0, 0.33, 50,
+                                  1100, noises=noises, return_parts=True)
+    e = report("vc chunk f32 (ref vs oracle)", raw[0], parts["raw"][0])
+    d = np.abs(pcm.astype(np.int32) - opcm.astype(np.int32))
+    print(f"  ref {t_ref:.1f}s  pcm max |diff| {d.max()} LSB")
+    assert e < 1e-4 and d.max() <= 8
+    # the same run without the index must differ: the blend is live in the fixture
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=0, volume_envelope=1.0, protect=0.33,
+                 f0_min=50, f0_max=1100, cfgs=json.dumps([hcfg, rcfg, scfg]), noise_seed=seed, index_rate=index_rate,
+                 index_rows=n_rows, ids_sha256=hashlib.sha256(idx.searches[0].astype(np.int64).tobytes()).hexdigest(),
+                 ids_head=idx.searches[0][:16].astype(np.int64))
+    store.update(_full_store(pcm, raw, parts, 997))
+    np.savez_compressed(os.path.join(GOLD, f"pipeline_{tag}.npz"), **store)
+    os.remove(path)
+
+
+def gold_pipeline_c5(tag="c5_two_models", seed0=2500):
+    """BASELINE configs[4] in small: two resident voice models (40 k and 48 k, full size) sharing ONE HuBERT and
+    ONE RMVPE, utterances of different lengths -- the reference's VC.pipeline output per (utterance, model)."""
+    hcfg, rcfg = S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL
+    geo = (1, 6, 38, 41)
+    jobs = [(30, 4.2, S.SYNTH_CFG_40K), (31, 6.1, S.SYNTH_CFG_48K), (32, 3.3, S.SYNTH_CFG_48K)]
+    pads = [np.pad(O_pipe.highpass(S.make_clip(c, sec).astype(np.float64)), (16000, 16000), mode="reflect")
+            .astype(np.float32) for c, sec, _ in jobs]
+    seed = seed0
+    for _ in range(200):                              # one RMVPE seed that is well-conditioned on every utterance
+        if all(stable_seed(rcfg, a_, seed, tries=1) == seed for a_ in pads):
+            break
+        seed += 100
+    else:
+        raise RuntimeError("no common stable seed")
+    print(f"[pipeline {tag}] shared HuBERT/RMVPE seed {seed}")
+    hsd, rsd = S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.rmvpe_state(rcfg, seed))
+    pre = (ref_rmvpe(rcfg, rsd), HubertAdapter(hf_hubert(hcfg, hsd)))
+    store = dict(seed=seed, geo=np.array(geo), n_utts=len(jobs), hcfg=json.dumps(hcfg), rcfg=json.dumps(rcfg))
+    for u, (clip, sec, scfg) in enumerate(jobs):
+        sseed = seed + (3 if scfg is S.SYNTH_CFG_40K else 7)
+        ssd = S.to_torch(S.synth_state(scfg, sseed))
+        audio = S.make_clip(clip, sec)
+        nseed = seed + 11 * (u + 1)
+        pcm, raw, noises = run_ref_pipeline(((hcfg, hsd), (rcfg, rsd), (scfg, ssd)), geo, audio, 0, 1.0, 0.33, 50,
+                                            1100, nseed, scfg[-1], prebuilt=pre)
+        models = O_pipe.Models(hsd, hcfg, rsd, rcfg, ssd, scfg)
+        opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(scfg[-1], *geo), audio, 0, 0, None, 0.0, 1.0, 0.33, 50,
+                                      1100, noises=noises, return_parts=True)
+        e = report(f"utt {u} vc f32 (ref vs oracle)", raw[0], parts["raw"][0])
+        assert e < 1e-4
+        st = _full_store(pcm, raw, parts, 97)
+        st.update(clip=clip, seconds=sec, scfg=json.dumps(scfg), synth_seed=sseed, noise_seed=nseed)
+        for k, v in st.items():
+            store[f"u{u}_{k}"] = v
     np.savez_compressed(os.path.join(GOLD, f"pipeline_{tag}.npz"), **store)
 
 
@@ -359,6 +478,8 @@ def main():
                                                  50, 1100, full_store=False)
         steps["pipe_c2"] = lambda: gold_pipeline("c2_30s_48k", full48, (1, 6, 38, 41), 30.0, 0, 0, 0, 1.0, 0.33,
                                                  50, 1100, full_store=False)
+        steps["pipe_c3"] = gold_pipeline_c3
+        steps["pipe_c5"] = gold_pipeline_c5
     for k, fn in steps.items():
         if a.only and a.only not in k:
             continue
