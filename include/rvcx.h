@@ -192,6 +192,15 @@ int rvcx_op_conv1d(rvcx_ctx*, const float* x, const float* w, const float* bias,
                    float* y, int B, int Cin, int Tin, int Cout, int K, int stride, int dil,
                    int pad_left, int Tout, int groups, int pre_lrelu, float pre_slope, int act,
                    float act_slope, const int32_t* lens_in, const int32_t* lens_out);
+/* one ResBlock1 step, y = x + c2(lrelu(c1(lrelu(x)) + b1)) + b2 -- rvc/lib/algorithm/residuals.py:45-53.
+ * w1 / w2 (C, C, K); c1 has dilation dil, c2 dilation 1.  fused = 1: the single-kernel form (resblock.hip);
+ * fused = 0: the two conv launches it replaces.  lens (B) optional per-item valid lengths. */
+int rvcx_op_resblock_pair(rvcx_ctx*, const float* x, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* y, int B, int C, int T, int K, int dil, float slope, int fused,
+                          const int32_t* lens);
+/* micro-benchmark of one ResBlock1 step on device-resident random data (fused kernel or the two launches) */
+int rvcx_bench_resblock_pair(rvcx_ctx*, int B, int C, int T, int K, int dil, int fused, int iters,
+                             float* ms_per_launch);
 /* micro-benchmark of the conv kernel on device-resident random data: `iters` back-to-back launches of
  * y = conv1d(lrelu(x)) + bias + res, average milliseconds per launch (HIP events on the library stream) */
 int rvcx_bench_conv1d(rvcx_ctx*, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,

@@ -63,7 +63,7 @@ SYMBOLS = [
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -171,6 +171,25 @@ class Context:
                                       C.c_float(0.0 if pre_lrelu is None else pre_lrelu), act,
                                       C.c_float(act_slope), _p(li, C.c_int32), _p(lo, C.c_int32)), "op_conv1d")
         return y
+
+    def resblock_pair(self, x, w1, b1, w2, b2, dil=1, slope=0.1, fused=True, lens=None):
+        x, w1, w2 = f32(x), f32(w1), f32(w2)
+        B, Cc, T = x.shape
+        K = w1.shape[2]
+        y = np.empty_like(x)
+        b1 = None if b1 is None else f32(b1)
+        b2 = None if b2 is None else f32(b2)
+        li = i32(lens)
+        self._ck(lib().rvcx_op_resblock_pair(self._h, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), B, Cc, T, K, dil,
+                                             C.c_float(slope), 1 if fused else 0, _p(li, C.c_int32)),
+                 "op_resblock_pair")
+        return y
+
+    def bench_resblock_pair(self, B, Cc, T, K, dil=1, fused=True, iters=10):
+        ms = C.c_float(0)
+        self._ck(lib().rvcx_bench_resblock_pair(self._h, B, Cc, T, K, dil, 1 if fused else 0, iters, C.byref(ms)),
+                 "bench_resblock_pair")
+        return ms.value, 4.0 * B * Cc * Cc * K * T / (ms.value * 1e-3) / 1e12
 
     @staticmethod
     def conv_override(tile=-1, variant=-1, splitk=-1):
@@ -463,6 +482,8 @@ class Context:
         def name(i):
             if kd[i] < 0:
                 return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
+            if kd[i] >= 500000:
+                return f"resblock_pair<C={kd[i] - 500000},N1={bn[i]}> (c1 -> c2 -> +x fused)"
             if kd[i] >= 400000:
                 c = kd[i] - 400000
                 return f"conv_h3<{bm[i]},{bn[i]},{'linear' if c == 1 else 'stride2' if c == 2 else 'halo%d' % c}>"

@@ -178,6 +178,134 @@ int rvcx_op_conv1d(rvcx_ctx* ctx, const float* x, const float* w, const float* b
   API_END
 }
 
+int rvcx_op_resblock_pair(rvcx_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* y, int B, int Cc, int T, int K, int dil, float slope, int fused,
+                          const int32_t* lens) {
+  API_BEGIN(ctx)
+  TEMP_REGION(C);
+  const size_t n = (size_t)B * Cc * T;
+  C->arena.reserve(n * 4 * 4 + (64 << 20));
+  C->arena.reset();
+  ConvW L1 = make_conv(*C, w1, b1, Cc, Cc, K, 1, true);
+  ConvW L2 = make_conv(*C, w2, b2, Cc, Cc, K, 1, true);
+  float* dx = to_dev(*C, x, n);
+  float* dt = C->arena.alloc<float>(n);
+  float* dy = C->arena.alloc<float>(n);
+  RVCX_HIP(hipMemsetAsync(dy, 0xff, n * 4, C->stream));      // NaN fill: every element must be written
+  const int* dl = to_dev_i(*C, lens, B);
+  if (fused) {
+    PairArgs pa;
+    pa.x = dx;
+    pa.y = dy;
+    pa.w1 = (L1.w_h3 && *L1.h3_ok) ? L1.w_h3 : nullptr;
+    pa.w2 = (L2.w_h3 && *L2.h3_ok) ? L2.w_h3 : nullptr;
+    pa.b1 = L1.bias;
+    pa.b2 = L2.bias;
+    pa.lens = dl;
+    pa.B = B;
+    pa.C = Cc;
+    pa.T = T;
+    pa.bs = (long)Cc * T;
+    pa.cs = T;
+    pa.k = K;
+    pa.dil = dil;
+    pa.slope = slope;
+    if (!resblock_pair_ok(pa)) fail("resblock pair: shape not supported by the fused kernel");
+    C->pair_on(pa, C->stream);
+  } else {   // the two launches the fused kernel replaces (synth.hip's fallback path)
+    ConvArgs a = conv1d_args(L1, dx, dt, B, T, T, 1, dil, (K * dil - dil) / 2);
+    a.pre_act = ACT_LRELU;
+    a.pre_slope = slope;
+    a.act = ACT_LRELU;
+    a.act_slope = slope;
+    a.lens_in = dl;
+    a.lens_out = dl;
+    ConvArgs a2 = conv1d_args(L2, dt, dy, B, T, T, 1, 1, (K - 1) / 2);
+    const bool split = conv_h3_split_ok(a) && conv_h3_split_ok(a2);
+    if (split) {
+      a.y_split = dt;
+      a.y = nullptr;
+    }
+    C->conv(a);
+    if (split) a2.x_split = dt;
+    conv_set_res(a2, dx, Cc, T);
+    a2.lens_in = dl;
+    a2.lens_out = dl;
+    C->conv(a2);
+  }
+  to_host(*C, y, dy, n);
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_bench_resblock_pair(rvcx_ctx* ctx, int B, int Cc, int T, int K, int dil, int fused, int iters,
+                             float* ms_per_launch) {
+  API_BEGIN(ctx)
+  TEMP_REGION(C);
+  const size_t n = (size_t)B * Cc * T;
+  C->arena.reserve(n * 4 * 4 + (64 << 20));
+  C->arena.reset();
+  std::vector<float> w((size_t)Cc * Cc * K), bias((size_t)Cc, 0.1f);
+  for (size_t i = 0; i < w.size(); ++i) w[i] = ((float)((i * 2654435761u) % 2001) / 1000.f - 1.f) / std::sqrt((float)Cc * K);
+  ConvW L1 = make_conv(*C, w.data(), bias.data(), Cc, Cc, K, 1, true);
+  ConvW L2 = make_conv(*C, w.data(), bias.data(), Cc, Cc, K, 1, true);
+  float* dx = C->arena.alloc<float>(n);
+  float* dt = C->arena.alloc<float>(n);
+  float* dy = C->arena.alloc<float>(n);
+  launch_randn(dx, n, 1, 0, C->stream);
+  PairArgs pa;
+  pa.x = dx;
+  pa.y = dy;
+  pa.w1 = L1.w_h3;
+  pa.w2 = L2.w_h3;
+  pa.b1 = L1.bias;
+  pa.b2 = L2.bias;
+  pa.B = B;
+  pa.C = Cc;
+  pa.T = T;
+  pa.bs = (long)Cc * T;
+  pa.cs = T;
+  pa.k = K;
+  pa.dil = dil;
+  ConvArgs a = conv1d_args(L1, dx, dt, B, T, T, 1, dil, (K * dil - dil) / 2);
+  a.pre_act = ACT_LRELU;
+  a.pre_slope = 0.1f;
+  a.act = ACT_LRELU;
+  a.act_slope = 0.1f;
+  ConvArgs a2 = conv1d_args(L2, dt, dy, B, T, T, 1, 1, (K - 1) / 2);
+  const bool split = conv_h3_split_ok(a) && conv_h3_split_ok(a2);
+  if (split) {
+    a.y_split = dt;
+    a.y = nullptr;
+    a2.x_split = dt;
+  }
+  conv_set_res(a2, dx, Cc, T);
+  auto once = [&]() {
+    if (fused) {
+      C->pair_on(pa, C->stream);
+    } else {
+      C->conv(a);
+      C->conv(a2);
+    }
+  };
+  if (fused && !resblock_pair_ok(pa)) fail("resblock pair: shape not supported by the fused kernel");
+  once();
+  hipEvent_t e0, e1;
+  RVCX_HIP(hipEventCreate(&e0));
+  RVCX_HIP(hipEventCreate(&e1));
+  RVCX_HIP(hipEventRecord(e0, C->stream));
+  for (int i = 0; i < iters; ++i) once();
+  RVCX_HIP(hipEventRecord(e1, C->stream));
+  RVCX_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RVCX_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_conv_override(int tile, int variant, int splitk) {
   rvcx::g_conv_override.tile = tile;
   rvcx::g_conv_override.variant = variant;

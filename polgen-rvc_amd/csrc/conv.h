@@ -69,6 +69,32 @@ inline int conv_tap_off(const ConvArgs& a, int kk) {
   return (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad;
 }
 
+// One ResBlock1 step fused into one kernel (resblock.hip): y = x + c2(lrelu(c1(lrelu(x)) + b1)) + b2
+struct PairArgs {
+  const float* x = nullptr;      // input and residual, (B, C, T) with batch stride bs / channel stride cs
+  float* y = nullptr;            // output (same strides) or null when only y2 is wanted
+  float* y2 = nullptr;           // running mean over the ResBlocks of a stage (acc2_mode), same strides
+  const void* w1 = nullptr;      // fp16 hi/lo images of the two convs (ConvW::w_h3)
+  const void* w2 = nullptr;
+  const float* b1 = nullptr;
+  const float* b2 = nullptr;
+  const int* lens = nullptr;     // per-item valid positions (null: T)
+  int B = 1, C = 0, T = 0;
+  long bs = 0;
+  int cs = 0;
+  int k = 1, dil = 1;            // c1: k taps, dilation dil; c2: k taps, dilation 1
+  float slope = 0.1f;
+  int acc2_mode = ACC2_NONE;
+  float acc2_div = 1.f;
+};
+bool resblock_pair_enabled();                                // RVCX_FUSE (default on) and the h3 kernels enabled
+bool resblock_pair_ok(const PairArgs& a);
+void launch_resblock_pair(const PairArgs& a, hipStream_t stream);              // raw launch (resblock.hip)
+void conv_launch_pair(const PairArgs& a, double flops, hipStream_t stream);    // + profile record (conv.hip)
+int resblock_pair_slot(int C);
+struct ConvProfile;
+void resblock_pair_describe(ConvProfile* p);
+
 struct ConvProfile {
   static constexpr int kMaxTiles = 56;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
   long launches[kMaxTiles] = {0};

@@ -194,6 +194,7 @@ void conv_profile_end(ConvProfile* out) {
   }
   conv_fast_describe(out);
   conv_h3_describe(out);
+  resblock_pair_describe(out);
   for (auto& r : g_prof) {
     RVCX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -209,6 +210,23 @@ void conv_profile_end(ConvProfile* out) {
     (void)hipEventDestroy(r.b);
   }
   g_prof.clear();
+}
+
+void conv_launch_pair(const PairArgs& a, double flops, hipStream_t stream) {
+  if (!g_prof_on) {
+    launch_resblock_pair(a, stream);
+    return;
+  }
+  ProfRec rec;
+  RVCX_HIP(hipEventCreate(&rec.a));
+  RVCX_HIP(hipEventCreate(&rec.b));
+  rec.tile = resblock_pair_slot(a.C);
+  rec.flops = flops;
+  rec.cin = a.C; rec.cout = a.C; rec.k = a.k; rec.nout = a.T; rec.stride = a.dil; rec.B = a.B;
+  RVCX_HIP(hipEventRecord(rec.a, stream));
+  launch_resblock_pair(a, stream);
+  RVCX_HIP(hipEventRecord(rec.b, stream));
+  g_prof.push_back(rec);
 }
 
 void launch_conv(ConvArgs a, hipStream_t stream) {

@@ -175,6 +175,11 @@ struct Ctx {
       }
     splitk_items = items;
   }
+  void pair_on(const PairArgs& a, hipStream_t s) {
+    const double f = 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * a.T;   // both convs, 2 M N K each
+    flops += f;
+    conv_launch_pair(a, f, s);
+  }
   void conv(const ConvArgs& a) { conv_on(a, stream); }
   void conv_on(ConvArgs a, hipStream_t s) {
     flops += conv_flops(a);

@@ -1,0 +1,347 @@
+// One step of ResBlock1 (rvc/lib/algorithm/residuals.py:45-53) as ONE kernel:
+//     xt = c1(leaky_relu(x));  xt = c2(leaky_relu(xt));  x = xt + x
+// c1: k taps, dilation d; c2: k taps, dilation 1; both C -> C channels, "same" zero padding.
+//
+// Unfused, the pair moves five activation tensors through HBM (read x, write xt, read xt, read x again as the
+// residual, write y) and re-stages the same input tile once per 32-channel output block.  Here a workgroup owns
+// ALL C channels of a tile of positions: the c1 output tile never leaves the CU -- it is written, already in the
+// fp16 hi/lo split form and element order the MFMA B operand wants, into LDS and consumed from there by c2; the
+// residual is re-read from the (L2-hot) x tile the workgroup just staged.  HBM traffic per pair: read x, write y.
+//
+// Arithmetic is exactly conv_h3_kernel's (same split, same MFMA order: chunks of 16 input channels ascending, taps
+// ascending, three MFMAs {S wh . xh, wh . S xl, S wl . xh} per block), so the fused step is bit-identical to the two
+// launches it replaces (tests/test_gpu_conv.py::test_fused_resblock_pair_equals_two_launches).
+//
+// Tile: N1 = 32 NT positions of the c1 output (= the c2 input tile incl. its (k-1)/2 halo on both sides); the
+// workgroup stores BN = N1 - (k-1) output positions.  LDS: Y1[C/16][op][h][N1 + 16] + As[KKT][op][h][C] +
+// Bs[op][h][N1 + 64], 16-byte elements (8 halves = the k-slice one lane feeds to one MFMA).
+#include <algorithm>
+#include <cstdlib>
+
+#include "conv.h"
+#include "conv_device.h"
+#include "h3_device.h"
+
+namespace rvcx {
+
+namespace {
+
+constexpr int kPairHalo = 64;    // (k - 1) d <= 50 for k <= 11, d <= 5
+constexpr int kPairPadY = 16;    // c2 reads up to k - 1 <= 10 columns past N1 (for output columns that are discarded)
+
+template <int C, int NT, int WR, int WC, int KKT>
+__global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairArgs a) {
+  constexpr int THREADS = 64 * WR * WC;
+  constexpr int N1 = 32 * NT, N1P = N1 + kPairPadY, WROW = N1 + kPairHalo;
+  constexpr int WM = (C / 32) / WR, WN = NT / WC;
+  constexpr int NCHUNK = C / 16;
+  constexpr int A_ELEMS = KKT * 4 * C, NA = (A_ELEMS + THREADS - 1) / THREADS;
+  constexpr int B_TASKS = 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
+  static_assert(WM >= 1 && WN >= 1 && WM * WR * 32 == C && WN * WC == NT, "bad tile");
+  extern __shared__ uint4 lds[];
+  uint4* Y1 = lds;                              // [chunk][op][h][N1P]
+  uint4* As = Y1 + NCHUNK * 4 * N1P;            // [kkl][op][h][C]
+  uint4* Bs = As + A_ELEMS;                     // [op][h][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int k = a.k, h2 = (k - 1) / 2, pad1 = (k - 1) * a.dil / 2;
+  const int bn_out = N1 - (k - 1);
+  const int n0 = blockIdx.x * bn_out;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int wuse = N1 + (k - 1) * a.dil;        // input columns the tile really needs
+  const int in_base = n0 - h2 - pad1;           // position of input-tile column 0
+  const float slope = a.slope;
+  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.bs, C * a.cs * 4);
+  const H3Rsrc w1r = h3_rsrc(a.w1, k * NCHUNK * 4 * C * 16);
+  const H3Rsrc w2r = h3_rsrc(a.w2, k * NCHUNK * 4 * C * 16);
+  const int xrow = a.cs * 4;
+  constexpr int slab = 4 * C * 16;              // bytes of one (tap, chunk) weight slab
+
+  f32x16 acc[WM][WN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  // chunk-invariant addressing
+  int a_kkl[NA], a_off[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int e = tid + THREADS * j;
+    const int co = e % C, rest = e / C;          // rest = (kkl*2 + op)*2 + h
+    a_kkl[j] = rest / 4;
+    a_off[j] = e < A_ELEMS ? ((rest % 4) * C + co) * 16 : kH3Oob;
+  }
+  int b_off[NBT], b_row[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) {
+    const int t = tid + THREADS * j;
+    const int hh = t / WROW, p = t - hh * WROW;
+    const int pos = in_base + p;
+    b_row[j] = hh * 8;
+    b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len) ? pos * 4 : kH3Oob;
+  }
+
+  uint4 ra[NA];
+  float rb[NBT][8];
+  auto fetch_b = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int row0 = (chunk * 16 + b_row[j]) * xrow;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
+    }
+  };
+  auto fetch_a = [&](const H3Rsrc& wr_, int chunk, int kk0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int kk = kk0 + a_kkl[j];
+      const bool ok = a_off[j] != kH3Oob && kk < k;
+      ra[j] = h3_load4(wr_, ok ? (kk * NCHUNK + chunk) * slab + a_off[j] : kH3Oob);
+    }
+  };
+  auto commit_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (NA * THREADS == A_ELEMS || tid + THREADS * j < A_ELEMS) As[tid + THREADS * j] = ra[j];
+  };
+  auto commit_b = [&]() {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + THREADS * j;
+      if (NBT * THREADS == B_TASKS || t < B_TASKS) {
+        half8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v = rb[j][q];
+          v = v > 0.f ? v : v * slope;                 // leaky_relu ahead of c1
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        const int hh = t / WROW, p = t - hh * WROW;
+        Bs[(0 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
+        Bs[(1 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+      }
+    }
+  };
+  // one (<= KKT taps) x (16 channels) k-step group on the tile Bt (taps advance by `tap_step` columns)
+  auto compute = [&](const uint4* Bt, int pitch, int kk0, int tap_step) {
+#pragma unroll
+    for (int kkl = 0; kkl < KKT; ++kkl) {
+      const int kk = kk0 + kkl;
+      if (kk < k) {
+        const int tp = kk * tap_step;
+        half8 af[3][WM], bf[2][WN];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          af[0][m] = __builtin_bit_cast(half8, As[((kkl * 2 + 0) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+          af[2][m] = __builtin_bit_cast(half8, As[((kkl * 2 + 1) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+          af[1][m] = af[0][m] * (_Float16)(1.f / kH3Scale);
+        }
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+          for (int n = 0; n < WN; ++n)
+            bf[op][n] = __builtin_bit_cast(half8, Bt[(op * 2 + h) * pitch + wc * (WN * 32) + n * 32 + i + tp]);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) {
+            acc[m][n] = h3_mfma(af[0][m], bf[0][n], acc[m][n]);
+            acc[m][n] = h3_mfma(af[1][m], bf[1][n], acc[m][n]);
+            acc[m][n] = h3_mfma(af[2][m], bf[0][n], acc[m][n]);
+          }
+      }
+    }
+  };
+  const int nkk = (k + KKT - 1) / KKT;
+  const int nst = NCHUNK * nkk;
+  constexpr float inv = 1.f / kH3Scale;
+
+  // ================================================================ phase 1: Y1 = lrelu(c1(lrelu(x)) + b1)
+  zero_acc();
+  fetch_b(0);
+  fetch_a(w1r, 0, 0);
+  {
+    int chunk = 0, kk0 = 0;
+    for (int st = 0; st < nst; ++st) {
+      __syncthreads();
+      if (kk0 == 0) commit_b();
+      commit_a();
+      __syncthreads();
+      int kk1 = kk0 + KKT, chunk1 = chunk;
+      if (kk1 >= k) {
+        kk1 = 0;
+        chunk1 += 1;
+      }
+      if (st + 1 < nst) fetch_a(w1r, chunk1, kk1);
+      else fetch_a(w2r, 0, 0);                       // first weights of c2 fly during the c1 epilogue
+      if (kk0 == 0 && chunk + 1 < NCHUNK) fetch_b(chunk + 1);
+      compute(Bs, WROW, kk0, a.dil);
+      kk0 = kk1;
+      chunk = chunk1;
+    }
+  }
+  // c1 epilogue: bias, leaky_relu (the one ahead of c2), zero outside the sequence, split, into LDS
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      const int c_t = wr * (WM * 32) + m * 32;
+      const int j = wc * (WN * 32) + n * 32 + i;
+      const int pos1 = n0 - h2 + j;
+      const bool live = pos1 >= 0 && pos1 < len;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const int cg = c_t + 8 * g;
+        half4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[m][n][4 * g + q] * inv + (a.b1 ? a.b1[cg + 4 * h + q] : 0.f);
+          v = fmaxf(v, v * slope);
+          v = live ? v : 0.f;
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        char* e_hi = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 0) * 2 + (g & 1)) * N1P + j) + 8 * h;
+        char* e_lo = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 1) * 2 + (g & 1)) * N1P + j) + 8 * h;
+        *reinterpret_cast<half4*>(e_hi) = hi;
+        *reinterpret_cast<half4*>(e_lo) = lo;
+      }
+    }
+
+  // ================================================================ phase 2: y = c2(Y1) + b2 + x
+  zero_acc();
+  {
+    int chunk = 0, kk0 = 0;
+    for (int st = 0; st < nst; ++st) {
+      __syncthreads();
+      commit_a();
+      __syncthreads();
+      int kk1 = kk0 + KKT, chunk1 = chunk;
+      if (kk1 >= k) {
+        kk1 = 0;
+        chunk1 += 1;
+      }
+      if (st + 1 < nst) fetch_a(w2r, chunk1, kk1);
+      compute(Y1 + chunk * 4 * N1P, N1P, kk0, 1);
+      kk0 = kk1;
+      chunk = chunk1;
+    }
+  }
+  // c2 epilogue: bias, residual (x itself: L2-hot, this workgroup staged it a moment ago), length mask, store
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      const int col = wc * (WN * 32) + n * 32 + i;
+      const int pos = n0 + col;
+      if (col >= bn_out || pos >= a.T) continue;
+      const bool live = pos < len;
+      const int co_base = wr * (WM * 32) + m * 32 + 4 * h;
+      const float* xb = a.x + (long)b * a.bs + pos;
+      float* yb = a.y ? a.y + (long)b * a.bs + pos : nullptr;
+      float* y2b = a.acc2_mode != ACC2_NONE ? a.y2 + (long)b * a.bs + pos : nullptr;
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float bv[8], rv[8], pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int co = co_base + ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+          bv[q] = a.b2 ? a.b2[co] : 0.f;
+          rv[q] = xb[(long)co * a.cs];
+          pv[q] = (y2b && a.acc2_mode != ACC2_SET) ? y2b[(long)co * a.cs] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int co = co_base + ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+          float v = acc[m][n][r0 + q] * inv + bv[q];
+          v = v + rv[q];
+          v = live ? v : 0.f;
+          if (yb) yb[(long)co * a.cs] = v;
+          if (y2b) {
+            float* p2 = y2b + (long)co * a.cs;
+            if (a.acc2_mode == ACC2_SET) *p2 = v;
+            else if (a.acc2_mode == ACC2_ADD) *p2 = pv[q] + v;
+            else *p2 = (pv[q] + v) / a.acc2_div;
+          }
+        }
+      }
+    }
+}
+
+struct PairCfg {
+  int C, n1, threads;
+  size_t lds;
+  void (*kern)(const PairArgs);
+};
+template <int C, int NT, int WR, int WC, int KKT>
+constexpr PairCfg make_cfg() {
+  return {C, 32 * NT, 64 * WR * WC,
+          (size_t)((C / 16) * 4 * (32 * NT + kPairPadY) + KKT * 4 * C + 4 * (32 * NT + kPairHalo)) * 16,
+          resblock_pair_kernel<C, NT, WR, WC, KKT>};
+}
+const PairCfg kPair[] = {
+    make_cfg<32, 8, 1, 4, 4>(),
+    make_cfg<64, 8, 2, 4, 4>(),
+    make_cfg<128, 4, 4, 2, 4>(),
+};
+int g_pair_mode = -1;
+
+}  // namespace
+
+bool resblock_pair_enabled() {
+  if (g_pair_mode < 0) g_pair_mode = getenv("RVCX_FUSE") ? atoi(getenv("RVCX_FUSE")) : 1;
+  return g_pair_mode != 0 && conv_h3_enabled();
+}
+
+bool resblock_pair_ok(const PairArgs& a) {
+  if (!resblock_pair_enabled() || !a.w1 || !a.w2) return false;
+  if (a.k < 1 || a.k > 11 || a.dil < 1 || (a.k - 1) * a.dil > kPairHalo - 14 || (a.k & 1) == 0) return false;
+  if ((long)a.C * a.cs * 4 >= kH3Oob || (long)a.k * a.C * a.C * 4 >= kH3Oob) return false;
+  for (const auto& c : kPair)
+    if (c.C == a.C) return true;
+  return false;
+}
+
+int resblock_pair_slot(int C) { return C == 32 ? 50 : (C == 64 ? 51 : 52); }
+
+void resblock_pair_describe(ConvProfile* p) {
+  for (const auto& c : kPair) {
+    const int s = resblock_pair_slot(c.C);
+    p->bm[s] = c.C;
+    p->bn[s] = c.n1;
+    p->halo[s] = 500000 + c.C;
+  }
+}
+
+void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
+  RVCX_CHECK(resblock_pair_ok(a), "resblock pair: unsupported shape");
+  static const bool init = [] {       // once per process, also when several contexts start on different threads
+    for (const auto& c : kPair)
+      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)c.lds));
+    return true;
+  }();
+  (void)init;
+  for (const auto& c : kPair)
+    if (c.C == a.C) {
+      const int bn_out = c.n1 - (a.k - 1);
+      dim3 grid(cdiv(a.T, bn_out), 1, a.B);
+      hipLaunchKernelGGL(c.kern, grid, dim3(c.threads), c.lds, stream, a);
+      RVCX_HIP(hipGetLastError());
+      return;
+    }
+}
+
+}  // namespace rvcx

@@ -1,7 +1,9 @@
 // Synthesizer.infer (rvc/lib/algorithm/synthesizers.py:163-188): TextEncoder -> z sampling ->
 // reverse ResidualCouplingBlock -> GeneratorNSF, as a sequence of MFMA conv launches with fused
 // epilogues plus a few memory-bound glue kernels.  Layout: (B, C, T) channel-first, T contiguous.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "models.h"
 #include "ops.h"
@@ -325,110 +327,151 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   tm.mark(2);
 
   // ================================================================ NSF-HiFi-GAN decoder
+  // The decoder runs `db` utterances at a time (default ONE) even inside a batch: its activations are ~200 MB
+  // per tensor and utterance, and at one utterance the producer -> consumer hand-off between consecutive layers is
+  // largely served by the 256 MB Infinity Cache.  Measured with B = 8 in one launch sequence: 22.4 ms per clip
+  // against 16.5 ms one at a time (every layer then streams from HBM) -- RVCX_DEC_BATCH overrides.
   if (!c.serial) RVCX_HIP(hipStreamWaitEvent(s, c.ev_src[1], 0));
+  static const int dec_batch = getenv("RVCX_DEC_BATCH") ? std::max(1, atoi(getenv("RVCX_DEC_BATCH"))) : 1;
   const int C0 = cf.up_initial_channel;
-  float* cur = A.alloc<float>((size_t)B * C0 * T);
-  {
-    ConvArgs a = conv1d_args(m.conv_pre, z, cur, B, T, T, 1, 1, 3);
-    a.lens_in = lens;
-    c.conv(a);
-    float* gcond = A.alloc<float>((size_t)B * C0);
-    a = conv1d_args(m.cond, g, gcond, B, 1, 1);
-    c.conv(a);
-    launch_add_channel_bias(cur, gcond, B, C0, T, s);
-  }
-  long Tin = T;
-  for (size_t i = 0; i < m.stages.size(); ++i) {
-    const auto& S = m.stages[i];
-    const long Tout = Tin * cf.up_rates[i];
-    const size_t n = (size_t)B * S.ch * Tout;
-    float* xs = A.alloc<float>(n);      // survives the stage (next stage's input)
-    const size_t stage_mark = A.mark();
-    float* xu = A.alloc<float>(n);
-    const int nk = cf.n_resblocks;
-    float* xcb[4];
-    float* xtb[4];
-    for (int j = 0; j < nk; ++j) {
-      xcb[j] = A.alloc<float>(n);
-      xtb[j] = A.alloc<float>(n);
+  const size_t dec_mark = A.mark();
+  for (int b0 = 0; b0 < B; b0 += dec_batch) {
+    const int db = std::min(dec_batch, B - b0);
+    A.reset(dec_mark);
+    float* cur = A.alloc<float>((size_t)db * C0 * T);
+    {
+      ConvArgs a = conv1d_args(m.conv_pre, z + (size_t)b0 * inter * T, cur, db, T, T, 1, 1, 3);
+      a.lens_in = lens ? lens + b0 : nullptr;
+      c.conv(a);
+      float* gcond = A.alloc<float>((size_t)db * C0);
+      a = conv1d_args(m.cond, g + (size_t)b0 * gin, gcond, db, 1, 1);
+      c.conv(a);
+      launch_add_channel_bias(cur, gcond, db, C0, T, s);
     }
-    const int* lin = lens_stage[i];
-    const int* lout = lens_stage[i + 1];
-    ConvArgs a = convT1d_args(S.up, cur, xu, B, (int)Tin, (int)Tout);
-    a.pre_act = ACT_LRELU;
-    a.pre_slope = 0.1f;
-    a.lens_in = lin;
-    a.lens_out = lout;
-    conv_set_res(a, nz[i], S.ch, (int)Tout);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
-    c.conv(a);
-    // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
-    // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases
-    // interleave on the CUs instead of marching in lockstep.  Only the running sum xs is ordered
-    // (SET -> ADD -> ADD_DIV) through events.
-    const bool side = c.resblock_streams && !c.serial;   // measured gain ~3.5 %; RVCX_RESBLOCK_STREAMS=0 turns it off
-    hipStream_t rs[4] = {s, side ? c.aux[0] : s, side ? c.aux[1] : s, s};
-    RVCX_HIP(hipEventRecord(c.ev_aux[0], s));
-    for (int j = 1; j < nk && j < 3; ++j) RVCX_HIP(hipStreamWaitEvent(rs[j], c.ev_aux[0], 0));
-    for (int j = 0; j < nk; ++j) {
-      hipStream_t sj = rs[j];
-      const int k = cf.res_kernels[j];
-      const float* xin = xu;
-      float* xc = xcb[j];
-      float* xt = xtb[j];
-      for (int mi = 0; mi < 3; ++mi) {
-        const int d = cf.res_dilations[j][mi];
-        a = conv1d_args(S.c1[j][mi], xin, xt, B, (int)Tout, (int)Tout, 1, d, (k * d - d) / 2);
-        a.pre_act = ACT_LRELU;
-        a.pre_slope = 0.1f;
-        a.act = ACT_LRELU;       // the leaky_relu that precedes c2, applied once here
-        a.act_slope = 0.1f;
-        a.lens_in = lout;
-        a.lens_out = lout;
-        // c1 -> c2 hand-off: when both run on the split-fp16 kernels, xt travels already split (hi / scaled lo
-        // halves in the consumer's LDS element order): c2 stages it with 16-byte loads and no conversion
-        ConvArgs a2 = conv1d_args(S.c2[j][mi], xt, xc, B, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
-        const bool split = conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
-        if (split) {
-          a.y_split = xt;
-          a.y = nullptr;
-        }
-        c.conv_on(a, sj);
-        a = a2;
-        if (split) a.x_split = xt;
-        conv_set_res(a, xin, S.ch, (int)Tout);
-        a.lens_in = lout;
-        a.lens_out = lout;
-        if (mi == 2) {           // last conv of the block: accumulate into xs, skip the plain store
-          a.y = nullptr;
-          a.y2 = xs;
-          a.y2_bs = (long)S.ch * Tout;
-          a.y2_cs = (int)Tout;
-          a.acc2_mode = j == 0 ? ACC2_SET : (j == nk - 1 ? ACC2_ADD_DIV : ACC2_ADD);
-          a.acc2_div = (float)nk;
-          if (nk == 1) a.acc2_mode = ACC2_SET;
-          if (j > 0) RVCX_HIP(hipStreamWaitEvent(sj, c.ev_aux[j], 0));   // xs of block j-1 is complete
-        }
-        c.conv_on(a, sj);
-        if (mi == 2) RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
-        xin = xc;
+    long Tin = T;
+    for (size_t i = 0; i < m.stages.size(); ++i) {
+      const auto& S = m.stages[i];
+      const long Tout = Tin * cf.up_rates[i];
+      const size_t n = (size_t)db * S.ch * Tout;
+      float* xs = A.alloc<float>(n);      // survives the stage (next stage's input)
+      const size_t stage_mark = A.mark();
+      float* xu = A.alloc<float>(n);
+      const int nk = cf.n_resblocks;
+      float* xcb[4];
+      float* xtb[4];
+      for (int j = 0; j < nk; ++j) {
+        xcb[j] = A.alloc<float>(n);
+        xtb[j] = A.alloc<float>(n);
       }
+      const int* lin = lens_stage[i] ? lens_stage[i] + b0 : nullptr;
+      const int* lout = lens_stage[i + 1] ? lens_stage[i + 1] + b0 : nullptr;
+      ConvArgs a = convT1d_args(S.up, cur, xu, db, (int)Tin, (int)Tout);
+      a.pre_act = ACT_LRELU;
+      a.pre_slope = 0.1f;
+      a.lens_in = lin;
+      a.lens_out = lout;
+      conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout, S.ch, (int)Tout);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
+      c.conv(a);
+      // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
+      // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases
+      // interleave on the CUs instead of marching in lockstep.  Only the running sum xs is ordered
+      // (SET -> ADD -> ADD_DIV) through events.
+      const bool side = c.resblock_streams && !c.serial;   // measured gain ~3.5 %; RVCX_RESBLOCK_STREAMS=0 turns it off
+      hipStream_t rs[4] = {s, side ? c.aux[0] : s, side ? c.aux[1] : s, s};
+      RVCX_HIP(hipEventRecord(c.ev_aux[0], s));
+      for (int j = 1; j < nk && j < 3; ++j) RVCX_HIP(hipStreamWaitEvent(rs[j], c.ev_aux[0], 0));
+      for (int j = 0; j < nk; ++j) {
+        hipStream_t sj = rs[j];
+        const int k = cf.res_kernels[j];
+        const float* xin = xu;
+        float* xc = xcb[j];
+        float* xt = xtb[j];
+        for (int mi = 0; mi < 3; ++mi) {
+          const int d = cf.res_dilations[j][mi];
+          // ---- fused step (resblock.hip): c1 -> c2 -> + x in one kernel, xt never leaves the CU
+          {
+            PairArgs pa;
+            pa.x = xin;
+            pa.y = xc;
+            pa.w1 = (S.c1[j][mi].w_h3 && S.c1[j][mi].h3_ok && *S.c1[j][mi].h3_ok) ? S.c1[j][mi].w_h3 : nullptr;
+            pa.w2 = (S.c2[j][mi].w_h3 && S.c2[j][mi].h3_ok && *S.c2[j][mi].h3_ok) ? S.c2[j][mi].w_h3 : nullptr;
+            pa.b1 = S.c1[j][mi].bias;
+            pa.b2 = S.c2[j][mi].bias;
+            pa.lens = lout;
+            pa.B = db;
+            pa.C = S.ch;
+            pa.T = (int)Tout;
+            pa.bs = (long)S.ch * Tout;
+            pa.cs = (int)Tout;
+            pa.k = k;
+            pa.dil = d;
+            pa.slope = 0.1f;
+            if (S.c1[j][mi].cin == S.ch && S.c1[j][mi].cout == S.ch && S.c2[j][mi].k == k && resblock_pair_ok(pa)) {
+              if (mi == 2) {
+                pa.y = nullptr;
+                pa.y2 = xs;
+                pa.acc2_mode = j == 0 ? ACC2_SET : (j == nk - 1 ? ACC2_ADD_DIV : ACC2_ADD);
+                pa.acc2_div = (float)nk;
+                if (nk == 1) pa.acc2_mode = ACC2_SET;
+                if (j > 0) RVCX_HIP(hipStreamWaitEvent(sj, c.ev_aux[j], 0));   // xs of block j-1 is complete
+              }
+              c.pair_on(pa, sj);
+              if (mi == 2) RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
+              xin = xc;
+              continue;
+            }
+          }
+          a = conv1d_args(S.c1[j][mi], xin, xt, db, (int)Tout, (int)Tout, 1, d, (k * d - d) / 2);
+          a.pre_act = ACT_LRELU;
+          a.pre_slope = 0.1f;
+          a.act = ACT_LRELU;       // the leaky_relu that precedes c2, applied once here
+          a.act_slope = 0.1f;
+          a.lens_in = lout;
+          a.lens_out = lout;
+          // c1 -> c2 hand-off: when both run on the split-fp16 kernels, xt travels already split (hi / scaled lo
+          // halves in the consumer's LDS element order): c2 stages it with 16-byte loads and no conversion
+          ConvArgs a2 = conv1d_args(S.c2[j][mi], xt, xc, db, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
+          const bool split = conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
+          if (split) {
+            a.y_split = xt;
+            a.y = nullptr;
+          }
+          c.conv_on(a, sj);
+          a = a2;
+          if (split) a.x_split = xt;
+          conv_set_res(a, xin, S.ch, (int)Tout);
+          a.lens_in = lout;
+          a.lens_out = lout;
+          if (mi == 2) {           // last conv of the block: accumulate into xs, skip the plain store
+            a.y = nullptr;
+            a.y2 = xs;
+            a.y2_bs = (long)S.ch * Tout;
+            a.y2_cs = (int)Tout;
+            a.acc2_mode = j == 0 ? ACC2_SET : (j == nk - 1 ? ACC2_ADD_DIV : ACC2_ADD);
+            a.acc2_div = (float)nk;
+            if (nk == 1) a.acc2_mode = ACC2_SET;
+            if (j > 0) RVCX_HIP(hipStreamWaitEvent(sj, c.ev_aux[j], 0));   // xs of block j-1 is complete
+          }
+          c.conv_on(a, sj);
+          if (mi == 2) RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
+          xin = xc;
+        }
+      }
+      if (rs[nk - 1] != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_aux[nk], 0));   // join before the next stage
+      cur = xs;
+      Tin = Tout;
+      A.reset(stage_mark);
     }
-    if (rs[nk - 1] != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_aux[nk], 0));   // join before the next stage
-    cur = xs;
-    Tin = Tout;
-    A.reset(stage_mark);
-  }
-  {
-    // x = leaky_relu(x) [default slope 0.01, nsf.py:142]; tanh(conv_post(x))
-    const auto& S = m.stages.back();
-    ConvArgs a = conv1d_args(m.conv_post, cur, io.out, B, (int)Tin, (int)Tin, 1, 1, 3);
-    a.pre_act = ACT_LRELU;
-    a.pre_slope = 0.01f;
-    a.act = ACT_TANH;
-    a.lens_in = lens_stage[m.stages.size()];
-    a.lens_out = lens_stage[m.stages.size()];
-    (void)S;
-    c.conv(a);
+    {
+      // x = leaky_relu(x) [default slope 0.01, nsf.py:142]; tanh(conv_post(x))
+      ConvArgs a = conv1d_args(m.conv_post, cur, io.out + (size_t)b0 * Tupp, db, (int)Tin, (int)Tin, 1, 1, 3);
+      a.pre_act = ACT_LRELU;
+      a.pre_slope = 0.01f;
+      a.act = ACT_TANH;
+      a.lens_in = lens_stage[m.stages.size()] ? lens_stage[m.stages.size()] + b0 : nullptr;
+      a.lens_out = a.lens_in;
+      c.conv(a);
+    }
   }
   tm.mark(3);
 }

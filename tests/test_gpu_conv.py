@@ -180,3 +180,34 @@ def test_every_3x3_tile_stores_every_subtile(ctx, tile):
         assert np.array_equal(got, ref)
     finally:
         ctx.conv_override(-1, -1, -1)
+
+
+@pytest.mark.parametrize("C,K,d,T", [(32, 3, 1, 5000), (32, 11, 5, 777), (64, 7, 3, 4099), (64, 11, 5, 300),
+                                     (128, 3, 1, 1000), (128, 7, 1, 2500), (128, 11, 5, 1531), (128, 11, 3, 100)])
+def test_fused_resblock_pair_equals_two_launches(ctx, C, K, d, T):
+    """One ResBlock1 step (residuals.py:45-53) as one kernel (resblock.hip): against torch fp32 within fp32
+    rounding, and bit-identical to the two conv_h3 launches it replaces -- ragged batch (per-item lengths,
+    one of them shorter than a tile) included; every output element is written (NaN-filled destination)."""
+    g = torch.Generator().manual_seed(C * 100 + K)
+    B = 3
+    x = torch.randn(B, C, T, generator=g)
+    w1 = torch.randn(C, C, K, generator=g) / (C * K) ** 0.5
+    w2 = torch.randn(C, C, K, generator=g) / (C * K) ** 0.5
+    b1, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    lens = np.array([T, max(1, T // 2 + 3), min(T, 17)], np.int32)
+    xm = x.clone()
+    for b in range(B):
+        xm[b, :, lens[b]:] = 0
+    ref = torch.zeros_like(x)
+    for b in range(B):       # each item alone at its own length: exactly the semantics of the batched kernels
+        xb = xm[b:b + 1, :, :lens[b]]
+        t = F.conv1d(F.leaky_relu(xb, 0.1), w1, b1, dilation=d, padding=(K * d - d) // 2)
+        t = F.conv1d(F.leaky_relu(t, 0.1), w2, b2, padding=(K - 1) // 2)
+        ref[b, :, :lens[b]] = t + xb
+    fused = ctx.resblock_pair(xm.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), dil=d, lens=lens)
+    two = ctx.resblock_pair(xm.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), dil=d, lens=lens, fused=False)
+    assert np.isfinite(fused).all()
+    e = rms(fused - ref.numpy()) / rms(ref.numpy())
+    print(f"C={C} k={K} d={d} T={T}: fused vs torch rel err {e:.2e}; equal to two launches: {np.array_equal(fused, two)}")
+    assert e < 2e-6
+    assert np.array_equal(fused, two)

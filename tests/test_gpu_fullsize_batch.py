@@ -167,3 +167,71 @@ def test_voice_model_regions_are_freed_on_unload(ctx):
         ctx.load_index(big)
     ctx.load_index(None)
     assert base - free_bytes() < (64 << 20)
+
+
+def _fixture_noise(cfg, chunk_len, tgt_sr, noise_seed):
+    """The two Gaussian draws of a reference run, regenerated from the private generator's seed the fixture
+    records (tools/gen_golden.py: z first, then the source noise)."""
+    import torch
+    T = chunk_len // (tgt_sr // 100)
+    gen = torch.Generator().manual_seed(int(noise_seed))
+    z = torch.randn((1, cfg[2], T), generator=gen)
+    src = torch.randn((1, T * (tgt_sr // 100), 1), generator=gen)
+    return np.concatenate([z.numpy().ravel(), src.numpy().ravel()])
+
+
+def _check_vs_fixture(d, pre, pcm, f32, tgt_sr):
+    stride = int(d[pre + "stride"])
+    n_raw = int(d[pre + "chunk_lens"][0])
+    assert len(pcm) == n_raw - 2 * tgt_sr
+    diff = np.abs(pcm[::stride].astype(np.int32) - d[pre + "pcm_samples"].astype(np.int32))
+    idx = np.arange(0, n_raw, stride)
+    keep = (idx >= tgt_sr) & (idx < n_raw - tgt_sr)
+    e = rms(f32[idx[keep] - tgt_sr] - d[pre + "raw_samples"][keep])
+    blocks = 0
+    for b, ref in enumerate(d[pre + "block_rms"]):            # every sample: per-4096-block RMS of the reference output
+        lo, hi = b * 4096, min(n_raw, (b + 1) * 4096)
+        if lo >= tgt_sr and hi <= n_raw - tgt_sr:
+            assert abs(rms(f32[lo - tgt_sr: hi - tgt_sr]) - float(ref)) <= 2e-4 * max(1.0, float(ref)) + 5e-6, b
+            blocks += 1
+    return e, int(diff.max()), float(np.mean(diff > 1)), blocks
+
+
+def test_c5_two_resident_models_interleaved_vs_reference(ctx):
+    """BASELINE configs[4] in small, against the REFERENCE (fixture pipeline_c5_two_models, produced by the
+    reference's own VC.pipeline): a 40 k and a 48 k voice model at full size share one HuBERT and one RMVPE in a
+    context; utterances of different lengths are converted alternately, twice -- every result matches the
+    reference within 1e-4 RMS (float) / 8 LSB (PCM) and repeats bit for bit."""
+    import json
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_c5_two_models.npz"))
+    seed = int(d["seed"])
+    hcfg, rcfg = json.loads(str(d["hcfg"])), json.loads(str(d["rcfg"]))
+    ctx.load_hubert(W.hubert_cfg_struct(hcfg), S.hubert_state(hcfg, seed))
+    ctx.load_rmvpe(W.rmvpe_cfg_struct(rcfg), S.rmvpe_state(rcfg, seed))
+    mids, utts = {}, []
+    try:
+        for u in range(int(d["n_utts"])):
+            pre = f"u{u}_"
+            scfg = json.loads(str(d[pre + "scfg"]))
+            key = (scfg[-1], int(d[pre + "synth_seed"]))
+            if key not in mids:
+                mids[key] = ctx.load_synth(W.synth_cfg_struct(scfg, 768), S.synth_state(scfg, key[1]))
+            utts.append((pre, scfg, mids[key], S.make_clip(int(d[pre + "clip"]), float(d[pre + "seconds"]))))
+        assert len(mids) == 2 and {k[0] for k in mids} == {40000, 48000}
+        first = {}
+        for rnd in range(2):
+            for pre, scfg, mid, clip in utts:                   # alternates 40 k / 48 k / 48 k
+                tgt = scfg[-1]
+                noise = _fixture_noise(scfg, int(d[pre + "chunk_lens"][0]), tgt, d[pre + "noise_seed"])
+                pcm, f32 = ctx.convert_batch(mid, [clip], _params(), noises=[noise], want_f32=True)
+                if rnd == 0:
+                    e, dmax, frac, blocks = _check_vs_fixture(d, pre, pcm[0], f32[0], tgt)
+                    print(f"{pre} {tgt} Hz: float rms err {e:.3e}, pcm max diff {dmax} LSB, {blocks} blocks")
+                    assert e < 1e-4 and dmax <= 8 and frac < 0.02 and blocks > 20
+                    first[pre] = pcm[0]
+                else:
+                    assert np.array_equal(first[pre], pcm[0])
+    finally:
+        for mid in mids.values():
+            _lib.lib().rvcx_unload_synth(ctx._h, mid)
