@@ -17,6 +17,7 @@
 // Bs[op][h][N1 + 64], 16-byte elements (8 halves = the k-slice one lane feeds to one MFMA).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv.h"
 #include "conv_device.h"
@@ -29,34 +30,41 @@ namespace {
 constexpr int kPairHalo = 64;    // (k - 1) d <= 50 for k <= 11, d <= 5
 constexpr int kPairPadY = 16;    // c2 reads up to k - 1 <= 10 columns past N1 (for output columns that are discarded)
 
-template <int C, int NT, int WR, int WC, int KKT>
+// K: taps (compile time: the k-loop is straight-line code, fragment reads of slot s+1 are issued ahead of the MFMAs
+// of slot s).  A stage = NCS chunks of 16 input channels x a group of <= KKT taps ("slots"); NCS > 1 only with
+// KKT == K (small kernels: more MFMA work between two barriers).
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS>
 __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairArgs a) {
   constexpr int THREADS = 64 * WR * WC;
   constexpr int N1 = 32 * NT, N1P = N1 + kPairPadY, WROW = N1 + kPairHalo;
   constexpr int WM = (C / 32) / WR, WN = NT / WC;
   constexpr int NCHUNK = C / 16;
-  constexpr int A_ELEMS = KKT * 4 * C, NA = (A_ELEMS + THREADS - 1) / THREADS;
-  constexpr int B_TASKS = 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
+  constexpr int NG = (K + KKT - 1) / KKT;                 // tap groups per chunk set
+  constexpr int SL = NCS * KKT;                           // weight slots resident per stage
+  constexpr int A_ELEMS = SL * 4 * C, NA = (A_ELEMS + THREADS - 1) / THREADS;
+  constexpr int B_TASKS = NCS * 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
+  constexpr int BN_OUT = N1 - (K - 1), H2 = (K - 1) / 2;
   static_assert(WM >= 1 && WN >= 1 && WM * WR * 32 == C && WN * WC == NT, "bad tile");
+  static_assert(NCS == 1 || KKT == K, "several chunks per stage only with all taps resident");
+  static_assert(NCHUNK % NCS == 0, "chunk sets must tile the channels");
   extern __shared__ uint4 lds[];
   uint4* Y1 = lds;                              // [chunk][op][h][N1P]
-  uint4* As = Y1 + NCHUNK * 4 * N1P;            // [kkl][op][h][C]
-  uint4* Bs = As + A_ELEMS;                     // [op][h][WROW]
+  uint4* As = Y1 + NCHUNK * 4 * N1P;            // [slot][op][h][C]
+  uint4* Bs = As + A_ELEMS;                     // [cl][op][h][WROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
-  const int k = a.k, h2 = (k - 1) / 2, pad1 = (k - 1) * a.dil / 2;
-  const int bn_out = N1 - (k - 1);
-  const int n0 = blockIdx.x * bn_out;
+  const int pad1 = (K - 1) * a.dil / 2;
+  const int n0 = blockIdx.x * BN_OUT;
   const int len = a.lens ? a.lens[b] : a.T;
-  const int wuse = N1 + (k - 1) * a.dil;        // input columns the tile really needs
-  const int in_base = n0 - h2 - pad1;           // position of input-tile column 0
+  const int wuse = N1 + (K - 1) * a.dil;        // input columns the tile really needs
+  const int in_base = n0 - H2 - pad1;           // position of input-tile column 0
   const float slope = a.slope;
   const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.bs, C * a.cs * 4);
-  const H3Rsrc w1r = h3_rsrc(a.w1, k * NCHUNK * 4 * C * 16);
-  const H3Rsrc w2r = h3_rsrc(a.w2, k * NCHUNK * 4 * C * 16);
+  const H3Rsrc w1r = h3_rsrc(a.w1, K * NCHUNK * 4 * C * 16);
+  const H3Rsrc w2r = h3_rsrc(a.w2, K * NCHUNK * 4 * C * 16);
   const int xrow = a.cs * 4;
   constexpr int slab = 4 * C * 16;              // bytes of one (tap, chunk) weight slab
 
@@ -70,41 +78,43 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   };
 
-  // chunk-invariant addressing
-  int a_kkl[NA], a_off[NA];
+  // stage-invariant addressing: weight element e = tid + THREADS j -> (slot = cl * KKT + kkl, op, h, co)
+  int a_cl[NA], a_kkl[NA], a_off[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int e = tid + THREADS * j;
-    const int co = e % C, rest = e / C;          // rest = (kkl*2 + op)*2 + h
-    a_kkl[j] = rest / 4;
+    const int co = e % C, rest = e / C;          // rest = (slot*2 + op)*2 + h
+    const int slot = rest / 4;
+    a_cl[j] = slot / KKT;
+    a_kkl[j] = slot % KKT;
     a_off[j] = e < A_ELEMS ? ((rest % 4) * C + co) * 16 : kH3Oob;
   }
-  int b_off[NBT], b_row[NBT];
+  int b_off[NBT], b_row[NBT];                    // input task t -> (cl, h, p): 8 channels at one position
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int t = tid + THREADS * j;
-    const int hh = t / WROW, p = t - hh * WROW;
+    const int ch2 = t / WROW, p = t - ch2 * WROW;   // ch2 = cl*2 + h
     const int pos = in_base + p;
-    b_row[j] = hh * 8;
+    b_row[j] = (ch2 >> 1) * 16 + (ch2 & 1) * 8;
     b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len) ? pos * 4 : kH3Oob;
   }
 
   uint4 ra[NA];
   float rb[NBT][8];
-  auto fetch_b = [&](int chunk) {
+  auto fetch_b = [&](int chunk0) {
 #pragma unroll
     for (int j = 0; j < NBT; ++j) {
-      const int row0 = (chunk * 16 + b_row[j]) * xrow;
+      const int row0 = (chunk0 * 16 + b_row[j]) * xrow;
 #pragma unroll
       for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
     }
   };
-  auto fetch_a = [&](const H3Rsrc& wr_, int chunk, int kk0) {
+  auto fetch_a = [&](const H3Rsrc& wr_, int chunk0, int kk0) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int kk = kk0 + a_kkl[j];
-      const bool ok = a_off[j] != kH3Oob && kk < k;
-      ra[j] = h3_load4(wr_, ok ? (kk * NCHUNK + chunk) * slab + a_off[j] : kH3Oob);
+      const bool ok = a_off[j] != kH3Oob && kk < K;
+      ra[j] = h3_load4(wr_, ok ? (kk * NCHUNK + chunk0 + a_cl[j]) * slab + a_off[j] : kH3Oob);
     }
   };
   auto commit_a = [&]() {
@@ -126,44 +136,55 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
           hi[q] = vh;
           lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
         }
-        const int hh = t / WROW, p = t - hh * WROW;
-        Bs[(0 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
-        Bs[(1 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+        const int ch2 = t / WROW, p = t - ch2 * WROW;
+        const int cl = ch2 >> 1, hh = ch2 & 1;
+        Bs[((cl * 2 + 0) * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
+        Bs[((cl * 2 + 1) * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
       }
     }
   };
-  // one (<= KKT taps) x (16 channels) k-step group on the tile Bt (taps advance by `tap_step` columns)
-  auto compute = [&](const uint4* Bt, int pitch, int kk0, int tap_step) {
+  // The k-steps of one stage: slots (cl, kkl), TAPS taps per chunk.  Bt: tile of chunk cl at Bt + cl * cl_pitch,
+  // [op][h][pitch]; tap kk of the group starting at kk0 reads column + (kk0 + kkl) * tap_step.  Fragments of the
+  // next slot are read before the MFMAs of the current one are issued.
+  auto compute = [&](auto taps_tag, const uint4* Bt, int pitch, int cl_pitch, int kk0, int tap_step) {
+    constexpr int TAPS = decltype(taps_tag)::value;
+    constexpr int NS = NCS * TAPS;
+    half8 af[2][2][WM], bf[2][2][WN];
+    auto load = [&](int buf, int s) {
+      const int cl = s / TAPS, kkl = s % TAPS;
+      const int tp = (kk0 + kkl) * tap_step;
+      const uint4* Bc = Bt + cl * cl_pitch;
 #pragma unroll
-    for (int kkl = 0; kkl < KKT; ++kkl) {
-      const int kk = kk0 + kkl;
-      if (kk < k) {
-        const int tp = kk * tap_step;
-        half8 af[3][WM], bf[2][WN];
+      for (int m = 0; m < WM; ++m) {
+        af[buf][0][m] = __builtin_bit_cast(half8, As[(((cl * KKT + kkl) * 2 + 0) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+        af[buf][1][m] = __builtin_bit_cast(half8, As[(((cl * KKT + kkl) * 2 + 1) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+      }
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
-          af[0][m] = __builtin_bit_cast(half8, As[((kkl * 2 + 0) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
-          af[2][m] = __builtin_bit_cast(half8, As[((kkl * 2 + 1) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
-          af[1][m] = af[0][m] * (_Float16)(1.f / kH3Scale);
+      for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          bf[buf][op][n] = __builtin_bit_cast(half8, Bc[(op * 2 + h) * pitch + wc * (WN * 32) + n * 32 + i + tp]);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < NS) load(cur ^ 1, s + 1);
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        const half8 wh = af[cur][0][m] * (_Float16)(1.f / kH3Scale);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          acc[m][n] = h3_mfma(af[cur][0][m], bf[cur][0][n], acc[m][n]);   // (S wh) xh
+          acc[m][n] = h3_mfma(wh, bf[cur][1][n], acc[m][n]);              // wh (S xl)
+          acc[m][n] = h3_mfma(af[cur][1][m], bf[cur][0][n], acc[m][n]);   // (S wl) xh
         }
-#pragma unroll
-        for (int op = 0; op < 2; ++op)
-#pragma unroll
-          for (int n = 0; n < WN; ++n)
-            bf[op][n] = __builtin_bit_cast(half8, Bt[(op * 2 + h) * pitch + wc * (WN * 32) + n * 32 + i + tp]);
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-          for (int n = 0; n < WN; ++n) {
-            acc[m][n] = h3_mfma(af[0][m], bf[0][n], acc[m][n]);
-            acc[m][n] = h3_mfma(af[1][m], bf[1][n], acc[m][n]);
-            acc[m][n] = h3_mfma(af[2][m], bf[0][n], acc[m][n]);
-          }
       }
     }
   };
-  const int nkk = (k + KKT - 1) / KKT;
-  const int nst = NCHUNK * nkk;
+  using Full = std::integral_constant<int, KKT>;
+  using Last = std::integral_constant<int, K - (NG - 1) * KKT>;
+  constexpr int nst = (NCHUNK / NCS) * NG;
   constexpr float inv = 1.f / kH3Scale;
 
   // ================================================================ phase 1: Y1 = lrelu(c1(lrelu(x)) + b1)
@@ -171,22 +192,23 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   fetch_b(0);
   fetch_a(w1r, 0, 0);
   {
-    int chunk = 0, kk0 = 0;
+    int chunk = 0, g = 0;
     for (int st = 0; st < nst; ++st) {
       __syncthreads();
-      if (kk0 == 0) commit_b();
+      if (g == 0) commit_b();
       commit_a();
       __syncthreads();
-      int kk1 = kk0 + KKT, chunk1 = chunk;
-      if (kk1 >= k) {
-        kk1 = 0;
-        chunk1 += 1;
+      int g1 = g + 1, chunk1 = chunk;
+      if (g1 == NG) {
+        g1 = 0;
+        chunk1 += NCS;
       }
-      if (st + 1 < nst) fetch_a(w1r, chunk1, kk1);
+      if (st + 1 < nst) fetch_a(w1r, chunk1, g1 * KKT);
       else fetch_a(w2r, 0, 0);                       // first weights of c2 fly during the c1 epilogue
-      if (kk0 == 0 && chunk + 1 < NCHUNK) fetch_b(chunk + 1);
-      compute(Bs, WROW, kk0, a.dil);
-      kk0 = kk1;
+      if (g == 0 && chunk + NCS < NCHUNK) fetch_b(chunk + NCS);
+      if (NG > 1 && g == NG - 1) compute(Last{}, Bs, WROW, 4 * WROW, g * KKT, a.dil);
+      else compute(Full{}, Bs, WROW, 4 * WROW, g * KKT, a.dil);
+      g = g1;
       chunk = chunk1;
     }
   }
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
     for (int n = 0; n < WN; ++n) {
       const int c_t = wr * (WM * 32) + m * 32;
       const int j = wc * (WN * 32) + n * 32 + i;
-      const int pos1 = n0 - h2 + j;
+      const int pos1 = n0 - H2 + j;
       const bool live = pos1 >= 0 && pos1 < len;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -223,19 +245,20 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   // ================================================================ phase 2: y = c2(Y1) + b2 + x
   zero_acc();
   {
-    int chunk = 0, kk0 = 0;
+    int chunk = 0, g = 0;
     for (int st = 0; st < nst; ++st) {
       __syncthreads();
       commit_a();
       __syncthreads();
-      int kk1 = kk0 + KKT, chunk1 = chunk;
-      if (kk1 >= k) {
-        kk1 = 0;
-        chunk1 += 1;
+      int g1 = g + 1, chunk1 = chunk;
+      if (g1 == NG) {
+        g1 = 0;
+        chunk1 += NCS;
       }
-      if (st + 1 < nst) fetch_a(w2r, chunk1, kk1);
-      compute(Y1 + chunk * 4 * N1P, N1P, kk0, 1);
-      kk0 = kk1;
+      if (st + 1 < nst) fetch_a(w2r, chunk1, g1 * KKT);
+      if (NG > 1 && g == NG - 1) compute(Last{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
+      else compute(Full{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
+      g = g1;
       chunk = chunk1;
     }
   }
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
     for (int n = 0; n < WN; ++n) {
       const int col = wc * (WN * 32) + n * 32 + i;
       const int pos = n0 + col;
-      if (col >= bn_out || pos >= a.T) continue;
+      if (col >= BN_OUT || pos >= a.T) continue;
       const bool live = pos < len;
       const int co_base = wr * (WM * 32) + m * 32 + 4 * h;
       const float* xb = a.x + (long)b * a.bs + pos;
@@ -281,22 +304,29 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
 }
 
 struct PairCfg {
-  int C, n1, threads;
+  int C, K, n1, threads;
   size_t lds;
   void (*kern)(const PairArgs);
 };
-template <int C, int NT, int WR, int WC, int KKT>
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS>
 constexpr PairCfg make_cfg() {
-  return {C, 32 * NT, 64 * WR * WC,
-          (size_t)((C / 16) * 4 * (32 * NT + kPairPadY) + KKT * 4 * C + 4 * (32 * NT + kPairHalo)) * 16,
-          resblock_pair_kernel<C, NT, WR, WC, KKT>};
+  return {C, K, 32 * NT, 64 * WR * WC,
+          (size_t)((C / 16) * 4 * (32 * NT + kPairPadY) + NCS * KKT * 4 * C + NCS * 4 * (32 * NT + kPairHalo)) * 16,
+          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS>};
 }
+// (C, K) instantiations of the RVC v2 decoders (resblock kernels 3 / 7 / 11): 512 threads, one workgroup per CU
 const PairCfg kPair[] = {
-    make_cfg<32, 8, 1, 4, 4>(),
-    make_cfg<64, 8, 2, 4, 4>(),
-    make_cfg<128, 4, 4, 2, 4>(),
+    make_cfg<32, 16, 1, 8, 3, 3, 2>(),  make_cfg<32, 16, 1, 8, 7, 7, 1>(),  make_cfg<32, 16, 1, 8, 11, 11, 1>(),
+    make_cfg<64, 8, 2, 4, 3, 3, 2>(),   make_cfg<64, 8, 2, 4, 7, 7, 1>(),   make_cfg<64, 8, 2, 4, 11, 11, 1>(),
+    make_cfg<128, 4, 4, 2, 3, 3, 2>(),  make_cfg<128, 4, 4, 2, 7, 7, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1>(),
 };
 int g_pair_mode = -1;
+
+const PairCfg* find_cfg(int C, int K) {
+  for (const auto& c : kPair)
+    if (c.C == C && c.K == K) return &c;
+  return nullptr;
+}
 
 }  // namespace
 
@@ -307,11 +337,9 @@ bool resblock_pair_enabled() {
 
 bool resblock_pair_ok(const PairArgs& a) {
   if (!resblock_pair_enabled() || !a.w1 || !a.w2) return false;
-  if (a.k < 1 || a.k > 11 || a.dil < 1 || (a.k - 1) * a.dil > kPairHalo - 14 || (a.k & 1) == 0) return false;
+  if (a.dil < 1 || (a.k - 1) * a.dil > kPairHalo - 14) return false;
   if ((long)a.C * a.cs * 4 >= kH3Oob || (long)a.k * a.C * a.C * 4 >= kH3Oob) return false;
-  for (const auto& c : kPair)
-    if (c.C == a.C) return true;
-  return false;
+  return find_cfg(a.C, a.k) != nullptr;
 }
 
 int resblock_pair_slot(int C) { return C == 32 ? 50 : (C == 64 ? 51 : 52); }
@@ -334,14 +362,11 @@ void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
     return true;
   }();
   (void)init;
-  for (const auto& c : kPair)
-    if (c.C == a.C) {
-      const int bn_out = c.n1 - (a.k - 1);
-      dim3 grid(cdiv(a.T, bn_out), 1, a.B);
-      hipLaunchKernelGGL(c.kern, grid, dim3(c.threads), c.lds, stream, a);
-      RVCX_HIP(hipGetLastError());
-      return;
-    }
+  const PairCfg& c = *find_cfg(a.C, a.k);
+  const int bn_out = c.n1 - (a.k - 1);
+  dim3 grid(cdiv(a.T, bn_out), 1, a.B);
+  hipLaunchKernelGGL(c.kern, grid, dim3(c.threads), c.lds, stream, a);
+  RVCX_HIP(hipGetLastError());
 }
 
 }  // namespace rvcx
