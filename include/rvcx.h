@@ -104,6 +104,8 @@ int rvcx_weights_adopt(rvcx_ctx*);
 int rvcx_rmvpe_f0(rvcx_ctx*, int B, const float* audio_hd, int64_t n, float thred, float f0_min,
                   float f0_max, float* f0_hd, float* hidden_hd);
 int rvcx_rmvpe_frames(int64_t n);
+/* MelSpectrogram.forward -- rvc/lib/predictors/RMVPE.py:412-439: audio (B, n) -> log-mel (B, 128, 1 + n/160) */
+int rvcx_rmvpe_mel(rvcx_ctx*, int B, const float* audio_hd, int64_t n, float* mel_hd);
 /* HubertModel.extract_features(source, padding_mask=False, output_layer=L)[0] --
  * call site rvc/infer/pipeline.py:228-236.  wav (B, n) -> feats (B, T', embed_dim). */
 int rvcx_hubert_features(rvcx_ctx*, int B, const float* wav_hd, int64_t n, int output_layer,
@@ -117,6 +119,12 @@ int rvcx_synth_infer(rvcx_ctx*, int model_id, int B, int T, const int32_t* lens,
                      const float* phone_hd, const int32_t* pitch_hd, const float* pitchf_hd,
                      const int32_t* sid, const float* z_noise_hd, const float* src_noise_hd,
                      uint64_t seed, float* out_hd);
+/* the same with the intermediates the reference returns beside the waveform (synthesizers.py:186-188):
+ * stats (B, 2*inter, T) = [m_p ; logs_p] of the TextEncoder, zflow (B, inter, T) = z after the reverse flow */
+int rvcx_synth_infer_taps(rvcx_ctx*, int model_id, int B, int T, const int32_t* lens,
+                          const float* phone_hd, const int32_t* pitch_hd, const float* pitchf_hd,
+                          const int32_t* sid, const float* z_noise_hd, const float* src_noise_hd,
+                          uint64_t seed, float* out_hd, float* stats_hd, float* zflow_hd);
 int rvcx_synth_upp(rvcx_ctx*, int model_id);
 /* index.search(k=8) + weighted blend -- rvc/infer/pipeline.py:239-250.
  * feats (T, dim) in/out; ids (T,8) int64 and dist (T,8) optional. */
@@ -182,6 +190,10 @@ int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, do
                       int32_t* bn, int32_t* kind, int cap);
 /* per-launch table (CSV text: tile,B,cin,cout,k,stride,nout,gflop,ms,tflops) of the last profile */
 const char* rvcx_conv_profile_csv(rvcx_ctx*);
+/* calls this context repeated on the exact-fp32 kernels because a split-fp16 kernel met an activation beyond
+ * fp16 range (|x| >= 6e4; attention K / V >= 234): the default kernels form fp32-grade products from fp16 hi/lo
+ * halves, which have fp16's exponent range.  The repeat is automatic and transparent; this counter reports it. */
+int64_t rvcx_fp32_reruns(rvcx_ctx*);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */
 double rvcx_flop_counter(rvcx_ctx*, int reset);
 void* rvcx_stream(rvcx_ctx*); /* hipStream_t the library launches on */

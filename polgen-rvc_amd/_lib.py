@@ -59,11 +59,11 @@ _lib = None
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
     "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index",
-    "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_hubert_features",
+    "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         _lib.rvcx_stream.restype = C.c_void_p
         _lib.rvcx_conv_profile_csv.restype = C.c_char_p
         _lib.rvcx_out_len.restype = C.c_int64
+        _lib.rvcx_fp32_reruns.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
     return _lib
 
@@ -269,7 +270,7 @@ class Context:
         return int(lib().rvcx_synth_upp(self._h, model_id))
 
     def synth_infer(self, model_id, phone, pitch, pitchf, lens=None, sid=None, z_noise=None, src_noise=None,
-                    seed=0):
+                    seed=0, taps=False):
         phone, pitchf = f32(phone), f32(pitchf)
         pitch = i32(pitch)
         B, T, _ = phone.shape
@@ -279,6 +280,16 @@ class Context:
         sid = i32(np.zeros(B) if sid is None else sid)
         zn = None if z_noise is None else f32(z_noise)
         sn = None if src_noise is None else f32(src_noise)
+        if taps:
+            inter = (zn.shape[1] if zn is not None else None)
+            if inter is None:
+                raise RvcxError("synth_infer(taps=True) needs z_noise (its shape gives inter_channels)")
+            stats = np.empty((B, 2 * inter, T), np.float32)
+            zflow = np.empty((B, inter, T), np.float32)
+            self._ck(lib().rvcx_synth_infer_taps(self._h, model_id, B, T, _p(lens, C.c_int32), _p(phone),
+                                                 _p(pitch, C.c_int32), _p(pitchf), _p(sid, C.c_int32), _p(zn), _p(sn),
+                                                 C.c_uint64(seed), _p(out), _p(stats), _p(zflow)), "synth_infer_taps")
+            return out, stats, zflow
         self._ck(lib().rvcx_synth_infer(self._h, model_id, B, T, _p(lens, C.c_int32), _p(phone),
                                         _p(pitch, C.c_int32), _p(pitchf), _p(sid, C.c_int32), _p(zn), _p(sn),
                                         C.c_uint64(seed), _p(out)), "synth_infer")
@@ -304,6 +315,15 @@ class Context:
         self._ck(lib().rvcx_rmvpe_f0(self._h, B, _p(audio), C.c_int64(n), C.c_float(thred), C.c_float(f0_min),
                                      C.c_float(f0_max), _p(f0), _p(hid)), "rmvpe_f0")
         return (f0, hid) if return_hidden else f0
+
+    def rmvpe_mel(self, audio):
+        audio = f32(audio)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B, n = audio.shape
+        mel = np.empty((B, 128, 1 + n // 160), np.float32)
+        self._ck(lib().rvcx_rmvpe_mel(self._h, B, _p(audio), C.c_int64(n), _p(mel)), "rmvpe_mel")
+        return mel
 
     def hubert_frames(self, n: int) -> int:
         return int(lib().rvcx_hubert_frames(self._h, C.c_int64(n)))
@@ -391,6 +411,9 @@ class Context:
         if noises is not None:
             nz = []
             for w, nv in zip(wavs, noises):
+                if nv is None:
+                    nz.append(None)
+                    continue
                 cap = self.noise_capacity(model_id, w.shape[0], params)
                 buf = np.zeros(cap, np.float32)
                 nv = f32(nv).ravel()
@@ -505,6 +528,10 @@ class Context:
         lib().rvcx_last_timing(self._h, ms)
         names = ["highpass", "rmvpe", "hubert", "index", "enc_p", "flow", "decoder", "post", "total"]
         return dict(zip(names, [float(v) for v in ms]))
+
+    def fp32_reruns(self) -> int:
+        """calls repeated on the exact-fp32 kernels after an fp16-split overflow"""
+        return int(lib().rvcx_fp32_reruns(self._h))
 
     def flop_counter(self, reset=False) -> float:
         return float(lib().rvcx_flop_counter(self._h, 1 if reset else 0))

@@ -17,13 +17,30 @@ struct rvcx_ctx {
 
 static thread_local std::string g_last_error;
 
+// Every entry point's body runs inside a two-attempt loop: if a split-fp16 kernel reported an activation it could
+// not represent (Ctx::take_overflow), the whole call is repeated on the exact-fp32 kernels (thread-local
+// g_force_fp32) and counted (rvcx_fp32_reruns).  Bodies are written to be repeatable (they reset the arena first).
+struct Fp32Scope {
+  bool saved;
+  explicit Fp32Scope(bool on) : saved(g_force_fp32) { g_force_fp32 = saved || on; }
+  ~Fp32Scope() { g_force_fp32 = saved; }
+};
+
 #define API_BEGIN(ctxp)                       \
   Ctx* C = (ctxp) ? &(ctxp)->c : nullptr;     \
   try {                                       \
     if (!C) fail("null context");             \
-    RVCX_HIP(hipSetDevice(C->device));
+    RVCX_HIP(hipSetDevice(C->device));        \
+    for (int attempt_ = 0; attempt_ < 2; ++attempt_) { \
+      Fp32Scope fp32_scope_(attempt_ == 1);
 
 #define API_END                               \
+      if (attempt_ == 0 && C->take_overflow()) { \
+        C->fp32_reruns++;                     \
+        continue;                             \
+      }                                       \
+      break;                                  \
+    }                                         \
     return 0;                                 \
   } catch (const std::exception& e) {         \
     g_last_error = e.what();                  \
@@ -120,6 +137,8 @@ const char* rvcx_last_error(rvcx_ctx* ctx) {
 }
 
 void* rvcx_stream(rvcx_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+
+int64_t rvcx_fp32_reruns(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.fp32_reruns : -1; }
 
 double rvcx_flop_counter(rvcx_ctx* ctx, int reset) {
   if (!ctx) return 0.0;
@@ -554,15 +573,34 @@ int rvcx_weights_adopt(rvcx_ctx* ctx) {
   API_END
 }
 
+static int synth_infer_impl(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
+                            const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
+                            const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow);
+
 int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                      const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
                      const float* src_noise, uint64_t seed, float* out) {
+  return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, nullptr,
+                          nullptr);
+}
+
+int rvcx_synth_infer_taps(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
+                          const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
+                          const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow) {
+  return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, stats,
+                          zflow);
+}
+
+static int synth_infer_impl(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
+                            const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
+                            const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow) {
   API_BEGIN(ctx)
   SynthModel& M = get_synth(*C, model_id);
   const int D = M.cfg.input_dim, inter = M.cfg.inter_channels;
   const size_t Tupp = (size_t)T * M.upp;
   C->ensure_splitk(B);
-  C->arena.reserve(synth_arena_bytes(M, B, T) + (size_t)B * T * D * 8 + (size_t)B * Tupp * 8);
+  C->arena.reserve(synth_arena_bytes(M, B, T) + (size_t)B * T * D * 8 + (size_t)B * Tupp * 8 +
+                   (size_t)B * 3 * inter * T * 4 + 4096);
   C->arena.reset();
   float* ph = any_to_dev(*C, phone, (size_t)B * T * D);
   float* ph_ct = C->arena.alloc<float>((size_t)B * T * D);
@@ -585,7 +623,11 @@ int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* l
   io.src_noise = sn;
   float* dout = C->arena.alloc<float>((size_t)B * Tupp);
   io.out = dout;
+  if (stats) io.stats_out = C->arena.alloc<float>((size_t)B * 2 * inter * T);
+  if (zflow) io.z_out = C->arena.alloc<float>((size_t)B * inter * T);
   synth_forward(*C, M, io, nullptr);
+  if (stats) RVCX_HIP(hipMemcpyAsync(stats, io.stats_out, (size_t)B * 2 * inter * T * 4, hipMemcpyDefault, C->stream));
+  if (zflow) RVCX_HIP(hipMemcpyAsync(zflow, io.z_out, (size_t)B * inter * T * 4, hipMemcpyDefault, C->stream));
   RVCX_HIP(hipMemcpyAsync(out, dout, (size_t)B * Tupp * 4, hipMemcpyDefault, C->stream));
   RVCX_HIP(hipStreamSynchronize(C->stream));
   C->arena.reset();
@@ -656,6 +698,24 @@ int rvcx_rmvpe_f0(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float thr
   rmvpe_forward(*C, *C->rmvpe, B, da, n, thred, f0_min, f0_max, df0, dh, C->stream);
   RVCX_HIP(hipMemcpyAsync(f0, df0, (size_t)B * F * 4, hipMemcpyDefault, C->stream));
   if (hidden) RVCX_HIP(hipMemcpyAsync(hidden, dh, (size_t)B * F * 360 * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->check_dev_err();
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_rmvpe_mel(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float* mel) {
+  API_BEGIN(ctx)
+  if (!C->rmvpe) fail("rmvpe not loaded");
+  C->ensure_splitk(B);
+  const int F = (int)(1 + n / 160);
+  C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, B, n) + (size_t)B * (n + (size_t)F * 130) * 4);
+  C->arena.reset();
+  float* da = any_to_dev(*C, audio, (size_t)B * n);
+  float* df0 = C->arena.alloc<float>((size_t)B * F);
+  float* dm = C->arena.alloc<float>((size_t)B * 128 * F);
+  rmvpe_forward(*C, *C->rmvpe, B, da, n, 0.03f, 50.f, 1100.f, df0, nullptr, C->stream, dm);
+  RVCX_HIP(hipMemcpyAsync(mel, dm, (size_t)B * 128 * F * 4, hipMemcpyDefault, C->stream));
   RVCX_HIP(hipStreamSynchronize(C->stream));
   C->check_dev_err();
   C->arena.reset();

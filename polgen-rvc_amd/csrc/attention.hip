@@ -9,6 +9,7 @@
 // from LDS with the same permutation, so P never moves between lanes).
 #include <cstdlib>
 
+#include "conv.h"
 #include "ops.h"
 
 namespace rvcx {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
                                                       float* __restrict__ m_out, float* __restrict__ l_out,
                                                       const float* __restrict__ relq, int H, int D, int T,
                                                       int ld, long in_bs, long out_bs, float scale, int window,
-                                                      const int* lens, int nsplit, float* opart) {
+                                                      const int* lens, int nsplit, float* opart, int* ovf_word) {
   constexpr int NS = 2 * DT;                       // k16-steps over the head dimension
   __shared__ uint4 Ks[NS * 2 * 2 * 32];            // [s][op {S kh, S kl}][h][key]   (kh = (S kh)/S in registers)
   __shared__ uint4 Vs[DT * 2 * 2 * 2 * 32];        // [dt][s2][op {S vh, S vl}][h][d]
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
   const float* kb = k + base;
   const float* vb = v + base;
 
+  // K and V are held as S-scaled fp16 halves: they must stay below 65504 / S; Q below 65504 (conv.h: kH3ActLimit)
+  bool ovf = false;
   // Q fragment: lane (query i, half h), step s, slot e -> Q[16 s + 8 h + e][q0 + i] * scale, split {qh, S ql}
   ahalf8 qh[NS], ql[NS];
   const int qi = q0 + i;
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
     for (int e = 0; e < 8; ++e) {
       const int d = 16 * s + 8 * h + e;
       const float val = (d < D && qi < T) ? qb[(long)d * ld + qi] * scale : 0.f;
+      ovf |= !(fabsf(val) < kH3ActLimit);
       const _Float16 vh = (_Float16)val;
       qh[s][e] = vh;
       ql[s][e] = (_Float16)((val - (float)vh) * kAttS);
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float val = rk[j][e];
+          ovf |= !(fabsf(val) < kH3ActLimit / kAttS);
           const _Float16 vh = (_Float16)val;
           a0[e] = (_Float16)((float)vh * kAttS);
           a1[e] = vh;
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float val = rv[j][e];
+          ovf |= !(fabsf(val) < kH3ActLimit / kAttS);
           const _Float16 vh = (_Float16)val;
           a0[e] = (_Float16)((float)vh * kAttS);
           a1[e] = vh;
@@ -391,6 +397,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
         acc_o[dt] = att_mfma(a2, ph[s2], acc_o[dt]);
       }
   }
+  if (ovf && ovf_word) atomicOr(ovf_word, kErrH3Overflow);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(256) void rel_values_kernel(const float* __restrict
 
 void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
                       int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
-                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream) {
+                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream, int* ovf) {
   RVCX_CHECK(D % 2 == 0 && D <= 96, "attention: head dim must be even and <= 96");
   const int nrel = 2 * window + 1;
   float *relq = nullptr, *mb = nullptr, *lb = nullptr;
@@ -605,17 +612,17 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
   float* mo = nsplit > 1 ? nullptr : mb;
   float* lo = nsplit > 1 ? nullptr : lb;
   dim3 grid(cdiv(T, 128) * nsplit, H, B);
-  static int h3 = -1;   // RVCX_ATT_H3=0: exact-fp32 MFMA attention
-  if (h3 < 0) h3 = getenv("RVCX_ATT_H3") ? atoi(getenv("RVCX_ATT_H3")) : 1;
+  static const int h3_env = getenv("RVCX_ATT_H3") ? atoi(getenv("RVCX_ATT_H3")) : 1;   // 0: exact-fp32 MFMA attention
+  const int h3 = h3_env && !g_force_fp32;
   if (h3 && DT == 1)
     hipLaunchKernelGGL(attn_h3_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart);
+                       out_bs, scale, window, lens, nsplit, opart, ovf);
   else if (h3 && DT == 2)
     hipLaunchKernelGGL(attn_h3_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart);
+                       out_bs, scale, window, lens, nsplit, opart, ovf);
   else if (h3)
     hipLaunchKernelGGL(attn_h3_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart);
+                       out_bs, scale, window, lens, nsplit, opart, ovf);
   else if (DT == 1)
     hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
                        out_bs, scale, window, lens, nsplit, opart);

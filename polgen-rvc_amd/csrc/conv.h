@@ -61,6 +61,7 @@ struct ConvArgs {
   long long* trace = nullptr;    // RVCX_ABLATION: per-workgroup {hw_id, xcc, t_start, t_stage0, t_mainloop_end, t_end}
   int stagger = 0;               // start delay per resident-workgroup slot in 100 MHz ticks (first round only)
   int stagger_blocks = 0;        // workgroups of the first round (linear id below this get the delay)
+  int* ovf = nullptr;            // device error word: bit 1 is set when an activation does not fit the fp16 hi/lo split
   int dbg = 0;                   // timing ablations only (RVCX_CONV_DBG): 1 skip weight staging, 2 skip input staging, 4 skip MFMAs
 };
 
@@ -86,7 +87,14 @@ struct PairArgs {
   float slope = 0.1f;
   int acc2_mode = ACC2_NONE;
   float acc2_div = 1.f;
+  int* ovf = nullptr;            // as ConvArgs::ovf
 };
+// fp16 hi/lo split kernels hold activations as fp16 halves: |x| >= 65504 (attention K / V: >= 255) would become
+// inf.  Every split kernel checks what it converts and raises bit 1 of the context's device error word; the API
+// entry point then repeats the call on the exact-fp32 kernels (g_force_fp32, thread-local) and counts it.
+constexpr float kH3ActLimit = 6.0e4f;
+constexpr int kErrGruTimeout = 1, kErrH3Overflow = 2;
+extern thread_local bool g_force_fp32;
 bool resblock_pair_enabled();                                // RVCX_FUSE (default on) and the h3 kernels enabled
 bool resblock_pair_ok(const PairArgs& a);
 void launch_resblock_pair(const PairArgs& a, hipStream_t stream);              // raw launch (resblock.hip)
@@ -110,7 +118,8 @@ void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + til
 int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-time-tiled family; profile slot or -1
 void conv_fast_describe(ConvProfile* p);
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream);   // fp16x3 split kernels; slot or -1
-bool conv_h3_enabled();
+bool conv_h3_enabled();      // RVCX_H3 on and the calling thread is not in an exact-fp32 rerun
+bool conv_h3_configured();   // RVCX_H3 on (what checkpoint loading looks at)
 bool conv_h3_split_ok(const ConvArgs& a);   // may this launch read / write pre-split activations?
 void launch_splitk_finish(const ConvArgs& a, hipStream_t stream);   // deterministic reduction of the split-K slabs + epilogue
 void conv_h3_describe(ConvProfile* p);

@@ -54,6 +54,7 @@ __device__ __forceinline__ void store_tile_split(const ConvArgs& a, int b, int c
         float v = t[4 * g + q] + (a.bias ? a.bias[cg + 4 * hl + q] : 0.f);
         v = apply_act(v, a.act, a.act_slope);
         v = live ? v : 0.f;
+        if (!(fabsf(v) < kH3ActLimit) && a.ovf) atomicOr(a.ovf, kErrH3Overflow);   // never taken on sane data
         const _Float16 vh = (_Float16)v;
         hi[q] = vh;
         lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
 
   uint4 ra[NA];
   float rb[NBT][8];
+  bool ovf = false;                                    // an activation that does not fit fp16 (see kH3ActLimit)
   auto fetch_b = [&](int chunk) {                      // LIN: chunks chunk .. chunk+KKT-1 (clipped to cb1)
     if constexpr (xsplit) {
       const int cbyte = chunk * 4 * a.x_cs * 16;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
           for (int q = 0; q < 8; ++q) {
             float v = rb[j][q];
             if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
+            ovf |= !(fabsf(v) < kH3ActLimit);
             const _Float16 vh = (_Float16)v;
             hi[q] = vh;
             lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
     chunk = chunk1;
   }
 
+  if (ovf && a.ovf) atomicOr(a.ovf, kErrH3Overflow);
   constexpr float inv = 1.f / kH3Scale;
 #pragma unroll
   for (int m = 0; m < WM; ++m)
@@ -360,12 +364,21 @@ const H3Cfg kH3[] = {
     {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false, true>},
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
-int g_h3_mode = -1;   // RVCX_H3: 0 off, 1 on (default)
 }  // namespace
 
+thread_local bool g_force_fp32 = false;
+
 bool conv_h3_enabled() {
-  if (g_h3_mode < 0) g_h3_mode = getenv("RVCX_H3") ? atoi(getenv("RVCX_H3")) : 1;
-  return g_h3_mode != 0;
+  static const int mode = getenv("RVCX_H3") ? atoi(getenv("RVCX_H3")) : 1;   // initialised once, thread-safe
+  return mode != 0 && !g_force_fp32;
+}
+
+bool conv_h3_configured() {
+  const bool saved = g_force_fp32;
+  g_force_fp32 = false;
+  const bool r = conv_h3_enabled();
+  g_force_fp32 = saved;
+  return r;
 }
 
 void conv_h3_describe(ConvProfile* p) {

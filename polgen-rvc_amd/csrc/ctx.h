@@ -149,8 +149,10 @@ struct Ctx {
   bool resblock_streams = false;  // run the ResBlocks of an NSF stage on 3 streams
   bool serial = false;            // profiling: keep every launch on the main stream (true per-kernel times)
   bool serial_env = false;        // RVCX_SERIAL=1: serial for the whole life of the context
-  int* dev_err = nullptr;         // device flag: a kernel gave up waiting (checked after each API call)
-  void check_dev_err();
+  int* dev_err = nullptr;         // device error word (conv.h: kErrGruTimeout, kErrH3Overflow), read after each API call
+  void check_dev_err();           // throws on a GRU timeout; an fp16-split overflow is left for take_overflow()
+  bool take_overflow();           // true (and the bit cleared) when a split kernel met an activation beyond fp16
+  long fp32_reruns = 0;           // calls repeated on the exact-fp32 kernels because of that
   float timing[9] = {0};
   StageTimer timer;
   std::unique_ptr<HubertModel> hubert;
@@ -178,7 +180,9 @@ struct Ctx {
   void pair_on(const PairArgs& a, hipStream_t s) {
     const double f = 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * a.T;   // both convs, 2 M N K each
     flops += f;
-    conv_launch_pair(a, f, s);
+    PairArgs b = a;
+    b.ovf = dev_err;
+    conv_launch_pair(b, f, s);
   }
   void conv(const ConvArgs& a) { conv_on(a, stream); }
   void conv_on(ConvArgs a, hipStream_t s) {
@@ -188,6 +192,7 @@ struct Ctx {
     a.part = splitk_buf[si];
     a.part_cap = kSplitKFloats * splitk_items;
     a.part_cap_item = kSplitKFloats;
+    a.ovf = dev_err;
     launch_conv(a, s);
   }
 };

@@ -60,10 +60,20 @@ void Ctx::check_dev_err() {
   if (!dev_err) return;
   int v = 0;
   RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (v) {
+  if (v & kErrGruTimeout) {
     RVCX_HIP(hipMemset(dev_err, 0, sizeof(int)));
     fail("device-side timeout: a GRU cluster workgroup lost its partner");
   }
+}
+
+bool Ctx::take_overflow() {
+  if (!dev_err) return false;
+  int v = 0;
+  RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (!(v & kErrH3Overflow)) return false;
+  v &= ~kErrH3Overflow;
+  RVCX_HIP(hipMemcpy(dev_err, &v, sizeof(int), hipMemcpyHostToDevice));
+  return true;
 }
 
 Ctx::~Ctx() {
@@ -160,7 +170,7 @@ ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, 
   L.cout_gp = conv_cout_pad(cout / groups);
   const std::vector<float> wp = pack_conv_weight(w, cout, cin_g, k, groups);
   L.w = c.slab.upload(wp);
-  if (h3 && groups == 1 && L.cin_gp % 16 == 0 && conv_h3_enabled()) upload_h3(c, L, wp, k);
+  if (h3 && groups == 1 && L.cin_gp % 16 == 0 && conv_h3_configured()) upload_h3(c, L, wp, k);
   L.bias = bias ? c.slab.upload(bias, (size_t)cout) : nullptr;
   return L;
 }
@@ -175,7 +185,7 @@ ConvT1dW make_convT1d(Ctx& c, const float* w, const float* bias, int cin, int co
   L.w.cin_gp = conv_cin_pad(cin);
   L.w.cout_gp = conv_cout_pad(pp.cout_total);
   L.w.w = c.slab.upload(pp.w);
-  if (L.w.cin_gp % 16 == 0 && conv_h3_enabled()) upload_h3(c, L.w, pp.w, pp.taps);   // polyphase taps: a dense stride-1 conv
+  if (L.w.cin_gp % 16 == 0 && conv_h3_configured()) upload_h3(c, L.w, pp.w, pp.taps);   // polyphase taps: a dense stride-1 conv
   L.w.bias = c.slab.upload(pp.bias);
   L.stride = s;
   L.pad_t = p;

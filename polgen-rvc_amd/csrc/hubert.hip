@@ -140,7 +140,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     ConvArgs a = conv1d_args(L.qkv, h, qkv, B, T, T);
     c.conv_on(a, s);
     launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T,
-                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s);
+                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s, c.dev_err);
     c.flops += attention_flops(B, cf.heads, hd, T);
     a = conv1d_args(L.o, att, h2, B, T, T);
     conv_set_res(a, h, E, T);

@@ -90,8 +90,9 @@ struct RmvpeModel {
 std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const TensorTable& t);
 size_t rmvpe_arena_bytes(const RmvpeModel& m, int B, int64_t n);
 // audio: device (B,n) f32.  f0: device (B, 1+n/160).  hidden: device (B, frames, 360) or null.
+// mel_out (optional): device (B, 128, frames) log-mel spectrogram (MelSpectrogram.forward, RMVPE.py:412-439)
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
-                   float f0_max, float* f0, float* hidden, hipStream_t s);
+                   float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out = nullptr);
 
 // ------------------------------------------------------------------------------ HuBERT
 struct HubertModel {

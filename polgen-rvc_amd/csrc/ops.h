@@ -7,7 +7,8 @@ namespace rvcx {
 // ---- attention.hip
 void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
                       int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
-                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream);
+                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream,
+                      int* ovf = nullptr /* device error word (fp16-split overflow bit), see conv.h */);
 size_t attention_scratch_floats(int B, int H, int T, int window);
 size_t attention_split_floats(int B, int H, int T);
 double attention_flops(int B, int H, int D, int T);
@@ -65,6 +66,8 @@ void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStre
 // log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp
 void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, const float* bn,
                      hipStream_t s);
+// y = log(max(x, floor))
+void launch_log_clamp(const float* x, float* y, long n, float floor, hipStream_t s);
 // 2x2 average pool on row-padded maps: (B*C, H, Wp) -> (B*C, H/2, W/2+2)
 void launch_avgpool2(const float* x, float* y, int planes, int H, int Wp, long x_ps, long y_ps, hipStream_t s);
 // copy channels of row-padded maps between buffers with different batch strides

@@ -458,6 +458,13 @@ void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int T
   hipLaunchKernelGGL(mel_post_kernel, EW_GRID(tot), 0, s, mel, out, nmel, F, Tp, bn, tot);
 }
 
+__global__ void log_clamp_kernel(const float* x, float* y, long n, float floor) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = logf(fmaxf(x[i], floor));
+}
+void launch_log_clamp(const float* x, float* y, long n, float floor, hipStream_t s) {
+  hipLaunchKernelGGL(log_clamp_kernel, EW_GRID(n), 0, s, x, y, n, floor);
+}
+
 __global__ void avgpool2_kernel(const float* x, float* y, int H, int Wp, long x_ps, long y_ps, long total) {
   const int W2 = (Wp - 2) / 2, Wpo = W2 + 2, H2 = H / 2;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
 
   uint4 ra[NA];
   float rb[NBT][8];
+  bool ovf = false;
   auto fetch_b = [&](int chunk0) {
 #pragma unroll
     for (int j = 0; j < NBT; ++j) {
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
         for (int q = 0; q < 8; ++q) {
           float v = rb[j][q];
           v = v > 0.f ? v : v * slope;                 // leaky_relu ahead of c1
+          ovf |= !(fabsf(v) < kH3ActLimit);
           const _Float16 vh = (_Float16)v;
           hi[q] = vh;
           lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
           float v = acc[m][n][4 * g + q] * inv + (a.b1 ? a.b1[cg + 4 * h + q] : 0.f);
           v = fmaxf(v, v * slope);
           v = live ? v : 0.f;
+          ovf |= !(fabsf(v) < kH3ActLimit);
           const _Float16 vh = (_Float16)v;
           hi[q] = vh;
           lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
@@ -241,6 +244,8 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
         *reinterpret_cast<half4*>(e_lo) = lo;
       }
     }
+
+  if (ovf && a.ovf) atomicOr(a.ovf, kErrH3Overflow);
 
   // ================================================================ phase 2: y = c2(Y1) + b2 + x
   zero_acc();
@@ -320,7 +325,6 @@ const PairCfg kPair[] = {
     make_cfg<64, 8, 2, 4, 3, 3, 2>(),   make_cfg<64, 8, 2, 4, 7, 7, 1>(),   make_cfg<64, 8, 2, 4, 11, 11, 1>(),
     make_cfg<128, 4, 4, 2, 3, 3, 2>(),  make_cfg<128, 4, 4, 2, 7, 7, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1>(),
 };
-int g_pair_mode = -1;
 
 const PairCfg* find_cfg(int C, int K) {
   for (const auto& c : kPair)
@@ -331,8 +335,8 @@ const PairCfg* find_cfg(int C, int K) {
 }  // namespace
 
 bool resblock_pair_enabled() {
-  if (g_pair_mode < 0) g_pair_mode = getenv("RVCX_FUSE") ? atoi(getenv("RVCX_FUSE")) : 1;
-  return g_pair_mode != 0 && conv_h3_enabled();
+  static const int mode = getenv("RVCX_FUSE") ? atoi(getenv("RVCX_FUSE")) : 1;
+  return mode != 0 && conv_h3_enabled();
 }
 
 bool resblock_pair_ok(const PairArgs& a) {

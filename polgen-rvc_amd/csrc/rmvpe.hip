@@ -241,7 +241,7 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
 }  // namespace
 
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
-                   float f0_max, float* f0, float* hidden, hipStream_t s) {
+                   float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out) {
   Arena& A = c.arena;
   const int F = (int)(1 + n / HOP), Tp = padded_frames(F);
   const int nenc = m.cfg.en_de_layers;
@@ -288,6 +288,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   float* w2 = A.alloc<float>(big);
   float* w3 = A.alloc<float>(big);
   Map2 x{w0, (long)Hs[0] * Ws[0], 1, Hs[0], Ws[0]};
+  if (mel_out) launch_log_clamp(mel, mel_out, (long)B * N_MELS * F, 1e-5f, s);   // log(clamp(mel, 1e-5)), RMVPE.py:438
   launch_mel_post(mel, x.p, B, N_MELS, F, Tp, m.bn0, s);
   for (int l = 0; l < nenc; ++l) {
     const int nblk = (int)m.enc[l].size();

@@ -251,7 +251,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     ConvArgs a = conv1d_args(L.qkv, x, qkv, B, T, T);
     c.conv(a);
     launch_attention(qkv, qkv + (size_t)hid * T, qkv + (size_t)2 * hid * T, att, B, heads, kc, T, T,
-                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, asplit, s);
+                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, asplit, s, c.dev_err);
     c.flops += attention_flops(B, heads, kc, T);
     a = conv1d_args(L.o, att, tmp, B, T, T);
     conv_set_res(a, x, hid, T);

@@ -211,3 +211,33 @@ def test_fused_resblock_pair_equals_two_launches(ctx, C, K, d, T):
     print(f"C={C} k={K} d={d} T={T}: fused vs torch rel err {e:.2e}; equal to two launches: {np.array_equal(fused, two)}")
     assert e < 2e-6
     assert np.array_equal(fused, two)
+
+
+def test_activation_beyond_fp16_range_falls_back_to_exact_fp32(ctx):
+    """the split-fp16 kernels hold activations as fp16 hi/lo halves -- |x| >= 65504 would
+    become inf -> NaN.  The kernels flag such an input, the entry point repeats the call on the exact-fp32
+    kernels and counts it: the result is the fp32 answer."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 2000, generator=g)
+    x[0, 3, 777] = 1.0e5
+    x[0, 40, 12] = -3.0e6
+    w = torch.randn(64, 64, 7, generator=g) / (64 * 7) ** 0.5
+    b = torch.randn(64, generator=g)
+    ref = F.conv1d(x, w, b, padding=3).numpy()
+    n0 = ctx.fp32_reruns()
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), pad_left=3)
+    assert ctx.fp32_reruns() == n0 + 1
+    assert np.isfinite(got).all()
+    assert rms(got - ref) / rms(ref) < 2e-6
+    # the fused ResBlock step has the same guard, on its input and on the tile it keeps in LDS
+    w2 = torch.randn(64, 64, 7, generator=g) / (64 * 7) ** 0.5
+    x2 = torch.randn(1, 64, 1500, generator=g)
+    x2[0, 5, 100] = 2.0e5
+    t = F.conv1d(F.leaky_relu(x2, 0.1), w, b, padding=3)
+    ref2 = (F.conv1d(F.leaky_relu(t, 0.1), w2, b, padding=3) + x2).numpy()
+    got2 = ctx.resblock_pair(x2.numpy(), w.numpy(), b.numpy(), w2.numpy(), b.numpy())
+    assert ctx.fp32_reruns() == n0 + 2 and np.isfinite(got2).all()
+    assert rms(got2 - ref2) / rms(ref2) < 2e-6
+    # in-range data never takes the detour
+    ctx.conv1d(torch.randn(1, 64, 500, generator=g).numpy(), w.numpy(), b.numpy(), pad_left=3)
+    assert ctx.fp32_reruns() == n0 + 2

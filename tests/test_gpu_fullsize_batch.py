@@ -235,3 +235,40 @@ def test_c5_two_resident_models_interleaved_vs_reference(ctx):
     finally:
         for mid in mids.values():
             _lib.lib().rvcx_unload_synth(ctx._h, mid)
+
+
+def test_c3_item_with_retrieval_blend_vs_reference(ctx, full):
+    """BASELINE configs[2], one utterance of the batch against the REFERENCE: fixture pipeline_c3_30s_48k_index is
+    the reference's own VC.pipeline output with index_rate 0.75 over a 65 536 x 768 index (its blend code,
+    pipeline.py:239-250, around an exact-L2 stand-in for faiss' search).  The index is rebuilt here from the
+    GPU's HuBERT features with the same planted-neighbour rule (they differ from the reference-side features by
+    ~1e-6, far below the neighbour gaps); the same item inside a batch of 4 must give the same bits."""
+    import hashlib
+    import json
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import synthetic as S
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_c3_30s_48k_index.npz"))
+    assert int(d["seed"]) == SEED and int(d["index_rows"]) == 65536
+    scfg = json.loads(str(d["cfgs"]))[2]
+    clip = S.make_clip(int(d["clip"]), float(d["seconds"]))
+    feats = ctx.hubert_features(_padded(ctx, clip), 768)[0]
+    big = S.make_index_from_feats(feats, 65536, 0)
+    # neighbour ids of the GPU's features in the GPU-side index == the ids the reference run searched
+    _, ids, _ = OP.index_blend(feats, big, 0.75)
+    assert hashlib.sha256(ids.astype(np.int64).tobytes()).hexdigest() == str(d["ids_sha256"])
+    ctx.load_index(big)
+    try:
+        noise = _fixture_noise(scfg, int(d["chunk_lens"][0]), 48000, d["noise_seed"])
+        p = _params(index_rate=float(d["index_rate"]))
+        pcm, f32 = ctx.convert_batch(full, [clip], p, noises=[noise], want_f32=True)
+        e, dmax, frac, blocks = _check_vs_fixture(d, "", pcm[0], f32[0], 48000)
+        print(f"C3 item vs reference: float rms err {e:.3e}, pcm max diff {dmax} LSB, {blocks} blocks checked")
+        assert e < 1e-4 and dmax <= 8 and frac < 0.02 and blocks > 300
+        others = [S.make_clip(40 + i, 30.0) for i in range(3)]
+        pcm4 = ctx.convert_batch(full, [others[0], clip, others[1], others[2]], p, noises=[None, noise, None, None])
+        assert np.array_equal(pcm4[1], pcm[0])
+        # without the blend the waveform is a different one: the fixture really exercises the retrieval path
+        pcm0, f0_ = ctx.convert_batch(full, [clip], _params(), noises=[noise], want_f32=True)
+        assert rms(f0_[0] - f32[0]) > 1e-4
+    finally:
+        ctx.load_index(None)

@@ -73,8 +73,15 @@ def test_synth_vs_reference_golden(ctx, tag):
     d = np.load(os.path.join(GOLD, f"synth_{tag}.npz"))
     cfg = json.loads(str(d["cfg"]))
     mid, _ = _load_model(ctx, cfg, int(d["seed"]))
-    got = ctx.synth_infer(mid, d["phone"], d["pitch"], d["f0"], z_noise=d["z_noise"],
-                          src_noise=d["src_noise"][:, :, 0])
+    got, stats, zflow = ctx.synth_infer(mid, d["phone"], d["pitch"], d["f0"], z_noise=d["z_noise"],
+                                        src_noise=d["src_noise"][:, :, 0], taps=True)
+    # the intermediates the reference returns beside the waveform: TextEncoder statistics and the flow output
+    inter = d["m_p"].shape[1]
+    for name, mine, ref_t in (("m_p", stats[:, :inter], d["m_p"]), ("logs_p", stats[:, inter:], d["logs_p"]),
+                              ("z", zflow, d["z"])):
+        et = rms(mine - ref_t) / max(rms(ref_t), 1e-12)
+        print(f"synth {tag}: {name} rel err {et:.3e}")
+        assert mine.shape == ref_t.shape and et < 1e-4, name
     ref = d["audio"][:, 0]
     e = rms(got - ref)
     print(f"synth {tag}: rms_ref={rms(ref):.4f} rms_err={e:.3e}")
