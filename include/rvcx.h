@@ -86,6 +86,12 @@ int rvcx_unload_synth(rvcx_ctx*, int model_id);
 /* replaces faiss.read_index + reconstruct_n -- rvc/infer/pipeline.py:322-323.
  * big_npy is the (n, dim) float32 matrix of stored vectors; NULL/0 drops the index. */
 int rvcx_load_index(rvcx_ctx*, const float* big_npy, int64_t n, int dim);
+/* the same for a faiss "IVF{nlist},Flat" index, which is what RVC training writes: index.search then scans only
+ * the inverted list of the query's nearest centroid (nprobe = 1, stored in the file; pipeline.py:242 uses it as
+ * read).  centroids (nlist, dim): the coarse quantiser; assign (n): list id of every stored vector (row = id).
+ * Lists with fewer than 8 vectors pad with id -1 / infinite distance, exactly as faiss does. */
+int rvcx_load_index_ivf(rvcx_ctx*, const float* big_npy, int64_t n, int dim, const float* centroids, int nlist,
+                        const int32_t* assign, int nprobe);
 
 /* Folded weights live in per-model regions (freed by rvcx_unload_synth / rvcx_load_index(NULL) / a reload).
  * rvcx_weights_regions lists the device chunks of everything loaded, in a fixed order (HuBERT, RMVPE, voice

@@ -88,6 +88,30 @@ def index_blend(feats: np.ndarray, big_npy: np.ndarray, index_rate: float, k: in
     return out.astype(np.float32), ix.astype(np.int64), score
 
 
+def index_blend_ivf(feats: np.ndarray, big_npy: np.ndarray, centroids: np.ndarray, assign: np.ndarray,
+                    index_rate: float, k: int = 8):
+    """pipeline.py:239-250 when ``index`` is a faiss "IVF{nlist},Flat" searched with nprobe = 1 (what RVC index
+    files are): the coarse quantiser picks the nearest centroid, only that inverted list is scanned; a list with
+    fewer than k vectors pads with id -1 / distance inf, and the reference's ``big_npy[ix]`` then reads the LAST row
+    with weight (1/inf)^2 = 0.  float64 distances; parity with faiss itself unpinned."""
+    q = feats.astype(np.float64)
+    c = centroids.astype(np.float64)
+    dc = (q * q).sum(1)[:, None] - 2.0 * q @ c.T + (c * c).sum(1)[None, :]
+    qlist = np.argmin(dc, axis=1)
+    b = big_npy.astype(np.float64)
+    d2 = (q * q).sum(1)[:, None] - 2.0 * q @ b.T + (b * b).sum(1)[None, :]
+    d2 = np.where(assign[None, :] == qlist[:, None], d2, np.inf)
+    ix = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    score = np.take_along_axis(d2, ix, axis=1).astype(np.float32)
+    ix = np.where(np.isinf(score), -1, ix)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        weight = np.square(1 / score)
+        weight /= weight.sum(axis=1, keepdims=True)
+        npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
+        out = npy * index_rate + (1 - index_rate) * feats
+    return out.astype(np.float32), ix.astype(np.int64), score
+
+
 def frame_rms(y: np.ndarray, frame_length: int, hop_length: int) -> np.ndarray:
     """librosa.feature.rms(y, frame_length, hop_length) (center=True, zero pad) -> (1, n_frames)."""
     pad = frame_length // 2

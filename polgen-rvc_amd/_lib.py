@@ -58,7 +58,7 @@ _lib = None
 # every symbol include/rvcx.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
-    "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index",
+    "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
     "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
@@ -356,6 +356,13 @@ class Context:
             return
         b = f32(big_npy)
         self._ck(lib().rvcx_load_index(self._h, _p(b), C.c_int64(b.shape[0]), int(b.shape[1])), "load_index")
+
+    def load_index_ivf(self, big_npy, centroids, assign, nprobe=1):
+        """faiss "IVF{nlist},Flat": stored vectors + coarse centroids + list id per vector; nprobe = 1 search."""
+        b, c = f32(big_npy), f32(centroids)
+        a = i32(assign)
+        self._ck(lib().rvcx_load_index_ivf(self._h, _p(b), C.c_int64(b.shape[0]), int(b.shape[1]), _p(c), int(c.shape[0]),
+                                           _p(a, C.c_int32), int(nprobe)), "load_index_ivf")
 
     def index_blend(self, feats, index_rate):
         f = f32(feats).copy()

@@ -799,6 +799,15 @@ int rvcx_load_index(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim) {
   API_END
 }
 
+int rvcx_load_index_ivf(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim, const float* centroids, int nlist,
+                        const int32_t* assign, int nprobe) {
+  API_BEGIN(ctx)
+  if (!big_npy || n <= 0 || !centroids || nlist <= 0 || !assign) fail("load_index_ivf: null argument");
+  if (nprobe != 1) fail("load_index_ivf: only nprobe = 1 (what RVC index files carry) is implemented");
+  C->index = index_load(*C, big_npy, n, dim, centroids, nlist, assign);
+  API_END
+}
+
 int rvcx_index_blend(rvcx_ctx* ctx, float* feats, int T, float index_rate, int64_t* ids, float* dist) {
   API_BEGIN(ctx)
   if (!C->index) fail("index not loaded");

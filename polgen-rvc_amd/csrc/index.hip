@@ -9,7 +9,8 @@ namespace rvcx {
 
 constexpr int TOPK = 8;
 
-std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim) {
+std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim, const float* centroids,
+                                      int nlist, const int32_t* assign) {
   auto ix = std::make_unique<IndexData>();
   RegionScope scope(c, *ix->region);
   ix->n = n;
@@ -23,6 +24,20 @@ std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, i
     norms[(size_t)i] = s;
   }
   ix->norms = c.slab.upload(norms);
+  if (centroids && nlist > 0 && assign) {
+    ix->nlist = nlist;
+    ix->cent = make_conv(c, centroids, nullptr, nlist, dim, 1, 1, false);
+    std::vector<float> cn((size_t)nlist);
+    for (int i = 0; i < nlist; ++i) {
+      float s = 0.f;
+      for (int d = 0; d < dim; ++d) s += centroids[(size_t)i * dim + d] * centroids[(size_t)i * dim + d];
+      cn[(size_t)i] = s;
+    }
+    ix->cent_norms = c.slab.upload(cn);
+    for (int64_t i = 0; i < n; ++i) RVCX_CHECK(assign[i] >= 0 && assign[i] < nlist, "index: list id out of range");
+    static_assert(sizeof(int32_t) == sizeof(float), "list ids travel through the float upload path");
+    ix->assign = reinterpret_cast<const int*>(c.slab.upload(reinterpret_cast<const float*>(assign), (size_t)n));
+  }
   ix->region->seal();
   return ix;
 }
@@ -30,7 +45,7 @@ std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, i
 constexpr int SPLITS = 32;
 
 size_t index_arena_bytes(const IndexData& ix, int T) {
-  return ((size_t)ix.n * T + (size_t)T * (SPLITS * TOPK * 2 + 64)) * sizeof(float) + (1 << 20);
+  return ((size_t)ix.n * T + (size_t)ix.nlist * T + (size_t)T * (SPLITS * TOPK * 2 + 72)) * sizeof(float) + (1 << 20);
 }
 
 namespace {
@@ -67,7 +82,9 @@ __device__ __forceinline__ void topk_insert(float (&bd)[TOPK], int (&bi)[TOPK], 
 __global__ __launch_bounds__(256) void topk_partial_kernel(const float* __restrict__ dots,
                                                            const float* __restrict__ bn,
                                                            const float* __restrict__ qn, float* pd, int* pi,
-                                                           long N, int T, int splits) {
+                                                           long N, int T, int splits,
+                                                           const int* __restrict__ assign,
+                                                           const int* __restrict__ qlist) {
   __shared__ float sd[4][64][TOPK];
   __shared__ int si[4][64][TOPK];
   const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -83,7 +100,9 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(const float* __restri
   }
   if (t < T) {
     const float q = qn[t];
+    const int mylist = qlist ? qlist[t] : -1;
     for (long r = r0 + part; r < r1; r += 4) {
+      if (assign && assign[r] != mylist) continue;     // nprobe = 1: only the query's own inverted list is scanned
       float d = q + bn[r] - 2.f * dots[r * T + t];
       d = fmaxf(d, 0.f);
       topk_insert(bd, bi, d, (int)r);
@@ -106,9 +125,28 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(const float* __restri
   }
 }
 
+// coarse quantiser of an IVF index: nearest centroid per query (IndexFlatL2.search(k = 1) on the centroids; first
+// minimum on ties)
+__global__ void coarse_assign_kernel(const float* __restrict__ cdots, const float* __restrict__ cn,
+                                     const float* __restrict__ qn, int* qlist, int nlist, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float q = qn[t];
+  float best = INFINITY;
+  int bi = 0;
+  for (int r = 0; r < nlist; ++r) {
+    const float d = fmaxf(q + cn[r] - 2.f * cdots[(long)r * T + t], 0.f);
+    if (d < best) {
+      best = d;
+      bi = r;
+    }
+  }
+  qlist[t] = bi;
+}
+
 // merge the per-split candidates, then blend: one block per query
 __global__ __launch_bounds__(256) void merge_blend_kernel(const float* pd, const int* pi, int splits,
-                                                          const float* __restrict__ rows, float* feats, int dim,
+                                                          const float* __restrict__ rows, long N, float* feats, int dim,
                                                           int T, float rate, float one_minus, long long* ids_out,
                                                           float* dist_out) {
   __shared__ float fd[TOPK];
@@ -141,6 +179,9 @@ __global__ __launch_bounds__(256) void merge_blend_kernel(const float* pd, const
       }
     float w[TOPK];
     for (int k = 0; k < TOPK; ++k) {
+      // an inverted list with fewer than 8 vectors: faiss pads with id -1 / distance inf (3.4e38 in 1.7.3); the
+      // reference then reads big_npy[-1] (numpy: the LAST row) with weight (1/inf)^2 = 0  (pipeline.py:243-245)
+      if (bi[k] < 0) bi[k] = (int)(N - 1);
       const float inv = 1.f / bd[k];
       w[k] = inv * inv;                                  // np.square(1 / score)
     }
@@ -149,7 +190,7 @@ __global__ __launch_bounds__(256) void merge_blend_kernel(const float* pd, const
       fd[k] = bd[k];
       fi[k] = bi[k];
       fw[k] = w[k] / ws;
-      if (ids_out) ids_out[(long)t * TOPK + k] = bi[k];
+      if (ids_out) ids_out[(long)t * TOPK + k] = isinf(bd[k]) ? -1 : bi[k];
       if (dist_out) dist_out[(long)t * TOPK + k] = bd[k];
     }
   }
@@ -176,11 +217,20 @@ void index_blend(Ctx& c, const IndexData& ix, float* feats_ct, int T, float inde
   }
   float* qn = A.alloc<float>((size_t)T);
   hipLaunchKernelGGL(qnorm_kernel, dim3(cdiv(T, 256)), dim3(256), 0, s, feats_ct, qn, ix.dim, T);
+  int* qlist = nullptr;
+  if (ix.nlist > 0) {
+    float* cdots = A.alloc<float>((size_t)ix.nlist * T);
+    ConvArgs a = conv1d_args(ix.cent, feats_ct, cdots, 1, T, T);
+    c.conv_on(a, s);
+    qlist = A.alloc<int>((size_t)T);
+    hipLaunchKernelGGL(coarse_assign_kernel, dim3(cdiv(T, 256)), dim3(256), 0, s, cdots, ix.cent_norms, qn, qlist,
+                       ix.nlist, T);
+  }
   float* pd = A.alloc<float>((size_t)SPLITS * T * TOPK);
   int* pi = A.alloc<int>((size_t)SPLITS * T * TOPK);
   hipLaunchKernelGGL(topk_partial_kernel, dim3(cdiv(T, 64), SPLITS), dim3(256), 0, s, dots, ix.norms, qn, pd, pi,
-                     (long)ix.n, T, SPLITS);
-  hipLaunchKernelGGL(merge_blend_kernel, dim3(T), dim3(256), 0, s, pd, pi, SPLITS, ix.rows, feats_ct, ix.dim, T,
+                     (long)ix.n, T, SPLITS, ix.assign, qlist);
+  hipLaunchKernelGGL(merge_blend_kernel, dim3(T), dim3(256), 0, s, pd, pi, SPLITS, ix.rows, (long)ix.n, feats_ct, ix.dim, T,
                      index_rate, (float)(1.0 - (double)index_rate), reinterpret_cast<long long*>(ids), dist);
   RVCX_HIP(hipGetLastError());
 }

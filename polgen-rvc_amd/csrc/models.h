@@ -126,8 +126,15 @@ struct IndexData {
   const float* norms = nullptr; // |b|^2 (N)
   int64_t n = 0;
   int dim = 0;
+  // IVF (faiss "IVF{nlist},Flat" searched with nprobe = 1, what RVC's training writes): the coarse centroids and
+  // the inverted list every stored vector belongs to.  nlist == 0: flat index.
+  ConvW cent;                   // (nlist, dim) as a 1x1 conv
+  const float* cent_norms = nullptr;
+  const int* assign = nullptr;  // (N) list id per stored vector
+  int nlist = 0;
 };
-std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim);
+std::unique_ptr<IndexData> index_load(Ctx& c, const float* big_npy, int64_t n, int dim, const float* centroids = nullptr,
+                                      int nlist = 0, const int32_t* assign = nullptr);
 size_t index_arena_bytes(const IndexData& ix, int T);
 // feats_ct (dim, T) channel-first in/out (device); ids (T,8) int64 / dist (T,8) optional device outputs
 void index_blend(Ctx& c, const IndexData& ix, float* feats_ct, int T, float index_rate, int64_t* ids,

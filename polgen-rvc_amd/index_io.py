@@ -2,9 +2,12 @@
 (rvc/infer/pipeline.py:322-323), without faiss.
 
 Supported: ``.npy`` dumps of big_npy, FAISS ``IndexFlat`` ("IxF2"/"IxFI") and ``IndexIVFFlat`` ("IwFl",
-array inverted lists).  The FAISS binary layouts are restated from the published faiss 1.7 io format;
-faiss is not installed here, so the FAISS branches are UNVERIFIED against a real file (parity unpinned).
-Search in rvcx is exact brute force; IVF probing (nprobe) is not reproduced.
+array inverted lists).  The FAISS binary layouts are restated from the published faiss 1.7 io format
+(impl/index_read.cpp: read_index_header, read_ivf_header, read_direct_map, read_InvertedLists); faiss is not
+installed here, so they are checked against a test-side encoder of the same layout (tests/faiss_writer.py), not
+against a file faiss wrote (parity unpinned).  For an IVF file the coarse centroids, the list of every stored
+vector and ``nprobe`` are returned too: rvcx then searches like faiss does -- only the query's nearest list when
+nprobe = 1 (what RVC index files carry).
 """
 from __future__ import annotations
 
@@ -44,6 +47,17 @@ def _header(r):
     return d, ntotal
 
 
+class IndexFile:
+    """What ``faiss.read_index`` + ``reconstruct_n(0, ntotal)`` give the reference (pipeline.py:322-323)."""
+
+    def __init__(self, vectors, centroids=None, assign=None, nprobe=None):
+        self.vectors, self.centroids, self.assign, self.nprobe = vectors, centroids, assign, nprobe
+
+    @property
+    def is_ivf(self):
+        return self.centroids is not None
+
+
 def _read_index(r):
     cc = r.fourcc()
     if cc in ("IxF2", "IxFI", "IxFl"):
@@ -53,7 +67,9 @@ def _read_index(r):
     if cc == "IwFl":
         d, ntotal = _header(r)
         nlist, nprobe = r.take("Q"), r.take("Q")
-        _read_index(r)                       # coarse quantizer
+        centroids, _ = _read_index(r)        # coarse quantizer (an IndexFlat of nlist centroids)
+        if centroids.shape != (nlist, d):
+            raise ValueError("IVF coarse quantizer does not hold nlist centroids")
         dm_type = r.take("B")                # direct map
         r.vec(np.int64)
         if dm_type == 2:
@@ -71,8 +87,11 @@ def _read_index(r):
             sizes[sp[0::2].astype(np.int64)] = sp[1::2]
         else:
             raise ValueError(f"unsupported list type {lt!r}")
+        if code_size != 4 * d or nl != nlist:
+            raise ValueError("IVF inverted lists are not flat float32 codes")
         out = np.zeros((ntotal, d), np.float32)
-        for sz in sizes:
+        assign = np.full(ntotal, -1, np.int32)
+        for li, sz in enumerate(sizes):
             sz = int(sz)
             codes = np.frombuffer(r.b, np.uint8, sz * code_size, r.o)
             r.o += sz * code_size
@@ -80,17 +99,26 @@ def _read_index(r):
             r.o += sz * 8
             if sz:
                 out[ids] = codes.view(np.float32).reshape(sz, d)
-        return out, None
+                assign[ids] = li
+        if (assign < 0).any():
+            raise ValueError("IVF index: stored ids are not 0..ntotal-1 (reconstruct_n would fail in the reference too)")
+        return out, dict(centroids=centroids, assign=assign, nprobe=int(nprobe))
     raise ValueError(f"unsupported FAISS index type {cc!r}")
 
 
-def read_index_vectors(path: str) -> np.ndarray:
+def read_index(path: str) -> IndexFile:
     if path.endswith(".npy"):
         a = np.load(path)
         if a.ndim != 2:
             raise ValueError("big_npy must be 2-D")
-        return np.ascontiguousarray(a, np.float32)
+        return IndexFile(np.ascontiguousarray(a, np.float32))
     with open(path, "rb") as f:
         data = f.read()
-    mat, _ = _read_index(_R(data))
-    return mat
+    mat, ivf = _read_index(_R(data))
+    if ivf is None:
+        return IndexFile(mat)
+    return IndexFile(mat, np.ascontiguousarray(ivf["centroids"], np.float32), ivf["assign"], ivf["nprobe"])
+
+
+def read_index_vectors(path: str) -> np.ndarray:
+    return read_index(path).vectors

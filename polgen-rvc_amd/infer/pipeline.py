@@ -177,9 +177,13 @@ class VC:
         try:
             key = _state.file_key(file_index)
             if _INDEX_RESIDENT.get(id(ctx)) != key:
-                from ..index_io import read_index_vectors
-                big_npy = read_index_vectors(file_index)
-                ctx.load_index(big_npy)
+                from ..index_io import read_index
+                ix = read_index(file_index)
+                big_npy = ix.vectors
+                if ix.is_ivf:       # RVC's "IVF{n},Flat" files: searched like faiss does, nprobe from the file
+                    ctx.load_index_ivf(big_npy, ix.centroids, ix.assign, ix.nprobe)
+                else:
+                    ctx.load_index(big_npy)
                 _INDEX_RESIDENT[id(ctx)] = key
                 ctx._index_shape = big_npy.shape
             n, d = getattr(ctx, "_index_shape", (0, 0))

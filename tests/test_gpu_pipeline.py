@@ -230,3 +230,41 @@ def test_odd_lengths_vs_oracle(ctx, seconds, clip):
     e = rms(f32 - parts["audio_f32"])
     assert e < 1e-4, e
     assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 8
+
+
+def test_ivf_index_file_is_searched_like_faiss_nprobe_1(ctx, tmp_path):
+    """Real RVC ``.index`` files are faiss "IVF{nlist},Flat" searched with nprobe = 1 (pipeline.py:242,322-323): only
+    the inverted list of the query's nearest centroid is scanned -- NOT brute force.  A byte stream of that layout
+    (tests/faiss_writer.py) goes through index_io -> rvcx_load_index_ivf; neighbour ids equal the oracle's float64
+    restatement of the IVF rule bit for bit (and differ from the flat search's), a list with fewer than 8 vectors
+    pads with id -1 / weight 0, blended features within 1e-5."""
+    import faiss_writer as FW
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import index_io, synthetic as S
+    g = np.random.Generator(np.random.PCG64(11))
+    big = S.make_index(4096, 128, 3)
+    cent = big[g.choice(4096, 40, replace=False)] + 0.05 * g.standard_normal((40, 128)).astype(np.float32)
+    d2 = ((big.astype(np.float64) ** 2).sum(1)[:, None] - 2.0 * big.astype(np.float64) @ cent.astype(np.float64).T
+          + (cent.astype(np.float64) ** 2).sum(1)[None, :])
+    assign = np.argmin(d2, axis=1).astype(np.int32)
+    small = int(np.argmin(np.bincount(assign, minlength=40)))
+    keep = np.where(assign == small)[0][:3]                   # make one list shorter than k = 8
+    assign[(assign == small) & ~np.isin(np.arange(4096), keep)] = (small + 1) % 40
+    path = os.path.join(tmp_path, "voice.index")
+    open(path, "wb").write(FW.ivf_flat_bytes(big, cent, assign, nprobe=1))
+    ix = index_io.read_index(path)
+    assert ix.is_ivf and ix.nprobe == 1
+    ctx.load_index_ivf(ix.vectors, ix.centroids, ix.assign, ix.nprobe)
+    try:
+        q = (big[g.integers(0, 4096, 400)] + 0.3 * g.standard_normal((400, 128))).astype(np.float32)
+        q[:5] = cent[small] + 0.01 * g.standard_normal((5, 128)).astype(np.float32)     # queries of the short list
+        out, ids, dist = ctx.index_blend(q, 0.75)
+        ref, rids, rdist = OP.index_blend_ivf(q, big, cent, assign, 0.75)
+        _, flat_ids, _ = OP.index_blend(q, big, 0.75)
+        assert (ids == rids).all()
+        assert (ids[:5, 3:] == -1).all() and (ids[:5, :3] >= 0).all()
+        assert (np.sort(ids, 1) != np.sort(flat_ids, 1)).any()
+        ok = np.isfinite(ref).all(1)
+        assert ok.all() and rms(out - ref) / rms(ref) < 1e-5
+    finally:
+        ctx.load_index(None)

@@ -128,6 +128,51 @@ def test_index_io_npy_and_flat(tmp_path):
     assert np.array_equal(index_io.read_index_vectors(q), big)
 
 
+def test_index_io_ivf_flat_roundtrip(tmp_path):
+    """A faiss "IVF{nlist},Flat" byte stream (tests/faiss_writer.py, the layout RVC's training writes): vectors come
+    back in id order as reconstruct_n returns them, with the coarse centroids, the list of every vector and nprobe;
+    both encodings of the list sizes ("full" / "sprs"); an empty list is fine."""
+    import faiss_writer as FW
+    g = np.random.Generator(np.random.PCG64(4))
+    big = S.make_index(300, 24, 2)
+    cent = g.standard_normal((7, 24)).astype(np.float32)
+    d2 = ((big[:, None, :].astype(np.float64) - cent[None].astype(np.float64)) ** 2).sum(-1)
+    d2[:, 5] = np.inf                                     # list 5 stays empty
+    assign = np.argmin(d2, axis=1).astype(np.int32)
+    for sparse in (False, True):
+        q = os.path.join(tmp_path, f"ivf{int(sparse)}.index")
+        open(q, "wb").write(FW.ivf_flat_bytes(big, cent, assign, nprobe=1, sparse_sizes=sparse))
+        ix = index_io.read_index(q)
+        assert ix.is_ivf and ix.nprobe == 1
+        assert np.array_equal(ix.vectors, big) and np.array_equal(ix.centroids, cent) and np.array_equal(ix.assign, assign)
+        assert np.array_equal(index_io.read_index_vectors(q), big)
+    q = os.path.join(tmp_path, "flat.index")
+    open(q, "wb").write(FW.flat_bytes(big))
+    ix = index_io.read_index(q)
+    assert not ix.is_ivf and np.array_equal(ix.vectors, big)
+
+
+def test_oracle_ivf_search_differs_from_flat_where_it_should():
+    """nprobe = 1 is not brute force: a query whose true nearest neighbours sit in a neighbouring list gets other
+    ids.  The oracle restates both rules; the padding case (a list shorter than 8) yields id -1 with weight 0."""
+    from oracle import pipeline as OP
+    g = np.random.Generator(np.random.PCG64(7))
+    big = g.standard_normal((500, 16)).astype(np.float32)
+    cent = g.standard_normal((12, 16)).astype(np.float32)
+    d2 = ((big[:, None, :].astype(np.float64) - cent[None].astype(np.float64)) ** 2).sum(-1)
+    assign = np.argmin(d2, axis=1).astype(np.int32)
+    q = g.standard_normal((64, 16)).astype(np.float32)
+    _, flat_ids, _ = OP.index_blend(q, big, 0.5)
+    out, ivf_ids, score = OP.index_blend_ivf(q, big, cent, assign, 0.5)
+    assert (np.sort(flat_ids, 1) != np.sort(ivf_ids, 1)).any()
+    qlist = np.argmin(((q[:, None, :].astype(np.float64) - cent[None].astype(np.float64)) ** 2).sum(-1), axis=1)
+    for t in range(len(q)):
+        real = ivf_ids[t][ivf_ids[t] >= 0]
+        assert (assign[real] == qlist[t]).all()
+        assert len(real) == min(8, int((assign == qlist[t]).sum()))
+    assert np.isfinite(out[(ivf_ids >= 0).any(1)]).all()
+
+
 def test_shard_is_a_balanced_partition():
     lens = [5, 30, 12, 7, 30, 9, 15, 3, 11]
     parts = [D.shard(len(lens), r, 4, lens) for r in range(4)]
