@@ -229,9 +229,27 @@ int rvcx_op_resblock_pair(rvcx_ctx* ctx, const float* x, const float* w1, const 
     pa.k = K;
     pa.dil = dil;
     pa.slope = slope;
-    if (!resblock_pair_ok(pa)) fail("resblock pair: shape not supported by the fused kernel");
+    if (!resblock_pair_ok(pa) && !g_force_fp32) fail("resblock pair: shape not supported by the fused kernel");
+  }
+  if (fused && !g_force_fp32) {
+    PairArgs pa;
+    pa.x = dx;
+    pa.y = dy;
+    pa.w1 = L1.w_h3;
+    pa.w2 = L2.w_h3;
+    pa.b1 = L1.bias;
+    pa.b2 = L2.bias;
+    pa.lens = dl;
+    pa.B = B;
+    pa.C = Cc;
+    pa.T = T;
+    pa.bs = (long)Cc * T;
+    pa.cs = T;
+    pa.k = K;
+    pa.dil = dil;
+    pa.slope = slope;
     C->pair_on(pa, C->stream);
-  } else {   // the two launches the fused kernel replaces (synth.hip's fallback path)
+  } else {   // the two launches the fused kernel replaces (synth.hip's fallback path; also the exact-fp32 rerun)
     ConvArgs a = conv1d_args(L1, dx, dt, B, T, T, 1, dil, (K * dil - dil) / 2);
     a.pre_act = ACT_LRELU;
     a.pre_slope = slope;

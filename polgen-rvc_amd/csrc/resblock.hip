@@ -359,6 +359,7 @@ void resblock_pair_describe(ConvProfile* p) {
 
 void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
   RVCX_CHECK(resblock_pair_ok(a), "resblock pair: unsupported shape");
+  RVCX_CHECK(a.y != a.x && a.y2 != a.x, "resblock pair: in-place operation is a race (halo reads vs neighbours' stores)");
   static const bool init = [] {       // once per process, also when several contexts start on different threads
     for (const auto& c : kPair)
       RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,

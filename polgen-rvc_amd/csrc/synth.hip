@@ -390,9 +390,11 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
           const int d = cf.res_dilations[j][mi];
           // ---- fused step (resblock.hip): c1 -> c2 -> + x in one kernel, xt never leaves the CU
           {
+            // x and y must be different buffers: a workgroup reads a halo of x that its neighbours own as output
+            float* yout = (xin == xc) ? xt : xc;
             PairArgs pa;
             pa.x = xin;
-            pa.y = xc;
+            pa.y = yout;
             pa.w1 = (S.c1[j][mi].w_h3 && S.c1[j][mi].h3_ok && *S.c1[j][mi].h3_ok) ? S.c1[j][mi].w_h3 : nullptr;
             pa.w2 = (S.c2[j][mi].w_h3 && S.c2[j][mi].h3_ok && *S.c2[j][mi].h3_ok) ? S.c2[j][mi].w_h3 : nullptr;
             pa.b1 = S.c1[j][mi].bias;
@@ -417,28 +419,30 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
               }
               c.pair_on(pa, sj);
               if (mi == 2) RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
-              xin = xc;
+              xin = yout;
               continue;
             }
           }
-          a = conv1d_args(S.c1[j][mi], xin, xt, db, (int)Tout, (int)Tout, 1, d, (k * d - d) / 2);
+          float* XT_ = (xin == xt) ? xc : xt;     // unfused fallback: c1 output / c2 output (c2 may run in place on xin)
+          float* XC_ = (xin == xt) ? xt : xc;
+          a = conv1d_args(S.c1[j][mi], xin, XT_, db, (int)Tout, (int)Tout, 1, d, (k * d - d) / 2);
           a.pre_act = ACT_LRELU;
           a.pre_slope = 0.1f;
           a.act = ACT_LRELU;       // the leaky_relu that precedes c2, applied once here
           a.act_slope = 0.1f;
           a.lens_in = lout;
           a.lens_out = lout;
-          // c1 -> c2 hand-off: when both run on the split-fp16 kernels, xt travels already split (hi / scaled lo
+          // c1 -> c2 hand-off: when both run on the split-fp16 kernels, XT_ travels already split (hi / scaled lo
           // halves in the consumer's LDS element order): c2 stages it with 16-byte loads and no conversion
-          ConvArgs a2 = conv1d_args(S.c2[j][mi], xt, xc, db, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
+          ConvArgs a2 = conv1d_args(S.c2[j][mi], XT_, XC_, db, (int)Tout, (int)Tout, 1, 1, (k - 1) / 2);
           const bool split = conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
           if (split) {
-            a.y_split = xt;
+            a.y_split = XT_;
             a.y = nullptr;
           }
           c.conv_on(a, sj);
           a = a2;
-          if (split) a.x_split = xt;
+          if (split) a.x_split = XT_;
           conv_set_res(a, xin, S.ch, (int)Tout);
           a.lens_in = lout;
           a.lens_out = lout;
@@ -454,7 +458,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
           }
           c.conv_on(a, sj);
           if (mi == 2) RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
-          xin = xc;
+          xin = XC_;
         }
       }
       if (rs[nk - 1] != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_aux[nk], 0));   // join before the next stage

@@ -197,7 +197,7 @@ def _check_vs_fixture(d, pre, pcm, f32, tgt_sr):
     return e, int(diff.max()), float(np.mean(diff > 1)), blocks
 
 
-def test_c5_two_resident_models_interleaved_vs_reference(ctx):
+def test_c5_two_resident_models_interleaved_vs_reference():
     """BASELINE configs[4] in small, against the REFERENCE (fixture pipeline_c5_two_models, produced by the
     reference's own VC.pipeline): a 40 k and a 48 k voice model at full size share one HuBERT and one RMVPE in a
     context; utterances of different lengths are converted alternately, twice -- every result matches the
@@ -207,6 +207,7 @@ def test_c5_two_resident_models_interleaved_vs_reference(ctx):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_c5_two_models.npz"))
     seed = int(d["seed"])
     hcfg, rcfg = json.loads(str(d["hcfg"])), json.loads(str(d["rcfg"]))
+    ctx = _lib.Context(0)          # its own context: this test brings its own HuBERT / RMVPE (fixture seed)
     ctx.load_hubert(W.hubert_cfg_struct(hcfg), S.hubert_state(hcfg, seed))
     ctx.load_rmvpe(W.rmvpe_cfg_struct(rcfg), S.rmvpe_state(rcfg, seed))
     mids, utts = {}, []
@@ -233,8 +234,7 @@ def test_c5_two_resident_models_interleaved_vs_reference(ctx):
                 else:
                     assert np.array_equal(first[pre], pcm[0])
     finally:
-        for mid in mids.values():
-            _lib.lib().rvcx_unload_synth(ctx._h, mid)
+        ctx.close()
 
 
 def test_c3_item_with_retrieval_blend_vs_reference(ctx, full):
