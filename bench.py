@@ -79,10 +79,20 @@ def pmc_traffic(tile_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE are separate profiler runs of this same command; bench.py cannot collect them itself)."""
     import re
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
     if not os.path.exists(path):
         return None, None
     kernels = json.load(open(path))["kernels"]
+    src = "profiles/pmc_traffic_r02.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, RVCX_SERIAL=1)"
+    mp = re.match(r"resblock_pair<C=(\d+),N1=(\d+)>", tile_name)
+    if mp:
+        want = f"resblock_pair_kernel<{mp.group(1)},"
+        tot_b, tot_n = 0.0, 0
+        for k, v in kernels.items():          # the (C, k) instantiations of one channel count share the profile slot
+            if want in k:
+                tot_b += v["hbm_bytes_per_launch"] * v["launches"]
+                tot_n += v["launches"]
+        return (tot_b / tot_n, src) if tot_n else (None, None)
     mh = re.match(r"conv_h3<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
     if mh:
         want = f"conv_h3_kernel<{mh.group(1)}, {mh.group(2)},"
@@ -91,7 +101,7 @@ def pmc_traffic(tile_name):
             mh.group(3), f", {mh.group(4)}, 1, false, false>")
         for k, v in kernels.items():
             if want in k and tail in k:
-                return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r02.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         return None, None
     m = re.match(r"conv_fast_(sb|db)<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
     if not m:
@@ -103,7 +113,7 @@ def pmc_traffic(tile_name):
         tail += ", 1>"   # trailing STRIDE template argument of conv_fast_sb_kernel
     for k, v in kernels.items():
         if want in k and tail in k:
-            return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r02.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
     return None, None
 
 
@@ -220,7 +230,7 @@ def main():
         conv_flops = sum(r["flops"] for r in prof)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dom["tile"])
-        h3 = dom["tile"].startswith("conv_h3")
+        h3 = dom["tile"].startswith("conv_h3") or dom["tile"].startswith("resblock_pair")
         peak = PEAK_H3_TFLOPS if h3 else PEAK_F32_TFLOPS
         roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,

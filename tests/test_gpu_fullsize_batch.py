@@ -131,9 +131,13 @@ def test_weight_regions_survive_a_simulated_broadcast(ctx, full):
         ra, ha = src.weights_regions()
         rb, hb = other.weights_regions()
         assert ha == hb and [n for _, n in ra] == [n for _, n in rb] and len(ra) > 3
-        hip = C.CDLL("libamdhip64.so")
+        # chunk by chunk through the zero-copy device views dist.broadcast_weights hands to RCCL
+        import torch
+        from polgen_rvc_amd import dist as D
+        dev = torch.device("cuda", 0)
         for (pa, n), (pb, _) in zip(ra, rb):
-            assert hip.hipMemcpy(C.c_void_p(pb), C.c_void_p(pa), C.c_size_t(n), 3) == 0
+            D._view(pb, n, dev).copy_(D._view(pa, n, dev))
+        torch.cuda.synchronize()
         other.weights_adopt()
         clip = S.make_clip(3, 6.0)
         a = src.convert_batch(mid1, [clip], _params(seed=2))[0]
@@ -268,7 +272,9 @@ def test_c3_item_with_retrieval_blend_vs_reference(ctx, full):
         pcm4 = ctx.convert_batch(full, [others[0], clip, others[1], others[2]], p, noises=[None, noise, None, None])
         assert np.array_equal(pcm4[1], pcm[0])
         # without the blend the waveform is a different one: the fixture really exercises the retrieval path
+        # (the planted neighbours sit within 0.005 per channel of the queries, so the blend moves the waveform
+        # only a little -- but several times more than the distance to the reference)
         pcm0, f0_ = ctx.convert_batch(full, [clip], _params(), noises=[noise], want_f32=True)
-        assert rms(f0_[0] - f32[0]) > 1e-4
+        assert rms(f0_[0] - f32[0]) > 3 * e
     finally:
         ctx.load_index(None)
