@@ -103,6 +103,10 @@ int rvcx_load_index_ivf(rvcx_ctx*, const float* big_npy, int64_t n, int dim, con
  * the value-dependent layer flags that travel in each region's header. */
 int rvcx_weights_regions(rvcx_ctx*, int cap, void** dev_ptrs, int64_t* nbytes, uint64_t* layout_hash);
 int rvcx_weights_adopt(rvcx_ctx*);
+/* Same-device counterpart of the broadcast: copy the folded weights of `src` into this context, which must have
+ * loaded the same configurations (placeholder values allowed) -- a second or third context per GPU (several
+ * conversions in flight) then costs a device copy instead of parsing and folding again. */
+int rvcx_weights_clone(rvcx_ctx*, rvcx_ctx* src);
 
 /* ---- stage-level entry points (parity tests bind these) ------------------------------- */
 /* RMVPE0Predictor.infer_from_audio_with_pitch -- rvc/lib/predictors/RMVPE.py:487-496.
@@ -196,6 +200,8 @@ int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, do
                       int32_t* bn, int32_t* kind, int cap);
 /* per-launch table (CSV text: tile,B,cin,cout,k,stride,nout,gflop,ms,tflops) of the last profile */
 const char* rvcx_conv_profile_csv(rvcx_ctx*);
+/* free / total bytes of the context's GPU (hipMemGetInfo): what is left for further voice models and indices */
+int rvcx_mem_info(rvcx_ctx*, int64_t* free_bytes, int64_t* total_bytes);
 /* calls this context repeated on the exact-fp32 kernels because a split-fp16 kernel met an activation beyond
  * fp16 range (|x| >= 6e4; attention K / V >= 234): the default kernels form fp32-grade products from fp16 hi/lo
  * halves, which have fp16's exponent range.  The repeat is automatic and transparent; this counter reports it. */

@@ -59,11 +59,11 @@ _lib = None
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
     "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
-    "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
+    "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_weights_clone", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
-    "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
+    "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass",
 ]
@@ -496,6 +496,10 @@ class Context:
             raise RvcxError("weights_regions: chunk count changed between calls")
         return [(int(ptrs[i] or 0), int(sizes[i])) for i in range(n)], int(h.value)
 
+    def weights_clone(self, src: "Context"):
+        """copy the folded weights of ``src`` (same GPU, same model configurations) into this context"""
+        self._ck(lib().rvcx_weights_clone(self._h, src._h), "weights_clone")
+
     def weights_adopt(self):
         self._ck(lib().rvcx_weights_adopt(self._h), "weights_adopt")
 
@@ -535,6 +539,11 @@ class Context:
         lib().rvcx_last_timing(self._h, ms)
         names = ["highpass", "rmvpe", "hubert", "index", "enc_p", "flow", "decoder", "post", "total"]
         return dict(zip(names, [float(v) for v in ms]))
+
+    def mem_info(self):
+        f, t = C.c_int64(0), C.c_int64(0)
+        self._ck(lib().rvcx_mem_info(self._h, C.byref(f), C.byref(t)), "mem_info")
+        return f.value, t.value
 
     def fp32_reruns(self) -> int:
         """calls repeated on the exact-fp32 kernels after an fp16-split overflow"""

@@ -138,6 +138,15 @@ const char* rvcx_last_error(rvcx_ctx* ctx) {
 
 void* rvcx_stream(rvcx_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
 
+int rvcx_mem_info(rvcx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
+  API_BEGIN(ctx)
+  size_t f = 0, t = 0;
+  RVCX_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  API_END
+}
+
 int64_t rvcx_fp32_reruns(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.fp32_reruns : -1; }
 
 double rvcx_flop_counter(rvcx_ctx* ctx, int reset) {
@@ -582,6 +591,25 @@ int rvcx_weights_regions(rvcx_ctx* ctx, int cap, void** dev_ptrs, int64_t* nbyte
     if (C) C->last_error = e.what();
     return -1;
   }
+}
+
+int rvcx_weights_clone(rvcx_ctx* ctx, rvcx_ctx* src) {
+  API_BEGIN(ctx)
+  if (!src) fail("weights_clone: null source context");
+  if (src->c.device != C->device) fail("weights_clone: contexts live on different devices (use the RCCL broadcast)");
+  uint64_t ha = 0, hb = 0;
+  std::vector<WeightRegion*> ra = all_regions(src->c, &ha), rb = all_regions(*C, &hb);
+  if (ha != hb || ra.size() != rb.size()) fail("weights_clone: the two contexts hold different model layouts");
+  RVCX_HIP(hipDeviceSynchronize());
+  for (size_t r = 0; r < ra.size(); ++r) {
+    if (ra[r]->n_chunks() != rb[r]->n_chunks()) fail("weights_clone: chunk lists differ");
+    for (int i = 0; i < ra[r]->n_chunks(); ++i) {
+      if (ra[r]->chunk_used(i) != rb[r]->chunk_used(i)) fail("weights_clone: chunk sizes differ");
+      RVCX_HIP(hipMemcpy(rb[r]->chunk_base(i), ra[r]->chunk_base(i), ra[r]->chunk_used(i), hipMemcpyDeviceToDevice));
+    }
+    rb[r]->adopt();
+  }
+  API_END
 }
 
 int rvcx_weights_adopt(rvcx_ctx* ctx) {

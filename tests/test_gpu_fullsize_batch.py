@@ -113,9 +113,8 @@ def test_ragged_full_size_batch_equals_single_runs(ctx, full):
 def test_weight_regions_survive_a_simulated_broadcast(ctx, full):
     """the weight layout must depend on shapes only.  A second context loads ZERO-filled
     tensors of the same configurations (weight-norm folds of zeros are NaN), must report the same chunk sizes
-    and layout hash, receives the first context's chunks (device-to-device copies stand in for the RCCL
-    broadcast on this 1-GPU box), adopts the flags -- and then converts bit-identically."""
-    import ctypes as C
+    and layout hash, receives the first context's chunks (rvcx_weights_clone: device-to-device copies stand in for
+    the RCCL broadcast on this 1-GPU box), adopts the flags -- and then converts bit-identically."""
     from polgen_rvc_amd import _lib, synthetic as S, weights as W
     other = _lib.Context(0)
     try:
@@ -131,14 +130,7 @@ def test_weight_regions_survive_a_simulated_broadcast(ctx, full):
         ra, ha = src.weights_regions()
         rb, hb = other.weights_regions()
         assert ha == hb and [n for _, n in ra] == [n for _, n in rb] and len(ra) > 3
-        # chunk by chunk through the zero-copy device views dist.broadcast_weights hands to RCCL
-        import torch
-        from polgen_rvc_amd import dist as D
-        dev = torch.device("cuda", 0)
-        for (pa, n), (pb, _) in zip(ra, rb):
-            D._view(pb, n, dev).copy_(D._view(pa, n, dev))
-        torch.cuda.synchronize()
-        other.weights_adopt()
+        other.weights_clone(src)          # chunk-by-chunk device copies + adopt: what the broadcast does per rank
         clip = S.make_clip(3, 6.0)
         a = src.convert_batch(mid1, [clip], _params(seed=2))[0]
         b = other.convert_batch(mid2, [clip], _params(seed=2))[0]
@@ -150,14 +142,10 @@ def test_weight_regions_survive_a_simulated_broadcast(ctx, full):
 
 def test_voice_model_regions_are_freed_on_unload(ctx):
     """loading and unloading voice models / indices repeatedly must not exhaust anything."""
-    import ctypes as C
     from polgen_rvc_amd import _lib, synthetic as S, weights as W
-    hip = C.CDLL("libamdhip64.so")
-    free0, tot = C.c_size_t(0), C.c_size_t(0)
 
     def free_bytes():
-        hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
-        return free0.value
+        return ctx.mem_info()[0]
     st = S.synth_state(S.SYNTH_CFG_48K, 3)
     cfg = W.synth_cfg_struct(S.SYNTH_CFG_48K, 768)
     mid = ctx.load_synth(cfg, st)
