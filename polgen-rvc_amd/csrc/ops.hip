@@ -17,13 +17,24 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // ------------------------------------------------------------------ LayerNorm over channels
 // block = 16 time steps x 16 channel slices (T is only a few thousand frames: small column groups keep
 // every CU busy); each thread caches its <= LN_MAXC/16 channel values in registers: one global read.
+// Reductions over the channel axis: a wavefront holds 4 channel slices of the 16 time steps (lane = tx + 16 p), so
+// the partial sums of a time step are combined with two wavefront shuffles (xor 16, xor 32); the four waves of the
+// block then exchange one value per time step through a 4 x 16 LDS array.
 constexpr int LN_TX = 16, LN_PARTS = 16, LN_MAXC = 1024, LN_RPT = LN_MAXC / LN_PARTS;
 __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           int C, int T, float eps, const int* lens) {
-  __shared__ float red[LN_PARTS][LN_TX];
+  __shared__ float red[2][4][LN_TX];
   const int tx = threadIdx.x % LN_TX, part = threadIdx.x / LN_TX;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto block_sum = [&](float v, int slot) {     // sum over the 16 channel slices of time step tx
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < LN_TX) red[slot][wave][tx] = v;
+    __syncthreads();
+    return (red[slot][0][tx] + red[slot][1][tx]) + (red[slot][2][tx] + red[slot][3][tx]);
+  };
   const int b = blockIdx.y;
   const int t = blockIdx.x * LN_TX + tx;
   const bool valid = t < T;
@@ -42,13 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
     v[k] = (valid && c < C) ? v[k] : 0.f;
     s += v[k];
   }
-  red[part][tx] = s;
-  __syncthreads();
-  float tot = 0.f;
-#pragma unroll
-  for (int p = 0; p < LN_PARTS; ++p) tot += red[p][tx];
-  const float mean = tot / (float)C;
-  __syncthreads();
+  const float mean = block_sum(s, 0) / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < LN_RPT; ++k) {
@@ -56,12 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
     const float d = (c < C) ? v[k] - mean : 0.f;
     q += d * d;
   }
-  red[part][tx] = q;
-  __syncthreads();
-  float vt = 0.f;
-#pragma unroll
-  for (int p = 0; p < LN_PARTS; ++p) vt += red[p][tx];
-  const float rstd = 1.f / sqrtf(vt / (float)C + eps);
+  const float rstd = 1.f / sqrtf(block_sum(q, 1) / (float)C + eps);
   if (!valid) return;
   const bool live = !lens || t < lens[b];
 #pragma unroll

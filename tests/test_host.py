@@ -269,3 +269,18 @@ def test_load_audio_resamples_other_rates(tmp_path):
     assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3
     wavfile.write(tmp_path / "b.wav", 16000, (ref * 32767).astype(np.int16))
     assert np.abs(I.load_audio(str(tmp_path / "b.wav"), 16000) - ref).max() < 1e-4
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """bench.py --gpus N must stop before touching anything when the node does not have N GPUs (this container: 0)
+    or when it was not started one process per GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout)
