@@ -72,7 +72,9 @@ __device__ __forceinline__ void store_tile_split(const ConvArgs& a, int b, int c
 // XS: the input arrives pre-split (ConvArgs::x_split) -- a separate instantiation so that the fp32-input staging
 // code keeps its straight-line, batched loads.
 template <int BM, int BN, int WR, int WC, int KKT, int HALO, int STRIDE, bool LIN, bool XS = false>
-__global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a) {
+// (min waves per SIMD: 3 = at most 168 VGPRs.  The large Linear tiles and the 32x512 3x3 tile need more registers --
+// forced under 168 they spilled 68..213 of them -- and run two waves per SIMD instead.)
+__global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 3) void conv_h3_kernel(const ConvArgs a) {
   constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
   constexpr int WROW = LIN ? BN : BN * STRIDE + HALO;
   constexpr int NBTILE = LIN ? KKT : 1;               // input tiles resident per stage
