@@ -193,7 +193,7 @@ int rvcx_vc_frames(rvcx_ctx*, int64_t n);
 int rvcx_last_timing(rvcx_ctx*, float* ms9);
 /* HIP-event profile of the MFMA conv kernel family: begin=1 starts recording an event pair around
  * every conv launch on the library stream; begin=0 stops and returns, per tile configuration
- * (<= 40 entries; kind: -1 generic strided kernel, halo*10+{0 single-buffered, 1 LDS-DMA} for the stride-1
+ * (kind: -1 generic strided kernel, halo*10 for the stride-1
  * family, 100000/100001 its Linear variants), the launch count, algorithmic FLOPs (2*M*N*K of the unpadded problem) and the
  * summed kernel milliseconds, plus the tile shape (bm x bn). */
 int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
@@ -230,7 +230,7 @@ int rvcx_bench_resblock_pair(rvcx_ctx*, int B, int C, int T, int K, int dil, int
 int rvcx_bench_conv1d(rvcx_ctx*, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
                       int iters, float* ms_per_launch);
 /* tuning hook for the tile-selection sweep (tools/sweep_conv.py): force the conv_fast tile index, the
- * staging variant (0 register-staged, 1 LDS-DMA double-buffered) and the split-K factor; -1 = heuristic.
+ * staging variant (ignored: the LDS-DMA variant was removed in round 2) and the split-K factor; -1 = heuristic.
  * Process-wide; never set by the product path. */
 int rvcx_conv_override(int tile, int variant, int splitk);
 /* ConvTranspose1d: w (Cin,Cout,K), padding p; Tout = (Tin-1)*s - 2p + K */

@@ -526,8 +526,8 @@ class Context:
             if kd[i] >= 200000:
                 return f"conv_fast_sb<{bm[i]},{bn[i]},stride2>"
             if kd[i] >= 100000:
-                return f"conv_fast{'_db' if kd[i] % 10 else '_sb'}<{bm[i]},{bn[i]},linear>"
-            return f"conv_fast{'_db' if kd[i] % 10 else '_sb'}<{bm[i]},{bn[i]},halo{kd[i] // 10}>"
+                return f"conv_fast_sb<{bm[i]},{bn[i]},linear>"
+            return f"conv_fast_sb<{bm[i]},{bn[i]},halo{kd[i] // 10}>"
         return [dict(tile=name(i), launches=int(la[i]), flops=float(fl[i]), ms=float(ms[i]))
                 for i in range(N) if la[i] > 0]
 

@@ -26,19 +26,6 @@
 
 namespace rvcx {
 
-// LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base) + lane*SIZE.
-// Asynchronous (tracked by vmcnt), no VGPRs.  The builtin only exists in the device pass; hiding it from
-// the host pass keeps the host-side kernel stubs of this template instantiable.
-__device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_global_load_lds(g, lds_wave_base, 16, 0, 0);
-#endif
-}
-__device__ __forceinline__ void dma4(const float* g, float* lds_wave_base) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_global_load_lds(g, lds_wave_base, 4, 0, 0);
-#endif
-}
 // Buffer loads through a 128-bit resource descriptor: 32-bit byte offsets and hardware range checking -- an
 // offset >= num_records returns 0, so the zero fill of the sequence edges / padded channels / padded taps is
 // a select on the OFFSET and every load is unconditional (the compiler turned `valid ? *p : 0` into
@@ -74,203 +61,6 @@ __device__ __forceinline__ void wait_all_memory() {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_s_waitcnt(0);
 #endif
-}
-
-template <int BM, int BN, int WR, int WC, int KKT, int CIC, int HALO>
-__global__ __launch_bounds__(256, 3) void conv_fast_kernel(const ConvArgs a) {
-  constexpr int WM = BM / (32 * WR), WN = BN / (32 * WC);
-  constexpr int WROW = BN + HALO;
-  constexpr int A_FLOATS = KKT * CIC * BM;
-  constexpr int B_FLOATS = CIC * WROW;
-  constexpr int NA4 = A_FLOATS / 1024;
-  constexpr int NBJ = WROW / 64;
-  static_assert(WR * WC == 4 && A_FLOATS % 1024 == 0 && CIC % 4 == 0 && WROW % 64 == 0, "bad tile");
-  // two pipeline stages: LDS-DMA (global_load_lds) fills stage s+1 while the MFMAs consume stage s
-  __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WC, wc = wave % WC;
-  const int i = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z / a.splitk, ks = blockIdx.z - b * a.splitk;
-  const int co0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
-  const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
-  const float* xg = a.x + (long)b * a.x_bs;
-  const int in_base = n0 + a.off_min;
-  const int wuse = BN + a.wrow;          // a.wrow = off_max - off_min for this family
-  // leaky_relu(x) == max(x, slope*x): the pre-activation is applied when the B fragment is read
-  const float pre_slope = a.pre_act == ACT_LRELU ? a.pre_slope : 1.f;
-
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int m = 0; m < WM; ++m)
-#pragma unroll
-    for (int n = 0; n < WN; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  // chunk-invariant weight-tile addressing: float4 #j of this thread is row (kkl, cil), columns c4*4..+3
-  int a_kkl[NA4], a_col[NA4];
-  bool a_cok[NA4];
-#pragma unroll
-  for (int j = 0; j < NA4; ++j) {
-    const int idx = tid + j * 256;
-    const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-    a_kkl[j] = row / CIC;
-    a_cok[j] = co0 + c4 * 4 < a.Cout_gp;
-    a_col[j] = (row % CIC) * a.Cout_gp + min(co0 + c4 * 4, a.Cout_gp - 4);
-  }
-  const int nkk = (a.ksize + KKT - 1) / KKT;
-  const int nci = a.Cin_gp / CIC;
-  const int cb0 = ks * nci / a.splitk, cb1 = (ks + 1) * nci / a.splitk;   // this split's ci chunks
-  const int nst = (cb1 - cb0) * nkk;
-  const int len_m1 = max(len_in - 1, 0);
-  // block-uniform: the whole staged input window lies inside the sequence, all weight columns exist
-  const bool b_dma = in_base >= 0 && in_base + WROW <= len_in;
-  const bool a_dma = co0 + BM <= a.Cout_gp;
-
-  // ---- stage (ci0, kk0) -> LDS buffers.  Fast path: asynchronous LDS-DMA, no VGPRs, no VALU.
-  auto stage_a = [&](int ci0, int kk0, float* Ad) __attribute__((always_inline)) {
-    const float* wbase = a.w + (long)ci0 * a.Cout_gp;
-    if (a_dma && kk0 + KKT <= a.ksize) {
-#pragma unroll
-      for (int j = 0; j < NA4; ++j)
-        dma16(wbase + (long)(kk0 + a_kkl[j]) * a.Cin_gp * a.Cout_gp + a_col[j], Ad + (wave + 4 * j) * 256);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NA4; ++j) {
-        const int kk = kk0 + a_kkl[j];
-        float4 v = *reinterpret_cast<const float4*>(wbase + (long)min(kk, a.ksize - 1) * a.Cin_gp * a.Cout_gp + a_col[j]);
-        if (!(a_cok[j] && kk < a.ksize)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Ad + (tid + j * 256) * 4) = v;
-      }
-    }
-  };
-  auto stage_b = [&](int ci0, float* Bd) __attribute__((always_inline)) {
-    if (b_dma && ci0 + CIC <= a.Cin_g) {
-#pragma unroll
-      for (int rr = 0; rr < CIC / 4; ++rr) {
-        const int r = wave + 4 * rr;
-        const float* xr = xg + (long)(ci0 + r) * a.x_cs + in_base + lane;
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) dma4(xr + 64 * j, Bd + r * WROW + 64 * j);
-      }
-    } else {
-#pragma unroll
-      for (int rr = 0; rr < CIC / 4; ++rr) {
-        const int r = wave + 4 * rr;
-        const int ci = ci0 + r;
-        const bool cvalid = ci < a.Cin_g;
-        const float* xr = xg + (long)min(ci, a.Cin_g - 1) * a.x_cs;
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) {
-          const int p = lane + 64 * j;
-          const int pos = in_base + p;
-          float v = xr[min(max(pos, 0), len_m1)];
-          v = (cvalid && p < wuse && pos >= 0 && pos < len_in) ? v : 0.f;
-          Bd[r * WROW + p] = v;
-        }
-      }
-    }
-  };
-
-  int ci0 = cb0 * CIC, kk0 = 0;
-  if (nst > 0) {
-    stage_b(ci0, Bs[0]);
-    stage_a(ci0, 0, As[0]);
-  }
-  int bbuf = 0;
-  for (int st = 0; st < nst; ++st) {
-    // everything issued for stage st has landed (own DMAs: vmcnt; other waves': barrier)
-    wait_all_memory();
-    __syncthreads();
-    // ---- issue stage st+1 into the other buffers (last read in stage st-1, which every wave finished
-    // before the barrier above)
-    int nci0 = ci0, nkk0 = kk0 + KKT;
-    if (nkk0 >= a.ksize) {
-      nkk0 = 0;
-      nci0 += CIC;
-    }
-    if (st + 1 < nst) {
-      if (nkk0 == 0) stage_b(nci0, Bs[bbuf ^ 1]);
-      stage_a(nci0, nkk0, As[(st + 1) & 1]);
-    }
-    // ---- multiply stage st
-    const float* Ap = As[st & 1] + h * BM + wr * (WM * 32) + i;
-    const float* Bp = Bs[bbuf] + h * WROW + wc * (WN * 32) + i;
-#pragma unroll
-    for (int kkl = 0; kkl < KKT; ++kkl) {
-      const int kk = kk0 + kkl;
-      if ((KKT == 1 || kk < a.ksize) && !RVCX_DBG(a, 4)) {
-        const int tp = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
-        const float* Bt = Bp + tp;
-#pragma unroll
-        for (int cp = 0; cp < CIC / 2; ++cp) {
-          float av[WM], bv[WN];
-#pragma unroll
-          for (int m = 0; m < WM; ++m) av[m] = Ap[(kkl * CIC + 2 * cp) * BM + m * 32];
-#pragma unroll
-          for (int n = 0; n < WN; ++n) {
-            const float v = Bt[2 * cp * WROW + n * 32];
-            bv[n] = fmaxf(v, v * pre_slope);
-          }
-#pragma unroll
-          for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int n = 0; n < WN; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-        }
-      }
-    }
-    if (nkk0 == 0) bbuf ^= 1;
-    ci0 = nci0;
-    kk0 = nkk0;
-  }
-
-  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
-  const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
-  if (RVCX_DBG(a, 8)) return;
-  if (a.splitk > 1) {
-    // raw partial sums -> part[ks][b][co][nn]; conv_splitk_finish_kernel reduces and applies the epilogue
-    float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int n = 0; n < WN; ++n) {
-        const int nn = nn_w + n * 32;
-        if (nn < a.Nout) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = co_w + m * 32 + (r & 3) + 8 * (r >> 2);
-            if (co < a.Cout_g) pb[(long)co * a.Nout + nn] = acc[m][n][r];
-          }
-        }
-      }
-    return;
-  }
-  if (fast_epilogue_ok(a)) {
-    store_tile_fast(a, b, co_w, nn_w, acc[0][0], len_out);
-    if constexpr (WN > 1) store_tile_fast(a, b, co_w, nn_w + 32, acc[0][1], len_out);
-    if constexpr (WM > 1) {
-      store_tile_fast(a, b, co_w + 32, nn_w, acc[1][0], len_out);
-      if constexpr (WN > 1) store_tile_fast(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
-    }
-  } else if (a.out_mode == OUT_SHUF1D) {
-    store_tile_shuf1d(a, b, co_w, nn_w, acc[0][0], len_out);
-    if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w, nn_w + 32, acc[0][1], len_out);
-    if constexpr (WM > 1) {
-      store_tile_shuf1d(a, b, co_w + 32, nn_w, acc[1][0], len_out);
-      if constexpr (WN > 1) store_tile_shuf1d(a, b, co_w + 32, nn_w + 32, acc[1][1], len_out);
-    }
-  } else {
-    store_tile(a, b, 0, co_w, nn_w, acc[0][0], len_out);
-    if constexpr (WN > 1) store_tile(a, b, 0, co_w, nn_w + 32, acc[0][1], len_out);
-    if constexpr (WM > 1) {
-      store_tile(a, b, 0, co_w + 32, nn_w, acc[1][0], len_out);
-      if constexpr (WN > 1) store_tile(a, b, 0, co_w + 32, nn_w + 32, acc[1][1], len_out);
-    }
-  }
 }
 
 // ---- single-buffered variant (register staging, 2 barriers per stage, small LDS footprint -> more
@@ -571,29 +361,28 @@ struct FastCfg {
   int bm, bn, halo, cic;   // cic = 32 marks the k=1 (Linear) variants; halo < 0: stride-2 variant (halo = -halo)
   float eff;
   void (*kern)(const ConvArgs);      // long-N launches
-  void (*kern_db)(const ConvArgs);   // LDS-DMA double-buffered variant (latency-bound small-N launches)
 };
 
 const FastCfg kFast[] = {
     // 1-D convs (halo <= 64 covers k=11 d=5)
-    {128, 128, 64, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 64>, conv_fast_kernel<128, 128, 2, 2, 2, 16, 64>},
-    {128, 64, 64, 16, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 2, 16, 64>, conv_fast_kernel<128, 64, 4, 1, 2, 16, 64>},
-    {64, 256, 64, 16, 1.00f, conv_fast_sb_kernel<64, 256, 1, 4, 4, 16, 64>, conv_fast_kernel<64, 256, 1, 4, 4, 16, 64>},
-    {64, 128, 64, 16, 0.85f, conv_fast_sb_kernel<64, 128, 2, 2, 4, 16, 64>, conv_fast_kernel<64, 128, 2, 2, 4, 16, 64>},
-    {64, 64, 64, 16, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 4, 16, 64>, conv_fast_kernel<64, 64, 2, 2, 4, 16, 64>},
-    {32, 256, 64, 16, 0.90f, conv_fast_sb_kernel<32, 256, 1, 4, 4, 16, 64>, conv_fast_kernel<32, 256, 1, 4, 4, 16, 64>},
+    {128, 128, 64, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 64>},
+    {128, 64, 64, 16, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 2, 16, 64>},
+    {64, 256, 64, 16, 1.00f, conv_fast_sb_kernel<64, 256, 1, 4, 4, 16, 64>},
+    {64, 128, 64, 16, 0.85f, conv_fast_sb_kernel<64, 128, 2, 2, 4, 16, 64>},
+    {64, 64, 64, 16, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 4, 16, 64>},
+    {32, 256, 64, 16, 0.90f, conv_fast_sb_kernel<32, 256, 1, 4, 4, 16, 64>},
     // 3x3 convs on row-padded maps (halo = 2*Wp + 2 <= 262)
-    {128, 128, 320, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 320>, conv_fast_kernel<128, 128, 2, 2, 2, 16, 320>},
-    {64, 128, 320, 16, 0.85f, conv_fast_sb_kernel<64, 128, 2, 2, 4, 16, 320>, conv_fast_kernel<64, 128, 2, 2, 4, 16, 320>},
-    {32, 128, 320, 16, 0.70f, conv_fast_sb_kernel<32, 128, 1, 4, 4, 16, 320>, conv_fast_kernel<32, 128, 1, 4, 4, 16, 320>},
+    {128, 128, 320, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 320>},
+    {64, 128, 320, 16, 0.85f, conv_fast_sb_kernel<64, 128, 2, 2, 4, 16, 320>},
+    {32, 128, 320, 16, 0.70f, conv_fast_sb_kernel<32, 128, 1, 4, 4, 16, 320>},
     // Linear layers (k = 1)
-    {128, 128, 0, 32, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 1, 32, 0>, conv_fast_kernel<128, 128, 2, 2, 1, 32, 0>},
-    {128, 64, 0, 32, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 1, 32, 0>, conv_fast_kernel<128, 64, 4, 1, 1, 32, 0>},
-    {64, 64, 0, 32, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 1, 32, 0>, conv_fast_kernel<64, 64, 2, 2, 1, 32, 0>},
+    {128, 128, 0, 32, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 1, 32, 0>},
+    {128, 64, 0, 32, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 1, 32, 0>},
+    {64, 64, 0, 32, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 1, 32, 0>},
     // stride-2 1-D convs (HuBERT feature extractor k=3 / k=2)
-    {128, 128, -64, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 64, 2>, nullptr},
-    {128, 64, -64, 16, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 2, 16, 64, 2>, nullptr},
-    {64, 64, -64, 16, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 4, 16, 64, 2>, nullptr},
+    {128, 128, -64, 16, 1.00f, conv_fast_sb_kernel<128, 128, 2, 2, 2, 16, 64, 2>},
+    {128, 64, -64, 16, 0.85f, conv_fast_sb_kernel<128, 64, 4, 1, 2, 16, 64, 2>},
+    {64, 64, -64, 16, 0.70f, conv_fast_sb_kernel<64, 64, 2, 2, 4, 16, 64, 2>},
 };
 constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
@@ -621,13 +410,12 @@ void conv_fast_describe(ConvProfile* p) {
   p->bm[7] = 16;
   p->bn[7] = 256;
   p->halo[7] = 300000;   // slot 7: conv_cin1_kernel
-  for (int t = 0; t < kNumFast; ++t)
-    for (int v = 0; v < 2; ++v) {
-      const int s = 8 + 16 * v + t;
-      p->bm[s] = kFast[t].bm;
-      p->bn[s] = kFast[t].bn;
-      p->halo[s] = kFast[t].cic == 32 ? 100000 + v : (kFast[t].halo < 0 ? 200000 + v : kFast[t].halo * 10 + v);
-    }
+  for (int t = 0; t < kNumFast; ++t) {
+    const int s = 8 + t;
+    p->bm[s] = kFast[t].bm;
+    p->bn[s] = kFast[t].bn;
+    p->halo[s] = kFast[t].cic == 32 ? 100000 : (kFast[t].halo < 0 ? 200000 : kFast[t].halo * 10);
+  }
 }
 
 void launch_splitk_finish(const ConvArgs& a, hipStream_t stream) {
@@ -726,9 +514,6 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     a.dbg = dbg;
   }
   dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
-  // the register-prefetch kernel wins on every shape of the sweep; the LDS-DMA double-buffered variant
-  // (conv_fast_kernel) stays reachable through rvcx_conv_override for A/B runs only
-  bool use_db = false;
   {
     // spacing = one block's exclusive time on its CU (block wall time / occupancy), only worth it when the
     // launch runs for several rounds
@@ -738,12 +523,10 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     a.stagger = (multi_round && g_stagger_scale > 0.f) ? (int)(excl_us * 100.0 * g_stagger_scale) : 0;
     a.stagger_blocks = 256 * occ;
   }
-  if (g_conv_override.variant >= 0) use_db = g_conv_override.variant != 0;
-  if (!F.kern_db) use_db = false;
-  hipLaunchKernelGGL(use_db ? F.kern_db : F.kern, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());
-  return 8 + (use_db ? 16 : 0) + best;
+  return 8 + best;
 }
 
 }  // namespace rvcx
