@@ -48,6 +48,15 @@ typedef struct {
   int32_t n_blocks, en_de_layers, inter_layers, en_out_channels;
 } rvcx_rmvpe_cfg;
 
+/* FCPE(input_channel, out_dims, n_layers, n_chans) -- rvc/lib/predictors/FCPE.py:551-627, built from fcpe.pt's
+ * "config" block at FCPE.py:715-733; heads / dim_head / nb_features / dw_kernel are the module defaults
+ * (FCPE.py:445-446, 435, 315), read off the tensor shapes; mel_fmin / mel_fmax from config["mel"] */
+typedef struct {
+  int32_t n_layers, n_chans, input_channel, out_dims;
+  int32_t heads, dim_head, nb_features, dw_kernel;
+  float mel_fmin, mel_fmax;
+} rvcx_fcpe_cfg;
+
 /* fairseq HubertModel (hubert_base) geometry -- loaded at rvc/infer/infer.py:67-74 */
 typedef struct {
   int32_t conv_dim, n_conv;
@@ -67,7 +76,10 @@ typedef struct {
   int32_t sid;
   int32_t x_pad, x_query, x_center, x_max; /* seconds */
   uint64_t seed;          /* Philox seed for the two Gaussian draws when noise == NULL */
+  int32_t f0_method;      /* RVCX_F0_RMVPE ("rmvpe" / "rmvpe+", pipeline.py:142-167) or RVCX_F0_FCPE ("fcpe", :169-181) */
+  int32_t reserved;
 } rvcx_params;
+enum { RVCX_F0_RMVPE = 0, RVCX_F0_FCPE = 1 };
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 int rvcx_create(int device, rvcx_ctx** out);
@@ -80,6 +92,9 @@ const char* rvcx_version(void);
 int rvcx_load_hubert(rvcx_ctx*, const rvcx_hubert_cfg*, const rvcx_tensor* tbl, int n);
 /* replaces RMVPE0Predictor.__init__ -- rvc/lib/predictors/RMVPE.py:442-459 */
 int rvcx_load_rmvpe(rvcx_ctx*, const rvcx_rmvpe_cfg*, const rvcx_tensor* tbl, int n);
+/* replaces FCPEF0Predictor.__init__ / FCPEInfer.__init__ -- rvc/lib/predictors/FCPE.py:708-736, 806-826
+ * (tbl: the checkpoint's "model" state_dict) */
+int rvcx_load_fcpe(rvcx_ctx*, const rvcx_fcpe_cfg*, const rvcx_tensor* tbl, int n);
 /* replaces get_vc's Synthesizer construction -- rvc/infer/infer.py:78-105 */
 int rvcx_load_synth(rvcx_ctx*, const rvcx_synth_cfg*, const rvcx_tensor* tbl, int n, int* model_id);
 int rvcx_unload_synth(rvcx_ctx*, int model_id);
@@ -116,6 +131,17 @@ int rvcx_rmvpe_f0(rvcx_ctx*, int B, const float* audio_hd, int64_t n, float thre
 int rvcx_rmvpe_frames(int64_t n);
 /* MelSpectrogram.forward -- rvc/lib/predictors/RMVPE.py:412-439: audio (B, n) -> log-mel (B, 128, 1 + n/160) */
 int rvcx_rmvpe_mel(rvcx_ctx*, int B, const float* audio_hd, int64_t n, float* mel_hd);
+/* FCPEInfer.__call__(audio, sr=16000, threshold) -- rvc/lib/predictors/FCPE.py:739-745 (return_hz_f0, local_argmax
+ * decoder): audio (B, n) -> f0 (B, n/160 + 1) Hz, 0 where the salience maximum is <= threshold.
+ * salience (B, frames, 360) = the sigmoid output of FCPE.forward (FCPE.py:646), mel (B, 128, frames) =
+ * Wav2Mel.__call__ transposed (FCPE.py:768-788); both optional. */
+int rvcx_fcpe_f0(rvcx_ctx*, int B, const float* audio_hd, int64_t n, float threshold, float* f0_hd,
+                 float* salience_hd, float* mel_hd);
+int rvcx_fcpe_frames(int64_t n);
+/* FCPEF0Predictor.compute_f0(x, p_len) as VC.get_f0 calls it (threshold 0.03, pipeline.py:169-179; FCPE.py:869-877)
+ * followed by get_f0's own tail (pitch shift, coarse; pipeline.py:183-201): x (n samples) -> p_len frames. */
+int rvcx_get_f0_fcpe_x(rvcx_ctx*, const float* x_hd, int64_t n, int64_t p_len, const rvcx_params* p, int32_t* coarse,
+                       float* f0);
 /* HubertModel.extract_features(source, padding_mask=False, output_layer=L)[0] --
  * call site rvc/infer/pipeline.py:228-236.  wav (B, n) -> feats (B, T', embed_dim). */
 int rvcx_hubert_features(rvcx_ctx*, int B, const float* wav_hd, int64_t n, int output_layer,
@@ -211,6 +237,10 @@ double rvcx_flop_counter(rvcx_ctx*, int reset);
 void* rvcx_stream(rvcx_ctx*); /* hipStream_t the library launches on */
 
 /* ---- kernel-level entry points (unit parity tests of the HIP kernels) ------------------ */
+/* FCPEF0Predictor.post_process()[0] (FCPE.py:841-867) + the tail of VC.get_f0 (pipeline.py:183-201) on a given raw
+ * track: raw (F_in) Hz with 0 = unvoiced -> f0 (p_len, float32 of the float64 result) and coarse (p_len) */
+int rvcx_op_fcpe_post(rvcx_ctx*, const float* raw_hd, int F_in, int p_len, double pitch, double f0_min, double f0_max,
+                      int32_t* coarse, float* f0);
 /* y = act(conv1d(pre(x), w) + bias) + res ; x (B,Cin,Tin) w (Cout,Cin/groups,K) host f32 */
 int rvcx_op_conv1d(rvcx_ctx*, const float* x, const float* w, const float* bias, const float* res,
                    float* y, int B, int Cin, int Tin, int Cout, int K, int stride, int dil,

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 from scipy import signal
 
+from . import fcpe as O_fcpe
 from . import hubert as O_hubert
 from . import rmvpe as O_rmvpe
 from . import synth as O_synth
@@ -146,7 +147,8 @@ def to_int16(audio_opt: np.ndarray) -> np.ndarray:
 class Models:
     """Bundle of state dicts + configs the oracle needs (all torch tensors, CPU)."""
 
-    def __init__(self, hubert_sd, hubert_cfg, rmvpe_sd, rmvpe_cfg, synth_sd, synth_cfg):
+    def __init__(self, hubert_sd, hubert_cfg, rmvpe_sd, rmvpe_cfg, synth_sd, synth_cfg, fcpe_sd=None):
+        self.fcpe_sd = fcpe_sd
         self.hubert_sd, self.hubert_cfg = hubert_sd, hubert_cfg
         self.rmvpe_sd, self.rmvpe_cfg = rmvpe_sd, rmvpe_cfg
         self.synth_sd, self.synth_cfg = synth_sd, synth_cfg
@@ -221,15 +223,18 @@ def hubert_frames(n: int, cfg) -> int:
 def pipeline(models: Models, geo: Geometry, audio: np.ndarray, pitch: float = 0, sid: int = 0,
              big_npy=None, index_rate: float = 0.0, volume_envelope: float = 1.0,
              protect: float = 0.33, f0_min=50, f0_max=1100, noises=None, seed: int = 0,
-             return_parts=False):
-    """VC.pipeline (pipeline.py:289-467) with f0_method="rmvpe+", pitch_guidance=1, resample_sr=0,
-    f0_file=None.  ``noises`` = list of (z_noise, src_noise) per chunk; drawn from
+             return_parts=False, f0_method: str = "rmvpe+"):
+    """VC.pipeline (pipeline.py:289-467) with f0_method="rmvpe+" or "fcpe" (models.fcpe_sd), pitch_guidance=1,
+    resample_sr=0, f0_file=None.  ``noises`` = list of (z_noise, src_noise) per chunk; drawn from
     torch.manual_seed(seed) in the reference's order (z first, then source) if None."""
     audio = highpass(np.asarray(audio, dtype=np.float64))
     opt_ts = chunk_points(audio, geo)
     audio_pad = np.pad(audio, (geo.t_pad, geo.t_pad), mode="reflect")
     p_len = audio_pad.shape[0] // WINDOW
-    f0 = O_rmvpe.infer_f0(models.rmvpe_sd, models.rmvpe_cfg, audio_pad, 0.03, f0_min, f0_max)
+    if f0_method == "fcpe":                                   # pipeline.py:169-181
+        f0 = O_fcpe.compute_f0(models.fcpe_sd, audio_pad.astype(np.float32), p_len, 0.03)
+    else:
+        f0 = O_rmvpe.infer_f0(models.rmvpe_sd, models.rmvpe_cfg, audio_pad, 0.03, f0_min, f0_max)
     coarse, f0bak = f0_to_coarse(f0, pitch, f0_min, f0_max)
     coarse, f0bak = coarse[:p_len], f0bak[:p_len]
     plan = chunk_plan(audio.shape[0], opt_ts, geo)

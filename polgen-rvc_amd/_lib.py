@@ -39,6 +39,13 @@ class RmvpeCfg(C.Structure):
                 ("en_out_channels", C.c_int32)]
 
 
+class FcpeCfg(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_chans", C.c_int32), ("input_channel", C.c_int32),
+                ("out_dims", C.c_int32), ("heads", C.c_int32), ("dim_head", C.c_int32),
+                ("nb_features", C.c_int32), ("dw_kernel", C.c_int32), ("mel_fmin", C.c_float),
+                ("mel_fmax", C.c_float)]
+
+
 class HubertCfg(C.Structure):
     _fields_ = [("conv_dim", C.c_int32), ("n_conv", C.c_int32), ("conv_kernels", C.c_int32 * 8),
                 ("conv_strides", C.c_int32 * 8), ("embed_dim", C.c_int32), ("ffn_dim", C.c_int32),
@@ -50,7 +57,11 @@ class Params(C.Structure):
     _fields_ = [("pitch", C.c_float), ("f0_min", C.c_float), ("f0_max", C.c_float),
                 ("index_rate", C.c_float), ("protect", C.c_float), ("volume_envelope", C.c_float),
                 ("sid", C.c_int32), ("x_pad", C.c_int32), ("x_query", C.c_int32),
-                ("x_center", C.c_int32), ("x_max", C.c_int32), ("seed", C.c_uint64)]
+                ("x_center", C.c_int32), ("x_max", C.c_int32), ("seed", C.c_uint64),
+                ("f0_method", C.c_int32), ("reserved", C.c_int32)]
+
+
+F0_RMVPE, F0_FCPE = 0, 1        # rvcx_params.f0_method
 
 
 _lib = None
@@ -58,7 +69,7 @@ _lib = None
 # every symbol include/rvcx.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
-    "rvcx_load_rmvpe", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
+    "rvcx_load_rmvpe", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
     "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_weights_clone", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
@@ -299,6 +310,44 @@ class Context:
         tbl, keep = make_table(state)
         self._ck(lib().rvcx_load_rmvpe(self._h, C.byref(cfg_struct), tbl, len(tbl)), "load_rmvpe")
         self.rmvpe_loaded = True
+
+    def load_fcpe(self, cfg_struct, state: dict):
+        tbl, keep = make_table(state)
+        self._ck(lib().rvcx_load_fcpe(self._h, C.byref(cfg_struct), tbl, len(tbl)), "load_fcpe")
+        self.fcpe_loaded = True
+
+    def fcpe_f0(self, audio, threshold=0.05, return_salience=False, return_mel=False):
+        """FCPEInfer.__call__: audio (n,) or (B,n) at 16 kHz -> Hz (B, n//160 + 1) [, salience (B,F,360)] [, mel (B,128,F)]."""
+        audio = f32(audio)
+        if audio.ndim == 1:
+            audio = audio[None]
+        B, n = audio.shape
+        F = 1 + n // 160
+        f0 = np.empty((B, F), np.float32)
+        sal = np.empty((B, F, 360), np.float32) if return_salience else None
+        mel = np.empty((B, 128, F), np.float32) if return_mel else None
+        self._ck(lib().rvcx_fcpe_f0(self._h, B, _p(audio), C.c_int64(n), C.c_float(threshold), _p(f0), _p(sal),
+                                    _p(mel)), "fcpe_f0")
+        out = (f0,) + ((sal,) if return_salience else ()) + ((mel,) if return_mel else ())
+        return out if len(out) > 1 else f0
+
+    def get_f0_fcpe_x(self, x, p_len, params: "Params"):
+        """VC.get_f0(..., f0_method="fcpe") on the already padded + filtered signal: (coarse, f0) of p_len frames."""
+        x = f32(x)
+        coarse = np.empty(int(p_len), np.int32)
+        f0 = np.empty(int(p_len), np.float32)
+        self._ck(lib().rvcx_get_f0_fcpe_x(self._h, _p(x), C.c_int64(x.shape[0]), C.c_int64(int(p_len)),
+                                          C.byref(params), _p(coarse, C.c_int32), _p(f0)), "get_f0_fcpe_x")
+        return coarse, f0
+
+    def fcpe_post(self, raw, p_len, pitch=0.0, f0_min=50, f0_max=1100):
+        raw = f32(raw)
+        coarse = np.empty(int(p_len), np.int32)
+        f0 = np.empty(int(p_len), np.float32)
+        self._ck(lib().rvcx_op_fcpe_post(self._h, _p(raw), int(raw.shape[0]), int(p_len), C.c_double(pitch),
+                                         C.c_double(f0_min), C.c_double(f0_max), _p(coarse, C.c_int32), _p(f0)),
+                 "fcpe_post")
+        return coarse, f0
 
     def load_hubert(self, cfg_struct, state: dict):
         tbl, keep = make_table(state)

@@ -556,7 +556,7 @@ int rvcx_synth_upp(rvcx_ctx* ctx, int model_id) {
   return ctx->c.synths[model_id]->upp;
 }
 
-// every weight region of the context in a fixed order: HuBERT, RMVPE, voice models by id, index
+// every weight region of the context in a fixed order: HuBERT, RMVPE, FCPE, voice models by id, index
 static std::vector<WeightRegion*> all_regions(Ctx& c, uint64_t* hash) {
   std::vector<WeightRegion*> r;
   uint64_t h = 1469598103934665603ull;
@@ -567,6 +567,7 @@ static std::vector<WeightRegion*> all_regions(Ctx& c, uint64_t* hash) {
   };
   add(c.hubert ? c.hubert->region.get() : nullptr, 1);
   add(c.rmvpe ? c.rmvpe->region.get() : nullptr, 2);
+  add(c.fcpe ? c.fcpe->region.get() : nullptr, 4);
   for (size_t i = 0; i < c.synths.size(); ++i) add(c.synths[i] ? c.synths[i]->region.get() : nullptr, 16 + i);
   add(c.index ? c.index->region.get() : nullptr, 3);
   if (hash) *hash = h;
@@ -720,6 +721,74 @@ int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor*
   API_BEGIN(ctx)
   TensorTable t = make_table(tbl, n);
   C->rmvpe = rmvpe_load(*C, *cfg, t);
+  API_END
+}
+
+int rvcx_load_fcpe(rvcx_ctx* ctx, const rvcx_fcpe_cfg* cfg, const rvcx_tensor* tbl, int n) {
+  API_BEGIN(ctx)
+  TensorTable t = make_table(tbl, n);
+  C->fcpe = fcpe_load(*C, *cfg, t);
+  API_END
+}
+
+int rvcx_fcpe_f0(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float threshold, float* f0, float* salience,
+                 float* mel) {
+  API_BEGIN(ctx)
+  if (!C->fcpe) fail("fcpe not loaded");
+  C->ensure_splitk(B);
+  const int F = (int)(1 + n / 160), nb = C->fcpe->cfg.out_dims;
+  C->arena.reserve(fcpe_arena_bytes(*C->fcpe, B, n) + (size_t)B * (n + (size_t)F * (nb + 130)) * 4);
+  C->arena.reset();
+  float* da = any_to_dev(*C, audio, (size_t)B * n);
+  float* df0 = C->arena.alloc<float>((size_t)B * F);
+  float* ds = salience ? C->arena.alloc<float>((size_t)B * F * nb) : nullptr;
+  float* dm = mel ? C->arena.alloc<float>((size_t)B * 128 * F) : nullptr;
+  fcpe_forward(*C, *C->fcpe, B, da, n, threshold, df0, ds, dm, C->stream);
+  RVCX_HIP(hipMemcpyAsync(f0, df0, (size_t)B * F * 4, hipMemcpyDefault, C->stream));
+  if (salience) RVCX_HIP(hipMemcpyAsync(salience, ds, (size_t)B * F * nb * 4, hipMemcpyDefault, C->stream));
+  if (mel) RVCX_HIP(hipMemcpyAsync(mel, dm, (size_t)B * 128 * F * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->check_dev_err();
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_op_fcpe_post(rvcx_ctx* ctx, const float* raw, int F_in, int p_len, double pitch, double f0_min, double f0_max,
+                      int32_t* coarse, float* f0) {
+  API_BEGIN(ctx)
+  if (F_in <= 0 || p_len <= 0) fail("fcpe_post: empty track");
+  C->arena.reserve((size_t)(F_in + 5L * p_len) * 4 + (64 << 20));
+  C->arena.reset();
+  float* dr = any_to_dev(*C, raw, (size_t)F_in);
+  int* dc = C->arena.alloc<int>((size_t)p_len);
+  float* df = C->arena.alloc<float>((size_t)p_len);
+  fcpe_post_coarse(*C, dr, 1, F_in, p_len, df, dc, p_len, pitch, f0_min, f0_max, C->stream);
+  RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)p_len * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)p_len * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_get_f0_fcpe_x(rvcx_ctx* ctx, const float* x, int64_t n, int64_t p_len, const rvcx_params* p, int32_t* coarse,
+                       float* f0) {
+  API_BEGIN(ctx)
+  if (!C->fcpe) fail("fcpe not loaded");
+  if (p_len <= 0) fail("get_f0: p_len must be positive");
+  const long F = 1 + n / 160;
+  C->arena.reserve(fcpe_arena_bytes(*C->fcpe, 1, n) + (size_t)n * 8 + (size_t)(F + p_len) * 32 + (64 << 20));
+  C->arena.reset();
+  float* dx = any_to_dev(*C, x, (size_t)n);
+  float* fraw = C->arena.alloc<float>((size_t)F);
+  int* dc = C->arena.alloc<int>((size_t)p_len);
+  float* df = C->arena.alloc<float>((size_t)p_len);
+  fcpe_forward(*C, *C->fcpe, 1, dx, n, 0.03f, fraw, nullptr, nullptr, C->stream);
+  fcpe_post_coarse(*C, fraw, 1, (int)F, (int)p_len, df, dc, p_len, p->pitch, p->f0_min, p->f0_max, C->stream);
+  RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)p_len * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)p_len * 4, hipMemcpyDefault, C->stream));
+  RVCX_HIP(hipStreamSynchronize(C->stream));
+  C->check_dev_err();
+  C->arena.reset();
   API_END
 }
 
@@ -928,7 +997,7 @@ int rvcx_convert_batch_f64(rvcx_ctx* ctx, int model_id, int B, const double* con
 
 int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
   if (!ctx || !p || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id] ||
-      !ctx->c.hubert || !ctx->c.rmvpe)
+      !ctx->c.hubert)
     return -1;
   try {
     return convert_micro_batch(ctx->c, model_id, n, *p);
@@ -941,9 +1010,8 @@ int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* 
 int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0,
                 int64_t* p_len) {
   API_BEGIN(ctx)
-  if (!C->rmvpe) fail("rmvpe not loaded");
   const long t_pad = 16000L * p->x_pad, n_pad = n + 2 * t_pad;
-  C->arena.reserve(rmvpe_arena_bytes(*C->rmvpe, 1, n_pad) + (size_t)n_pad * 48 + (64 << 20));
+  C->arena.reserve(f0_arena_bytes(*C, *p, 1, n_pad) + (size_t)n_pad * 48 + (64 << 20));
   C->arena.reset();
   float* dw = any_to_dev(*C, wav16k, (size_t)n);
   double* ext = C->arena.alloc<double>(highpass_ext_doubles(n));
@@ -1114,5 +1182,6 @@ int rvcx_op_highpass(rvcx_ctx* ctx, const double* x, double* y, int64_t n) {
   } while (0)
 
 int rvcx_rmvpe_frames(int64_t n) { return (int)(1 + n / 160); }
+int rvcx_fcpe_frames(int64_t n) { return (int)(1 + n / 160); }
 
 }  // extern "C"

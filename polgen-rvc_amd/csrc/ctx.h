@@ -10,6 +10,7 @@ namespace rvcx {
 
 struct SynthModel;
 struct RmvpeModel;
+struct FcpeModel;
 struct HubertModel;
 struct IndexData;
 
@@ -157,6 +158,7 @@ struct Ctx {
   StageTimer timer;
   std::unique_ptr<HubertModel> hubert;
   std::unique_ptr<RmvpeModel> rmvpe;
+  std::unique_ptr<FcpeModel> fcpe;
   std::vector<std::unique_ptr<SynthModel>> synths;
   std::unique_ptr<IndexData> index;
   Ctx();

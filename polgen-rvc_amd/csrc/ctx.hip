@@ -79,6 +79,7 @@ bool Ctx::take_overflow() {
 Ctx::~Ctx() {
   hubert.reset();
   rmvpe.reset();
+  fcpe.reset();
   synths.clear();
   index.reset();
   if (timer.made)

@@ -94,6 +94,37 @@ size_t rmvpe_arena_bytes(const RmvpeModel& m, int B, int64_t n);
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
                    float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out = nullptr);
 
+// ------------------------------------------------------------------------------ FCPE
+struct FcpeModel {
+  std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model
+  rvcx_fcpe_cfg cfg{};
+  ConvW stft;        // shared Hann-windowed Fourier basis (n_fft 1024, hop 160)
+  ConvW melfb;       // (128, 513) slaney-scale filterbank as a 1x1 conv
+  ConvW stack0, stack3;
+  const float *gn_g = nullptr, *gn_b = nullptr;
+  struct Layer {
+    const float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;
+    ConvW qkv, out, pw1, pw2;      // to_q|to_k|to_v stacked; to_out; conformer 1x1 convs
+    const float* proj = nullptr;   // (nb_features, dim_head) random-feature projection (a checkpoint buffer)
+    const float *dw_w = nullptr, *dw_b = nullptr;   // depth-wise conv (inner, K), bias
+  };
+  std::vector<Layer> layers;
+  const float *norm_g = nullptr, *norm_b = nullptr;
+  ConvW dense;                     // weight-norm folded Linear(n_chans, 360)
+  const float* cent_table = nullptr;
+};
+ConvW make_stft_conv(Ctx& c);      // rmvpe.hip
+std::unique_ptr<FcpeModel> fcpe_load(Ctx& c, const rvcx_fcpe_cfg& cfg, const TensorTable& t);
+size_t fcpe_arena_bytes(const FcpeModel& m, int B, int64_t n);
+// FCPEInfer.__call__ (FCPE.py:739-745): audio device (B,n) f32 -> f0 device (B, n/160 + 1) Hz, 0 = below `threshold`.
+// sal_out (optional): (B, frames, 360) sigmoid salience;  mel_out (optional): (B, 128, frames) log-mel
+void fcpe_forward(Ctx& c, const FcpeModel& m, int B, const float* audio, int64_t n, float threshold, float* f0,
+                  float* sal_out, float* mel_out, hipStream_t s);
+// FCPEF0Predictor.post_process (FCPE.py:841-867) + the tail of VC.get_f0 (pipeline.py:183-201): raw Hz (B, F_in) ->
+// f0 (float32 of the float64 result) and coarse (1..255), p_len frames each, rows `out_stride` apart
+void fcpe_post_coarse(Ctx& c, const float* f0raw, int B, int F_in, int p_len, float* f0_out, int* coarse, long out_stride,
+                      double pitch, double f0_min, double f0_max, hipStream_t s);
+
 // ------------------------------------------------------------------------------ HuBERT
 struct HubertModel {
   std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model

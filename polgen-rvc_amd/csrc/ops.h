@@ -61,8 +61,8 @@ void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStrea
 // ---- RMVPE helpers
 // reflect-pad 1-D signals: x (B,n) -> y (B,n+2p) written with batch stride y_bs
 void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s);
-// |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F)
-void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s);
+// |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F) = sqrt(re^2 + im^2 + eps)   (eps: FCPE.py:147)
+void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s, float eps = 0.f);
 // log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp
 void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, const float* bn,
                      hipStream_t s);

@@ -421,17 +421,17 @@ void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs
   hipLaunchKernelGGL(reflect_pad_kernel, EW_GRID(tot), 0, s, x, y, n, p, y_bs, tot);
 }
 
-__global__ void magnitude_kernel(const float* ft, float* mag, int nb, int F, long total) {
+__global__ void magnitude_kernel(const float* ft, float* mag, int nb, int F, long total, float eps) {
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long b = idx / ((long)nb * F);
     const long r = idx - b * nb * F;
     const float re = ft[b * 2 * nb * F + r], im = ft[b * 2 * nb * F + (long)nb * F + r];
-    mag[idx] = sqrtf(re * re + im * im);
+    mag[idx] = sqrtf(re * re + im * im + eps);
   }
 }
-void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s) {
+void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s, float eps) {
   long tot = (long)B * nb * F;
-  hipLaunchKernelGGL(magnitude_kernel, EW_GRID(tot), 0, s, ft, mag, nb, F, tot);
+  hipLaunchKernelGGL(magnitude_kernel, EW_GRID(tot), 0, s, ft, mag, nb, F, tot, eps);
 }
 
 __global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, int Tp, const float* bn,

@@ -37,6 +37,9 @@ struct UttIO {
 void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& utts, const rvcx_params& p, float* stage_ms /*9 or null*/);
 int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p);   // utterances per micro-batch at this length
 
+// F0 back-end selected by params.f0_method: throws unless its model is resident; workspace for B signals of n_pad samples
+void check_f0_backend(const Ctx& c, const rvcx_params& p);
+size_t f0_arena_bytes(const Ctx& c, const rvcx_params& p, int B, long n_pad);
 // VC.get_f0 on device for B equal-length reflect-padded signals: coarse/f0 rows of out_stride elements
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
                    hipStream_t s, int B = 1, long out_stride = 0);

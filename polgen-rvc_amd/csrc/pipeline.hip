@@ -400,16 +400,38 @@ size_t convert_call_bytes(Ctx& c, int model_id, long n, const rvcx_params& p, bo
 int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p) {
   static const int env_max = getenv("RVCX_MAX_BATCH") ? std::max(1, atoi(getenv("RVCX_MAX_BATCH"))) : 8;
   static const size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 64) << 30;
-  const size_t per = convert_item_bytes(c, model_id, n, p) +
-                     rmvpe_arena_bytes(*c.rmvpe, 1, n + 32000L * p.x_pad);
+  const size_t per = convert_item_bytes(c, model_id, n, p) + f0_arena_bytes(c, p, 1, n + 32000L * p.x_pad);
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)env_max, budget / std::max<size_t>(per, 1)));
+}
+
+// the F0 back-end VC.get_f0 dispatches on (pipeline.py:142-181): which model must be resident, and its workspace
+void check_f0_backend(const Ctx& c, const rvcx_params& p) {
+  if (p.f0_method == RVCX_F0_RMVPE) {
+    RVCX_CHECK(c.rmvpe != nullptr, "get_f0: rmvpe not loaded");
+  } else if (p.f0_method == RVCX_F0_FCPE) {
+    RVCX_CHECK(c.fcpe != nullptr, "get_f0: fcpe not loaded");
+  } else {
+    fail("get_f0: unknown f0_method " + std::to_string(p.f0_method));
+  }
+}
+
+size_t f0_arena_bytes(const Ctx& c, const rvcx_params& p, int B, long n_pad) {
+  check_f0_backend(c, p);
+  if (p.f0_method == RVCX_F0_FCPE) return fcpe_arena_bytes(*c.fcpe, B, n_pad) + (size_t)B * (n_pad / 160 + 8) * 16;
+  return rmvpe_arena_bytes(*c.rmvpe, B, n_pad);
 }
 
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
                    hipStream_t s, int B, long out_stride) {
   // VC.get_f0 (pipeline.py:132-201) on already reflect-padded signals (B, n_pad); coarse / f0 rows of out_stride
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
+  check_f0_backend(c, p);
   float* f0raw = c.arena.alloc<float>((size_t)B * F);
+  if (p.f0_method == RVCX_F0_FCPE) {   // pipeline.py:169-181: threshold 0.03, compute_f0(x, p_len)
+    fcpe_forward(c, *c.fcpe, B, apad, n_pad, 0.03f, f0raw, nullptr, nullptr, s);
+    fcpe_post_coarse(c, f0raw, B, (int)F, (int)p_len, f0, coarse, out_stride, p.pitch, p.f0_min, p.f0_max, s);
+    return p_len;
+  }
   rmvpe_forward(c, *c.rmvpe, B, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s);
   for (int b = 0; b < B; ++b)
     launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)p_len,
@@ -427,7 +449,8 @@ long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, 
 // its CU-masked stream; finished PCM leaves behind its micro-batch on the main stream.  No host synchronisation inside the loop except
 // the cut-point read-back of clips longer than x_max seconds.
 void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_params& p, float* stage_ms) {
-  RVCX_CHECK(c.hubert && c.rmvpe, "convert: hubert / rmvpe not loaded");
+  RVCX_CHECK(c.hubert != nullptr, "convert: hubert not loaded");
+  check_f0_backend(c, p);
   RVCX_CHECK(model_id >= 0 && model_id < (int)c.synths.size() && c.synths[model_id], "convert: bad model id");
   const SynthModel& M = *c.synths[model_id];
   const Geometry g = make_geometry(p, M.cfg.sr);
@@ -471,7 +494,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   for (const auto& mb : mbs) {
     const long n = ios[order[mb.first]].n;
     mb_bytes = std::max(mb_bytes, (size_t)mb.count * convert_item_bytes(c, model_id, n, p));
-    f0_bytes = std::max(f0_bytes, rmvpe_arena_bytes(*c.rmvpe, mb.count, n + 2 * g.t_pad));
+    f0_bytes = std::max(f0_bytes, f0_arena_bytes(c, p, mb.count, n + 2 * g.t_pad));
   }
   (void)any_f64;
   (void)any_noise;

@@ -95,22 +95,26 @@ RmvpeModel::Block load_block(Ctx& c, const TensorTable& t, const std::string& p)
 
 }  // namespace
 
+// The strided STFT conv (Cin=1, k=1024, stride 160) is re-indexed k = 160*a + r so that it
+// becomes a dense stride-1 conv with Cin=160, k=7 over the hop-major transposed signal
+// X2[r][m] = x[160*m + r]: no wasted MFMA k-slots and a small LDS tile.  Shared with FCPE (same n_fft / hop / Hann).
+ConvW make_stft_conv(Ctx& c) {
+  auto b = stft_basis();
+  const int KA = (N_FFT + HOP - 1) / HOP;  // 7
+  std::vector<float> w2((size_t)(N_FFT + 2) * HOP * KA, 0.f);
+  for (int co = 0; co < N_FFT + 2; ++co)
+    for (int r = 0; r < HOP; ++r)
+      for (int a = 0; a < KA; ++a)
+        if (HOP * a + r < N_FFT) w2[((size_t)co * HOP + r) * KA + a] = b[(size_t)co * N_FFT + HOP * a + r];
+  return make_conv(c, w2.data(), nullptr, N_FFT + 2, HOP, KA, 1);
+}
+
 std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const TensorTable& t) {
   auto M = std::make_unique<RmvpeModel>();
   RegionScope scope(c, *M->region);
   M->cfg = cfg;
   {
-    // The strided STFT conv (Cin=1, k=1024, stride 160) is re-indexed k = 160*a + r so that it
-    // becomes a dense stride-1 conv with Cin=160, k=7 over the hop-major transposed signal
-    // X2[r][m] = x[160*m + r]: no wasted MFMA k-slots and a small LDS tile.
-    auto b = stft_basis();
-    const int KA = (N_FFT + HOP - 1) / HOP;  // 7
-    std::vector<float> w2((size_t)(N_FFT + 2) * HOP * KA, 0.f);
-    for (int co = 0; co < N_FFT + 2; ++co)
-      for (int r = 0; r < HOP; ++r)
-        for (int a = 0; a < KA; ++a)
-          if (HOP * a + r < N_FFT) w2[((size_t)co * HOP + r) * KA + a] = b[(size_t)co * N_FFT + HOP * a + r];
-    M->stft = make_conv(c, w2.data(), nullptr, N_FFT + 2, HOP, KA, 1);
+    M->stft = make_stft_conv(c);
     auto m = mel_filterbank();
     M->melfb = make_conv(c, m.data(), nullptr, N_MELS, N_FFT / 2 + 1, 1, 1);
   }

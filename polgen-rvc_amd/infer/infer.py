@@ -105,6 +105,31 @@ def load_rmvpe(device, model_path=None, state=None, cfg=None):
         _RESIDENT[slot] = (key, True)
 
 
+def load_fcpe(device, model_path=None, cpt=None):
+    """FCPEF0Predictor.__init__ -> FCPEInfer.__init__ (rvc/lib/predictors/FCPE.py:806-826, 708-736): fcpe.pt is
+    ``{"config": {...}, "model": state_dict}``; the reference builds it inside VC.get_f0 on every call from
+    rvc/models/predictors/fcpe.pt (pipeline.py:169-181) and drops it again -- here it stays resident."""
+    ctx = _context(device)
+    slot, key = (_dev_index(device), "fcpe"), None
+    if cpt is None:
+        key = _file_key(model_path)
+        if slot in _RESIDENT and _RESIDENT[slot][0] == key and getattr(ctx, "fcpe_loaded", False):
+            return
+        cpt = _torch_load(model_path)
+    if "model" not in cpt:
+        raise ValueError("Invalid fcpe checkpoint: no 'model' state dict (FCPE.py:734)")
+    model_cfg = dict(cpt.get("config", {}).get("model", {}))
+    if model_cfg.get("use_siren") or model_cfg.get("use_full"):
+        raise ValueError("Siren / full FCPE models are not supported (nor by the reference, FCPE.py:573-576)")
+    if model_cfg.get("confidence"):
+        raise ValueError("fcpe checkpoints with confidence=True make the reference return a tuple it cannot index")
+    ctx.load_fcpe(weights.fcpe_cfg_struct(weights.fcpe_cfg_from_state(cpt["model"], cpt.get("config"))), cpt["model"])
+    ctx.fcpe_loaded = True
+    _RESIDENT.pop(slot, None)
+    if key is not None:
+        _RESIDENT[slot] = (key, True)
+
+
 def get_vc(device, is_half, config, model_path, cpt=None):
     """rvc/infer/infer.py:78-105 -> (cpt, version, net_g, tgt_sr, vc).  A ``model_path`` seen before (same
     realpath, mtime and size) returns the voice model already resident in HBM; the returned ``cpt`` then

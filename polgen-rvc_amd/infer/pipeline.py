@@ -3,9 +3,9 @@ signatures, backed by librvcx.so (HIP, gfx950).  Everything between the float64 
 the int16 output array runs on the GPU through the C ABI; there is no CPU fallback.
 
 Differences that are deliberate and documented:
-  * ``f0_method``: only "rmvpe+" (and its BASELINE alias "rmvpe") is implemented; anything else
-    raises ValueError (the reference hits an accidental UnboundLocalError, pipeline.py:152-183).
-  * ``filter_radius`` / ``hop_length`` are accepted and unused, as in the reference for rmvpe+.
+  * ``f0_method``: "rmvpe+" (with its BASELINE alias "rmvpe") and "fcpe" are implemented; "mangio-crepe" raises
+    ValueError, as does anything else (the reference hits an accidental UnboundLocalError, pipeline.py:152-183).
+  * ``filter_radius`` / ``hop_length`` are accepted and unused, as in the reference for rmvpe+ and fcpe.
   * ``model`` / ``net_g`` are opaque handles (``HubertHandle`` / ``SynthHandle`` from .infer); ``index`` is
     the handle ``_load_index`` returns (the vectors live in HBM), ``big_npy`` the matrix or ``True``.
   * keyword-only extras after the reference's parameters (``noise`` / ``z_noise`` / ``src_noise`` replace the
@@ -23,8 +23,9 @@ from ._state import _INDEX_RESIDENT
 
 # rvc/infer/pipeline.py:14-16 -- resolved against the working directory at import, like the reference
 RMVPE_DIR = os.path.join(os.getcwd(), "rvc", "models", "predictors", "rmvpe.pt")
+FCPE_DIR = os.path.join(os.getcwd(), "rvc", "models", "predictors", "fcpe.pt")
 
-F0_METHODS = ("rmvpe+", "rmvpe")
+F0_METHODS = ("rmvpe+", "rmvpe", "fcpe")
 
 
 def _np(a, dtype=None):
@@ -67,13 +68,14 @@ class VC:
     def _ctx(self):
         return _state.context(self.device)
 
-    def _params(self, pitch, index_rate, volume_envelope, protect, f0_min, f0_max, sid=0):
+    def _params(self, pitch, index_rate, volume_envelope, protect, f0_min, f0_max, sid=0, f0_method="rmvpe+"):
         p = _lib.Params()
         p.pitch, p.f0_min, p.f0_max = float(pitch), float(f0_min), float(f0_max)
         p.index_rate, p.protect, p.volume_envelope = float(index_rate), float(protect), float(volume_envelope)
         p.sid = int(sid)
         p.x_pad, p.x_query, p.x_center, p.x_max = self.x_pad, self.x_query, self.x_center, self.x_max
         p.seed = _state.next_seed() if self.seed is None else int(self.seed)
+        p.f0_method = _lib.F0_FCPE if f0_method == "fcpe" else _lib.F0_RMVPE
         return p
 
     @staticmethod
@@ -90,6 +92,17 @@ class VC:
         self.model_rmvpe = True
         return ctx
 
+    def _ensure_fcpe(self, ctx=None):
+        """pipeline.py:169-178: FCPEF0Predictor(FCPE_DIR, ...) -- built per call by the reference, resident here."""
+        ctx = ctx or self._ctx()
+        if not getattr(ctx, "fcpe_loaded", False):
+            from . import infer
+            infer.load_fcpe(self.device, FCPE_DIR)
+        return ctx
+
+    def _ensure_f0_model(self, f0_method, ctx=None):
+        return self._ensure_fcpe(ctx) if f0_method == "fcpe" else self._ensure_rmvpe(ctx)
+
     # ------------------------------------------------------------------------------------
     def get_f0_crepe(self, x, f0_min, f0_max, p_len, hop_length, model="full"):
         """pipeline.py:86-117 (torchcrepe): not on the north-star path."""
@@ -104,16 +117,21 @@ class VC:
     def get_f0(self, input_audio_path, x, p_len, pitch, f0_method, filter_radius, hop_length, inp_f0=None,
                f0_min=50, f0_max=1100):
         """pipeline.py:132-201.  ``x`` is the reflect-padded, high-passed signal, as in the reference; returns
-        (f0_coarse int array, f0 float array) of 1 + len(x)//160 frames (the caller truncates to p_len)."""
+        (f0_coarse int array, f0 float array): 1 + len(x)//160 frames for rmvpe+ (the caller truncates to p_len),
+        p_len frames for fcpe (FCPEF0Predictor.compute_f0 resizes to p_len itself, FCPE.py:869-877)."""
         self._check_method(f0_method)
-        ctx = self._ensure_rmvpe()
+        ctx = self._ensure_f0_model(f0_method)
         x = _np(x, np.float32)
         if inp_f0 is None:
-            coarse, f0 = ctx.get_f0_x(x, self._params(pitch, 0, 1, 0.5, f0_min, f0_max))
+            p = self._params(pitch, 0, 1, 0.5, f0_min, f0_max, f0_method=f0_method)
+            coarse, f0 = ctx.get_f0_fcpe_x(x, p_len, p) if f0_method == "fcpe" else ctx.get_f0_x(x, p)
             return coarse.astype(np.int64), f0.astype(np.float64)
         # f0 file (pipeline.py:185-191): the estimate is patched on the host, then quantised exactly as the
         # reference does (numpy float64).  rvc_infer never takes this branch (f0_file=None, infer.py:149).
-        f0 = self.get_f0_rmvpe(x, f0_min=f0_min, f0_max=f0_max)
+        if f0_method == "fcpe":
+            f0 = ctx.get_f0_fcpe_x(x, p_len, self._params(0, 0, 1, 0.5, f0_min, f0_max, f0_method="fcpe"))[1].astype(np.float64)
+        else:
+            f0 = self.get_f0_rmvpe(x, f0_min=f0_min, f0_max=f0_max)
         f0 *= pow(2, pitch / 12)
         tf0 = self.sample_rate // self.window
         inp_f0 = np.asarray(inp_f0, dtype=np.float64)
@@ -223,10 +241,10 @@ class VC:
         ctx = net_g.ctx
         if model.ctx is not ctx:
             raise ValueError("hubert and voice model live on different rvcx contexts")
-        self._ensure_rmvpe(ctx)
+        self._ensure_f0_model(f0_method, ctx)
         index, _ = self._load_index(ctx, file_index, index_rate)
         p = self._params(pitch, index_rate if index is not None else 0.0, volume_envelope, protect, f0_min, f0_max,
-                         int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid)
+                         int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid, f0_method=f0_method)
         # float64 stays float64 across the ABI (filtfilt then sees what the reference's sees); else float32
         clips = [a if _np(a).dtype == np.float64 else _np(a, np.float32) for a in map(_np, audios)]
         if not all(c.dtype == clips[0].dtype for c in clips):

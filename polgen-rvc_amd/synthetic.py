@@ -10,6 +10,7 @@ Layouts follow SURVEY.md Appendix B (names/shapes dumped from the reference):
   * voice model  : rvc/infer/infer.py:78-105 (``cpt = {"weight", "config", "f0", "version"}``)
   * rmvpe.pt     : rvc/lib/predictors/RMVPE.py:449-456 (bare state_dict of E2E(4,1,(2,2)))
   * hubert_base  : fairseq 0.12.2 HubertModel naming (not vendored in the reference)
+  * fcpe.pt      : rvc/lib/predictors/FCPE.py:708-736 (``{"config": {...}, "model": state_dict of FCPE}``)
 """
 from __future__ import annotations
 
@@ -36,6 +37,10 @@ RMVPE_CFG_FULL = dict(n_blocks=4, n_gru=1, en_de_layers=5, inter_layers=4,
                       in_channels=1, en_out_channels=16)
 RMVPE_CFG_TINY = dict(n_blocks=1, n_gru=1, en_de_layers=2, inter_layers=1,
                       in_channels=1, en_out_channels=4)
+
+# fcpe.pt's own config block (FCPE.py:715-733 reads these); heads = 8 x dim_head = 64 are SelfAttention defaults
+FCPE_CFG_FULL = dict(n_layers=6, n_chans=512, input_channel=128, out_dims=360)
+FCPE_CFG_TINY = dict(n_layers=2, n_chans=64, input_channel=128, out_dims=360)
 
 HUBERT_CFG_BASE = dict(conv_dim=512, conv_kernels=[10, 3, 3, 3, 3, 2, 2],
                        conv_strides=[5, 2, 2, 2, 2, 2, 2], embed_dim=768, ffn_dim=3072,
@@ -266,6 +271,84 @@ def hubert_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
     T.normal("mask_emb", (E,), 0.1)
     T.conv("final_proj", (cfg["final_dim"], E), gain=1.0)
     return T.t
+
+
+# ----------------------------------------------------------------------------
+# FCPE (rvc/lib/predictors/FCPE.py:551-627), state_dict names of the reference module
+# ----------------------------------------------------------------------------
+def _gaussian_orthogonal(name: str, rows: int, cols: int, seed: int) -> np.ndarray:
+    """A draw with the structure of gaussian_orthogonal_random_matrix(scaling=0) (FCPE.py:355-381): stacked
+    orthogonal blocks, rows rescaled to the norms of Gaussian vectors.  In a checkpoint it is a stored buffer."""
+    blocks, r = [], rows
+    i = 0
+    while r > 0:
+        g = _rng(f"{name}.blk{i}", seed).standard_normal((cols, cols))
+        q, _ = np.linalg.qr(g)
+        blocks.append(q.T[:min(r, cols)])
+        r -= cols
+        i += 1
+    mult = np.linalg.norm(_rng(name + ".mult", seed).standard_normal((rows, cols)), axis=1)
+    return (mult[:, None] * np.concatenate(blocks)).astype(np.float32)
+
+
+def fcpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
+    cfg = cfg or FCPE_CFG_FULL
+    C, L, cin, nout = cfg["n_chans"], cfg["n_layers"], cfg["input_channel"], cfg["out_dims"]
+    inner, dh = 512, 64                                  # heads * dim_head, FCPE.py:445-446
+    nfeat = int(dh * math.log(dh))                       # 266, FCPE.py:435
+    T = _Table(seed + 43)
+    T.conv("stack.0", (C, cin, 3), gain=0.25)            # log-mel inputs are O(5)
+    T.normal("stack.1.weight", (C,), 0.1, mean=1.0)
+    T.normal("stack.1.bias", (C,), 0.05)
+    T.conv("stack.3", (C, C, 3), gain=1.0)
+    for i in range(L):
+        p = f"decoder._layers.{i}"
+        T.normal(p + ".norm.weight", (C,), 0.1, mean=1.0)
+        T.normal(p + ".norm.bias", (C,), 0.05)
+        for nm in ("to_q", "to_k", "to_v"):
+            T.conv(f"{p}.attn.{nm}", (inner, C), gain=1.0)
+        T.conv(f"{p}.attn.to_out", (C, inner), gain=0.7)
+        T.t[f"{p}.attn.fast_attention.projection_matrix"] = _gaussian_orthogonal(
+            f"{p}.attn.fast_attention.projection_matrix", nfeat, dh, seed + 43)
+        T.normal(p + ".conformer.net.0.weight", (C,), 0.1, mean=1.0)
+        T.normal(p + ".conformer.net.0.bias", (C,), 0.05)
+        T.conv(p + ".conformer.net.2", (4 * C, C, 1), gain=1.0)
+        T.conv(p + ".conformer.net.4.conv", (2 * C, 1, 31), gain=1.5)
+        T.conv(p + ".conformer.net.6", (C, 2 * C, 1), gain=1.0)
+    T.normal("norm.weight", (C,), 0.1, mean=1.0)
+    T.normal("norm.bias", (C,), 0.05)
+    # dense_out = weight_norm(Linear(C, 360)): rows smooth across the pitch bins (as a trained salience head is),
+    # gains and bias placed so that the per-frame maximum straddles the 0.03 confidence threshold of VC.get_f0
+    v = _smooth_axis0(_normal("dense_out.v", (nout, C), 1.0, seed + 43), 1.6)
+    T.t["dense_out.parametrizations.weight.original1"] = v
+    T.t["dense_out.parametrizations.weight.original0"] = (
+        4.0 * (1.0 + 0.1 * _rng("dense_out.g", seed + 43).standard_normal((nout, 1)))).astype(np.float32)
+    T.t["dense_out.bias"] = (_smooth_axis0(_normal("dense_out.bias", (nout,), 1.0, seed + 43), 9.0)
+                             * np.float32(0.3) - np.float32(FCPE_BIAS)).astype(np.float32)
+    lo, hi = np.float32(1200.0) * np.log2(np.float32(32.70) / np.float32(10.0)), \
+        np.float32(1200.0) * np.log2(np.float32(1975.5) / np.float32(10.0))
+    T.t["cent_table"] = np.linspace(float(lo), float(hi), nout).astype(np.float32)
+    return T.t
+
+
+FCPE_BIAS = 14.2
+
+
+def fcpe_checkpoint(cfg: dict = None, seed: int = 0) -> dict:
+    """The container FCPEInfer.__init__ reads (FCPE.py:708-736)."""
+    cfg = cfg or FCPE_CFG_FULL
+    return {
+        "config": {
+            "model": {"input_channel": cfg["input_channel"], "out_dims": cfg["out_dims"], "n_layers": cfg["n_layers"],
+                      "n_chans": cfg["n_chans"], "use_siren": False, "use_full": False, "f0_max": 1975.5,
+                      "f0_min": 32.70, "confidence": False},
+            "loss": {"loss_mse_scale": 10, "loss_l2_regularization": False, "loss_l2_regularization_scale": 1,
+                     "loss_grad1_mse": False, "loss_grad1_mse_scale": 1},
+            "mel": {"sampling_rate": 16000, "num_mels": 128, "n_fft": 1024, "win_size": 1024, "hop_size": 160,
+                    "fmin": 0, "fmax": 8000},
+        },
+        "model": fcpe_state(cfg, seed),
+    }
 
 
 # ----------------------------------------------------------------------------

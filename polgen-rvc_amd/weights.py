@@ -39,6 +39,16 @@ def rmvpe_cfg_struct(cfg: Dict) -> _lib.RmvpeCfg:
     return s
 
 
+def fcpe_cfg_struct(cfg: Dict) -> _lib.FcpeCfg:
+    s = _lib.FcpeCfg()
+    s.n_layers, s.n_chans = cfg["n_layers"], cfg["n_chans"]
+    s.input_channel, s.out_dims = cfg.get("input_channel", 128), cfg.get("out_dims", 360)
+    s.heads, s.dim_head = cfg.get("heads", 8), cfg.get("dim_head", 64)
+    s.nb_features, s.dw_kernel = cfg.get("nb_features", 266), cfg.get("dw_kernel", 31)
+    s.mel_fmin, s.mel_fmax = float(cfg.get("mel_fmin", 0.0)), float(cfg.get("mel_fmax", 8000.0))
+    return s
+
+
 def hubert_cfg_struct(cfg: Dict) -> _lib.HubertCfg:
     s = _lib.HubertCfg()
     s.conv_dim, s.n_conv = cfg["conv_dim"], len(cfg["conv_kernels"])
@@ -77,6 +87,32 @@ def hubert_cfg_from_state(state: Dict) -> Dict:
                 ffn_dim=_shape(state["encoder.layers.0.fc1.weight"])[0], heads=max(1, embed // 64), layers=layers,
                 pos_kernel=wv[2], pos_groups=embed // wv[1],
                 final_dim=_shape(state["final_proj.weight"])[0] if "final_proj.weight" in state else 256)
+
+
+def fcpe_cfg_from_state(state: Dict, config: Dict = None) -> Dict:
+    """FCPE geometry read off the "model" state dict of fcpe.pt (the reference builds the module from the
+    checkpoint's "config" block, FCPE.py:715-733; the tensor shapes say the same and also give the module
+    defaults the block does not hold: heads x dim_head, the number of random features, the depth-wise kernel).
+    ``config``: that block, used for the mel band edges and to refuse a front end this library does not have."""
+    layers = 0
+    while f"decoder._layers.{layers}.norm.weight" in state:
+        layers += 1
+    n_chans, input_channel = _shape(state["stack.0.weight"])[:2]
+    proj = _shape(state["decoder._layers.0.attn.fast_attention.projection_matrix"])
+    inner = _shape(state["decoder._layers.0.attn.to_q.weight"])[0]
+    key = "dense_out.parametrizations.weight.original0" if "dense_out.parametrizations.weight.original0" in state \
+        else "dense_out.weight_g"
+    cfg = dict(n_layers=layers, n_chans=n_chans, input_channel=input_channel, out_dims=_shape(state[key])[0],
+               heads=inner // proj[1], dim_head=proj[1], nb_features=proj[0],
+               dw_kernel=_shape(state["decoder._layers.0.conformer.net.4.conv.weight"])[2], mel_fmin=0.0, mel_fmax=8000.0)
+    mel = dict((config or {}).get("mel", {}))
+    if mel:
+        want = dict(sampling_rate=16000, num_mels=128, n_fft=1024, win_size=1024, hop_size=160)
+        bad = {k: mel.get(k) for k, v in want.items() if mel.get(k, v) != v}
+        if bad:
+            raise ValueError(f"fcpe checkpoint with an unsupported mel front end: {bad} (supported: {want})")
+        cfg["mel_fmin"], cfg["mel_fmax"] = float(mel.get("fmin", 0.0)), float(mel.get("fmax", 8000.0))
+    return cfg
 
 
 def rmvpe_cfg_from_state(state: Dict) -> Dict:

@@ -1,0 +1,163 @@
+"""FCPE F0 back-end (rvcx_load_fcpe / rvcx_fcpe_f0 / rvcx_get_f0_fcpe_x, VC.get_f0(f0_method="fcpe")) on the GPU
+against the vectors captured from the reference's own FCPE module and VC.get_f0 / VC.pipeline call sites
+(tests/golden/fcpe_*.npz, pipeline_*fcpe*.npz; tools/gen_golden.py) and against the CPU oracle.  fp32;
+tolerances stated per test."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(ctx, cfg, seed):
+    from polgen_rvc_amd import synthetic as S, weights as W
+    sd = S.fcpe_state(cfg, seed)
+    ctx.load_fcpe(W.fcpe_cfg_struct(W.fcpe_cfg_from_state(sd)), sd)
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full_2s"])
+def test_fcpe_stages_vs_reference_golden(ctx, tag):
+    """log-mel (slaney basis, sqrt(re^2+im^2+1e-9), repeated last frame) <= 1e-4 rel; sigmoid salience of
+    FCPE.forward <= 1e-4 rel RMS; decoded Hz <= 1e-4 rel on voiced frames with identical voicing decisions
+    (the fixture's seed keeps every salience maximum >= 0.2 % away from the 0.03 threshold)."""
+    d = np.load(os.path.join(GOLD, f"fcpe_{tag}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    _load(ctx, cfg, int(d["seed"]))
+    st = int(d["stride"])
+    f0, sal, mel = ctx.fcpe_f0(d["x"], 0.03, return_salience=True, return_mel=True)
+    assert f0.shape == (1, len(d["x"]) // 160 + 1)
+    em = rms(mel[0][:, ::st] - d["mel"]) / rms(d["mel"])
+    es = rms(sal[0][::st] - d["salience"]) / rms(d["salience"])
+    ref = d["raw_f0"]
+    print(f"fcpe {tag}: log-mel rel err {em:.3e}; salience rel err {es:.3e} (max abs "
+          f"{np.abs(sal[0][::st] - d['salience']).max():.2e}); voiced {int((f0 > 0).sum())}/{f0.size}")
+    assert mel[0][:, ::st].shape == d["mel"].shape and em < 1e-4
+    assert es < 1e-4
+    assert ((ref > 0) == (f0[0] > 0)).all()
+    v = ref > 0
+    assert (np.abs(f0[0][v] - ref[v]) / ref[v]).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full_2s"])
+def test_get_f0_fcpe_vs_reference_golden(ctx, tag):
+    """VC.get_f0(..., "fcpe", ...) as the reference returns it (pipeline.py:169-201): p_len frames, unvoiced frames
+    bridged by np.interp in float64, pitch shift, coarse.  f0 <= 1e-4 rel (max), coarse identical."""
+    from polgen_rvc_amd.infer import infer as I
+    d = np.load(os.path.join(GOLD, f"fcpe_{tag}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    _load(ctx, cfg, int(d["seed"]))
+    ctx.fcpe_loaded = True
+    I._CTX[0] = ctx
+    vc = I.VC(48000, I.Config())
+    p_len = len(d["x"]) // 160
+    coarse, f0 = vc.get_f0("x.wav", d["x"], p_len, float(d["pitch"]), "fcpe", 3, 128, None, 50, 1100)
+    assert coarse.shape == f0.shape == (p_len,) and coarse.dtype == np.int64 and f0.dtype == np.float64
+    e = (np.abs(f0 - d["f0"]) / np.maximum(d["f0"], 1.0)).max()
+    print(f"get_f0 fcpe {tag}: f0 max rel err {e:.3e}; coarse differs at {int((coarse != d['coarse']).sum())} frames")
+    assert e < 1e-4
+    assert (coarse == d["coarse"]).all()
+
+
+def test_fcpe_post_process_vs_oracle_edge_cases(ctx):
+    """FCPEF0Predictor.post_process + get_f0's tail through the device kernel on hand-made raw tracks: nothing
+    voiced, a single voiced frame, voiced runs touching either end, long unvoiced gaps, p_len equal to / smaller
+    than / larger than the model's frame count (nearest resize in float32 index arithmetic), 10 minutes of frames
+    (np.interp in float64 on the reference's two differently rounded time axes, 512*i/16000 vs 0.032*i).
+    f0 must be float32-exact against the oracle, coarse identical."""
+    from oracle import fcpe as OF, pipeline as OP
+    rng = np.random.default_rng(3)
+
+    def track(n, voiced_frac, runs=True):
+        f = (100.0 + 400.0 * rng.random(n)).astype(np.float32)
+        if runs:
+            gate = np.repeat(rng.random(n // 7 + 1) < voiced_frac, 7)[:n]
+        else:
+            gate = rng.random(n) < voiced_frac
+        return np.where(gate, f, 0).astype(np.float32)
+
+    cases = [np.zeros(301, np.float32), track(301, 0.5), track(3001, 0.3), track(3001, 0.9, False), track(60001, 0.4)]
+    one = np.zeros(301, np.float32); one[123] = 222.5
+    ends = track(501, 0.5); ends[0] = 0; ends[1] = 150.0; ends[-1] = 0; ends[-2] = 0; ends[-3] = 310.0
+    first_last = track(501, 0.5); first_last[0] = 99.0; first_last[-2] = 500.0
+    cases += [one, ends, first_last]
+    for raw in cases:
+        n = len(raw)
+        for p_len in sorted({n - 1, n, max(1, n // 3), n + 17}):
+            coarse, f0 = ctx.fcpe_post(raw, p_len, pitch=-5.0)
+            ref = OF.post_process(raw, p_len) if (raw != 0).any() else np.zeros(p_len)
+            rc, rf = OP.f0_to_coarse(ref, -5.0, 50, 1100)
+            assert np.array_equal(f0, rf.astype(np.float32)), (n, p_len, np.abs(f0 - rf).max())
+            assert np.array_equal(coarse, rc), (n, p_len)
+
+
+def test_fcpe_batch_equals_single(ctx):
+    """B = 3 signals through one launch sequence: every row bit-identical to converting it alone."""
+    from polgen_rvc_amd import synthetic as S
+    _load(ctx, S.FCPE_CFG_TINY, 401)
+    a = np.stack([S.make_clip(50 + i, 1.3) for i in range(3)])
+    fb, sb = ctx.fcpe_f0(a, 0.03, return_salience=True)
+    for i in range(3):
+        f1, s1 = ctx.fcpe_f0(a[i], 0.03, return_salience=True)
+        assert np.array_equal(sb[i], s1[0]) and np.array_equal(fb[i], f1[0])
+
+
+def test_fcpe_checkpoint_file_and_lazy_load(ctx, tmp_path, monkeypatch):
+    """fcpe.pt as the reference stores it ({"config", "model"}, FCPE.py:708-736) is opened lazily from FCPE_DIR on
+    the first get_f0(f0_method="fcpe") (pipeline.py:169-178); legacy weight_g / weight_v names of dense_out load too."""
+    from polgen_rvc_amd import synthetic as S
+    from polgen_rvc_amd.infer import infer as I, pipeline as P
+    ck = S.fcpe_checkpoint(S.FCPE_CFG_TINY, 401)
+    sd = dict(ck["model"])
+    sd["dense_out.weight_g"] = sd.pop("dense_out.parametrizations.weight.original0")
+    sd["dense_out.weight_v"] = sd.pop("dense_out.parametrizations.weight.original1")
+    ck["model"] = S.to_torch(sd)
+    path = tmp_path / "fcpe.pt"
+    torch.save(ck, path)
+    I._CTX[0] = ctx
+    ctx.fcpe_loaded = False
+    monkeypatch.setattr(P, "FCPE_DIR", str(path))
+    vc = I.VC(48000, I.Config())
+    x = np.pad(S.make_clip(40, 1.7), (16000, 16000), mode="reflect").astype(np.float32)
+    coarse, f0 = vc.get_f0("x.wav", x, len(x) // 160, 0, "fcpe", 3, 128)
+    assert ctx.fcpe_loaded
+    _load(ctx, S.FCPE_CFG_TINY, 401)
+    c2, f2 = vc.get_f0("x.wav", x, len(x) // 160, 0, "fcpe", 3, 128)
+    assert np.array_equal(coarse, c2) and np.array_equal(f0, f2)
+
+
+def test_pipeline_fcpe_vs_reference_golden(ctx):
+    """VC.pipeline(..., f0_method="fcpe", ...) end to end against the reference's output with the same draws."""
+    from polgen_rvc_amd import synthetic as S
+    from polgen_rvc_amd.infer import infer as I
+    d = np.load(os.path.join(GOLD, "pipeline_tiny_fcpe.npz"))
+    hcfg, fcfg, scfg = json.loads(str(d["cfgs"]))
+    seed = int(d["seed"])
+    I._CTX[0] = ctx
+    hub = I.load_hubert("cuda:0", False, None, state=S.hubert_state(hcfg, seed), cfg=hcfg)
+    _load(ctx, fcfg, seed)
+    ctx.fcpe_loaded = True
+    cpt = S.synth_checkpoint(scfg, seed)
+    cpt["weight"] = S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])
+    cfg = I.Config()
+    cfg.x_pad, cfg.x_query, cfg.x_center, cfg.x_max = [int(v) for v in d["geo"]]
+    cpt, version, net_g, tgt_sr, vc = I.get_vc("cuda:0", False, cfg, None, cpt=cpt)
+    audio = S.make_clip(int(d["clip"]), float(d["seconds"]))
+    noise = np.concatenate([d["z_noise_0"].ravel(), d["src_noise_0"].ravel()]).astype(np.float32)
+    pcm, f32 = vc.pipeline(hub, net_g, 0, audio.astype(np.float64), "x.wav", float(d["pitch"]), "fcpe", None, 0, 1, 3,
+                           tgt_sr, 0, float(d["volume_envelope"]), "v2", float(d["protect"]), 128, None, noise=noise,
+                           return_f32=True)
+    ref = d["pcm"]
+    assert pcm.shape == ref.shape
+    diff = np.abs(pcm.astype(np.int32) - ref.astype(np.int32))
+    tp = int(tgt_sr) * int(d["geo"][0])
+    e = rms(f32 - d["raw"][tp:-tp])
+    print(f"pipeline fcpe: pcm max diff {diff.max()} LSB, frac>1 {np.mean(diff > 1):.2e}; float rms err {e:.3e}")
+    assert diff.max() <= 8 and np.mean(diff > 1) < 0.02
+    assert e < 1e-4                                              # north-star budget 1e-3

@@ -67,6 +67,8 @@ def test_mirror_signatures_match_reference():
     sig = inspect.signature(P.VC.get_f0_rmvpe).parameters
     assert (sig["f0_min"].default, sig["f0_max"].default) == (1, 40000)
     assert P.RMVPE_DIR == os.path.join(os.getcwd(), "rvc", "models", "predictors", "rmvpe.pt")   # pipeline.py:14-16
+    assert P.FCPE_DIR == os.path.join(os.getcwd(), "rvc", "models", "predictors", "fcpe.pt")
+    assert set(P.F0_METHODS) == {"rmvpe+", "rmvpe", "fcpe"}      # pipeline.py:142-181 minus mangio-crepe
     assert list(inspect.signature(I.get_vc).parameters)[:4] == ["device", "is_half", "config", "model_path"]
     assert list(inspect.signature(I.load_hubert).parameters)[:3] == ["device", "is_half", "model_path"]
     cfg = I.Config()
@@ -284,3 +286,33 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout)
+
+
+def test_fcpe_cfg_is_read_off_the_checkpoint():
+    """FCPEInfer builds the module from fcpe.pt's config block (FCPE.py:715-733); the shapes must say the same,
+    and give the module defaults the block does not hold (heads x dim_head, random features, depth-wise kernel)."""
+    from polgen_rvc_amd import synthetic as S, weights as W
+    for cfg in (S.FCPE_CFG_TINY, S.FCPE_CFG_FULL):
+        ck = S.fcpe_checkpoint(cfg, 0) if cfg is S.FCPE_CFG_TINY else None
+        sd = ck["model"] if ck else {k: np.zeros(v, np.float32) for k, v in _fcpe_shapes(cfg).items()}
+        got = W.fcpe_cfg_from_state(sd, ck["config"] if ck else None)
+        assert (got["n_layers"], got["n_chans"]) == (cfg["n_layers"], cfg["n_chans"])
+        assert (got["heads"], got["dim_head"], got["nb_features"], got["dw_kernel"], got["out_dims"]) == (8, 64, 266, 31, 360)
+        st = W.fcpe_cfg_struct(got)
+        assert (st.n_layers, st.n_chans, st.mel_fmax) == (cfg["n_layers"], cfg["n_chans"], 8000.0)
+    bad = S.fcpe_checkpoint(S.FCPE_CFG_TINY, 0)
+    bad["config"]["mel"]["hop_size"] = 256
+    with pytest.raises(ValueError, match="mel front end"):
+        W.fcpe_cfg_from_state(bad["model"], bad["config"])
+
+
+def _fcpe_shapes(cfg):
+    C, L = cfg["n_chans"], cfg["n_layers"]
+    s = {"stack.0.weight": (C, 128, 3), "dense_out.weight_g": (360, 1), "dense_out.weight_v": (360, C)}
+    for i in range(L):
+        p = f"decoder._layers.{i}"
+        s[p + ".norm.weight"] = (C,)
+        s[p + ".attn.to_q.weight"] = (512, C)
+        s[p + ".attn.fast_attention.projection_matrix"] = (266, 64)
+        s[p + ".conformer.net.4.conv.weight"] = (2 * C, 1, 31)
+    return s

@@ -103,3 +103,39 @@ def test_index_blend_oracle_properties():
     out, ids, dist = OP.index_blend(q.astype(np.float32), big, 1.0)
     assert (ids[:, 0] == [3, 77, 200]).all() and (np.diff(dist, axis=1) >= 0).all()
     assert rms(out - big[[3, 77, 200]]) < 1e-2          # (1/d)^2 weights are dominated by the exact neighbour
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full_2s"])
+def test_fcpe_oracle_vs_reference(tag):
+    """oracle/fcpe.py against the reference's FCPE module and VC.get_f0(f0_method="fcpe") call site."""
+    from oracle import fcpe as O, pipeline as OP
+    S = _S()
+    d = np.load(os.path.join(GOLD, f"fcpe_{tag}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    sd = S.to_torch(S.fcpe_state(cfg, int(d["seed"])))
+    st = int(d["stride"])
+    mel = O.mel_spectrogram(torch.from_numpy(d["x"])[None])
+    assert np.abs(mel[0].numpy().T[:, ::st] - d["mel"]).max() < 1e-5
+    sal = O.salience(sd, mel)[0].numpy()
+    assert rms(sal[::st] - d["salience"]) / rms(d["salience"]) < 1e-5
+    raw = O.infer_hz(sd, d["x"], 0.03)
+    assert ((raw > 0) == (d["raw_f0"] > 0)).all() and np.abs(raw - d["raw_f0"]).max() < 1e-2
+    coarse, f0 = OP.f0_to_coarse(O.compute_f0(sd, d["x"], len(d["x"]) // 160), float(d["pitch"]), 50, 1100)
+    assert np.abs(f0 - d["f0"]).max() < 1e-2 and (coarse == d["coarse"]).all()
+
+
+def test_fcpe_pipeline_oracle_vs_reference():
+    from oracle import pipeline as OP
+    S = _S()
+    d = np.load(os.path.join(GOLD, "pipeline_tiny_fcpe.npz"))
+    hcfg, fcfg, scfg = json.loads(str(d["cfgs"]))
+    seed = int(d["seed"])
+    models = OP.Models(S.to_torch(S.hubert_state(hcfg, seed)), hcfg, None, None,
+                       S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])), scfg,
+                       fcpe_sd=S.to_torch(S.fcpe_state(fcfg, seed)))
+    noises = [(torch.from_numpy(d["z_noise_0"]), torch.from_numpy(d["src_noise_0"]))]
+    pcm = OP.pipeline(models, OP.Geometry(scfg[-1], *[int(v) for v in d["geo"]]), S.make_clip(int(d["clip"]), float(d["seconds"])),
+                      float(d["pitch"]), 0, None, 0.0, float(d["volume_envelope"]), float(d["protect"]), 50, 1100,
+                      noises=noises, f0_method="fcpe")
+    diff = np.abs(pcm.astype(np.int32) - d["pcm"].astype(np.int32))
+    assert pcm.shape == d["pcm"].shape and diff.max() <= 8 and np.mean(diff > 1) < 0.02

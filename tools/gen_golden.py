@@ -66,11 +66,12 @@ sys.modules["faiss"].read_index = lambda path: _INDEX_FILES[path]
 
 import polgen_rvc_amd  # noqa: E402
 from polgen_rvc_amd import synthetic as S  # noqa: E402
-from oracle import synth as O_synth, rmvpe as O_rmvpe, hubert as O_hubert, pipeline as O_pipe  # noqa: E402
+from oracle import synth as O_synth, rmvpe as O_rmvpe, hubert as O_hubert, pipeline as O_pipe, fcpe as O_fcpe  # noqa: E402
 
 import rvc.infer.pipeline as P  # noqa: E402  (reference)
 from rvc.lib.algorithm.synthesizers import Synthesizer  # noqa: E402
 from rvc.lib.predictors import RMVPE as R  # noqa: E402
+from rvc.lib.predictors import FCPE as RF  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
@@ -279,7 +280,7 @@ def gold_hubert(tag, cfg, seconds, seed):
 
 
 def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0_min, f0_max, seed,
-                     tgt_sr, file_index=None, index_rate=0, prebuilt=None):
+                     tgt_sr, file_index=None, index_rate=0, prebuilt=None, f0_method="rmvpe+"):
     (hcfg, hsd), (rcfg, rsd), (scfg, ssd) = models_cfg
     vc = P.VC(tgt_sr, Cfg(geo))
     if prebuilt is None:
@@ -308,7 +309,7 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
     torch.randn_like = cap
     torch.manual_seed(seed)
     try:
-        pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, "rmvpe+", file_index, index_rate,
+        pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, f0_method, file_index, index_rate,
                           1, 3, tgt_sr, 0, volume_envelope, "v2", protect, 128, None, f0_min, f0_max)
     finally:
         torch.randn_like = orig
@@ -350,6 +351,110 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
                  chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
                  coarse=parts["coarse"].astype(np.int16),
                  sha256=hashlib.sha256(pcm.tobytes()).hexdigest(),
+                 block_rms=np.array([rms(rawcat[i:i + 4096]) for i in range(0, len(rawcat), 4096)], np.float32))
+    if full_store:
+        store.update(pcm=pcm, raw=rawcat.astype(np.float32))
+        for i, (zn, sn) in enumerate(noises):
+            store[f"z_noise_{i}"] = zn.numpy()
+            store[f"src_noise_{i}"] = sn.numpy()
+    else:
+        store.update(pcm_samples=pcm[::997], raw_samples=rawcat[::997].astype(np.float32), noise_seed=seed)
+    np.savez_compressed(os.path.join(GOLD, f"pipeline_{tag}.npz"), **store)
+
+# ------------------------------------------------------------------ FCPE
+def fcpe_file(cfg, seed):
+    """fcpe.pt as FCPEInfer.__init__ reads it (FCPE.py:708-736), with synthetic weights, in a scratch directory;
+    the reference's VC.get_f0 opens the module constant FCPE_DIR (pipeline.py:16,170-171), pointed there."""
+    ck = S.fcpe_checkpoint(cfg, seed)
+    ck["model"] = S.to_torch(ck["model"])
+    path = os.path.join("/tmp", f"fcpe_{cfg['n_layers']}x{cfg['n_chans']}_{seed}.pt")
+    torch.save(ck, path)
+    P.FCPE_DIR = path
+    return path, ck["model"]
+
+
+def fcpe_stable_seed(cfg, x, seed, pitch=0.0, f0_min=50, f0_max=1100, tries=40):
+    """First seed >= `seed` (step 100) whose voiced / unvoiced decisions (salience maximum vs the 0.03 threshold)
+    and coarse quantisation are all well-conditioned."""
+    mel = O_fcpe.mel_spectrogram(torch.from_numpy(x)[None])
+    for k in range(tries):
+        sd = S.to_torch(S.fcpe_state(cfg, seed + 100 * k))
+        sal = O_fcpe.salience(sd, mel)[0]
+        conf = sal.max(-1).values.numpy()
+        margin = np.abs(conf - 0.03).min() / 0.03
+        f0 = O_fcpe.compute_f0(sd, x, len(x) // 160)
+        _, q = O_pipe.f0_to_coarse(f0, pitch, f0_min, f0_max)
+        f0m = 1127 * np.log(1 + q / 700)
+        m0, m1 = 1127 * np.log(1 + f0_min / 700), 1127 * np.log(1 + f0_max / 700)
+        qq = (f0m - m0) * 254 / (m1 - m0) + 1
+        tie = (q > 0) & (np.abs(qq - np.floor(qq) - 0.5) < 1e-3)
+        vf = (conf > 0.03).mean()
+        print(f"  seed {seed + 100 * k}: threshold margin {margin:.2e}, coarse ties {int(tie.sum())}, voiced {vf:.2f}")
+        if margin > 2e-3 and not tie.any() and 0.15 < vf < 0.95:
+            return seed + 100 * k
+    raise RuntimeError("no stable fcpe seed found")
+
+
+def gold_fcpe(tag, cfg, seconds, clip, seed, pitch, stride=1):
+    """FCPE stage by stage against the reference's own module, through the reference's own call site VC.get_f0."""
+    print(f"[fcpe {tag}] {seconds}s pitch={pitch}")
+    a_ = O_pipe.highpass(S.make_clip(clip, seconds).astype(np.float64))
+    x = np.pad(a_, (16000, 16000), mode="reflect").astype(np.float32)       # audio_pad, pipeline.py:357
+    p_len = len(x) // 160
+    seed = fcpe_stable_seed(cfg, x, seed, pitch)
+    path, sd = fcpe_file(cfg, seed)
+    pred = RF.FCPEF0Predictor(path, f0_min=50, f0_max=1100, dtype=torch.float32, device="cpu", sample_rate=16000,
+                              threshold=0.03)
+    xt = torch.from_numpy(x)
+    mel = pred.fcpe.wav2mel(audio=xt[None], sample_rate=16000)               # (1, F, 128)
+    m = pred.fcpe.model
+    h = m.stack(mel.transpose(1, 2)).transpose(1, 2)
+    sal = torch.sigmoid(m.dense_out(m.norm(m.decoder(h))))[0]                # FCPE.forward up to :646
+    raw = pred.fcpe(xt, sr=16000, threshold=0.03)[0, :, 0].numpy()
+    vc = P.VC(48000, Cfg((1, 6, 38, 41)))
+    coarse, f0bak = vc.get_f0("x.wav", x, p_len, pitch, "fcpe", 3, 128, None, 50, 1100)
+    o_mel = O_fcpe.mel_spectrogram(xt[None])
+    o_sal = O_fcpe.salience(sd, o_mel)[0]
+    o_raw = O_fcpe.infer_hz(sd, x, 0.03)
+    o_coarse, o_f0 = O_pipe.f0_to_coarse(O_fcpe.compute_f0(sd, x, p_len), pitch, 50, 1100)
+    report("mel", mel, o_mel); e1 = report("salience", sal, o_sal); e2 = report("raw f0", raw, o_raw)
+    e3 = report("get_f0 f0", f0bak, o_f0)
+    print(f"  voiced {int((raw > 0).sum())}/{len(raw)}; coarse differs at {int((coarse != o_coarse).sum())} frames")
+    assert e1 < 1e-5 and e2 < 1e-2 and e3 < 1e-2 and (coarse == o_coarse).all(), (e1, e2, e3)
+    np.savez_compressed(os.path.join(GOLD, f"fcpe_{tag}.npz"), seed=seed, cfg=json.dumps(cfg), clip=clip,
+                        seconds=seconds, pitch=pitch, x=x, mel=mel[0].numpy().T[:, ::stride],
+                        salience=sal.numpy()[::stride], raw_f0=raw, f0=f0bak.astype(np.float64),
+                        coarse=coarse.astype(np.int16), stride=stride)
+
+
+def gold_pipeline_fcpe(tag, cfgs, fcfg, geo, seconds, clip, seed, pitch, volume_envelope, protect, full_store=True):
+    """VC.pipeline(..., f0_method="fcpe") end to end (pipeline.py:169-181 inside :362-380)."""
+    hcfg, rcfg, scfg = cfgs
+    print(f"[pipeline {tag}] fcpe {seconds}s geo={geo} pitch={pitch}")
+    a_ = O_pipe.highpass(S.make_clip(clip, seconds).astype(np.float64))
+    a_ = np.pad(a_, (16000 * geo[0], 16000 * geo[0]), mode="reflect").astype(np.float32)
+    seed = fcpe_stable_seed(fcfg, a_, seed, pitch)
+    path, fsd = fcpe_file(fcfg, seed)
+    hsd, ssd = S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"]))
+    tgt_sr = scfg[-1]
+    audio = S.make_clip(clip, seconds)
+    pcm, raw, noises = run_ref_pipeline(((hcfg, hsd), (rcfg, None), (scfg, ssd)), geo, audio, pitch, volume_envelope,
+                                        protect, 50, 1100, seed, tgt_sr, f0_method="fcpe",
+                                        prebuilt=(None, HubertAdapter(hf_hubert(hcfg, hsd))))
+    models = O_pipe.Models(hsd, hcfg, None, rcfg, ssd, scfg, fcpe_sd=fsd)
+    opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(tgt_sr, *geo), audio, pitch, 0, None, 0.0, volume_envelope,
+                                  protect, 50, 1100, noises=noises, return_parts=True, f0_method="fcpe")
+    e = 0.0
+    for i, (a, b) in enumerate(zip(raw, parts["raw"])):
+        e = max(e, report(f"vc chunk {i} f32", a, b))
+    d = np.abs(pcm.astype(np.int32) - opcm.astype(np.int32))
+    print(f"  chunks={len(raw)} pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
+    assert e < 1e-4 and d.max() <= 8, (e, d.max())
+    rawcat = np.concatenate(raw)
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, volume_envelope=volume_envelope,
+                 protect=protect, f0_min=50, f0_max=1100, cfgs=json.dumps([hcfg, fcfg, scfg]), n_chunks=len(raw),
+                 chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
+                 coarse=parts["coarse"].astype(np.int16), sha256=hashlib.sha256(pcm.tobytes()).hexdigest(),
                  block_rms=np.array([rms(rawcat[i:i + 4096]) for i in range(0, len(rawcat), 4096)], np.float32))
     if full_store:
         store.update(pcm=pcm, raw=rawcat.astype(np.float32))
@@ -491,6 +596,9 @@ def main():
         # CI's canonical argument set (test_cli.yml:43): -p -0.5 -rms 0.25 -pro 0.33 -f0min 1 -f0max 1100
         "pipe_tiny_ci": lambda: gold_pipeline("tiny_ciargs", tiny, (1, 6, 38, 41), 2.5, 12, 1, -0.5, 0.25, 0.33, 1, 1100),
         # small geometry to force the multi-chunk branch (pipeline.py:381-415)
+        "fcpe_tiny": lambda: gold_fcpe("tiny", S.FCPE_CFG_TINY, 1.2, 21, 1, 0.0),
+        "fcpe_full": lambda: gold_fcpe("full_2s", S.FCPE_CFG_FULL, 2.0, 22, 0, -3.0, stride=2),
+        "pipe_fcpe_tiny": lambda: gold_pipeline_fcpe("tiny_fcpe", tiny, S.FCPE_CFG_TINY, (1, 6, 38, 41), 2.0, 14, 1, 1.0, 1.0, 0.33),
         "pipe_tiny_chunks": lambda: gold_pipeline("tiny_chunked", tiny, (1, 1, 2, 3), 7.3, 13, 1, 2, 1.0, 0.33, 50, 1100),
     }
     if a.full:
@@ -500,6 +608,8 @@ def main():
                                                  50, 1100, full_store=False)
         steps["pipe_c2"] = lambda: gold_pipeline("c2_30s_48k", full48, (1, 6, 38, 41), 30.0, 0, 0, 0, 1.0, 0.33,
                                                  50, 1100, full_store=False)
+        steps["pipe_fcpe_c2"] = lambda: gold_pipeline_fcpe("c2_30s_48k_fcpe", full48, S.FCPE_CFG_FULL, (1, 6, 38, 41), 30.0,
+                                                           0, 0, 0, 1.0, 0.33, full_store=False)
         steps["pipe_c3"] = gold_pipeline_c3
         steps["pipe_c5"] = gold_pipeline_c5
     for k, fn in steps.items():
