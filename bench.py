@@ -40,16 +40,21 @@ C3_INDEX_ROWS = 65536
 CPU_SAMPLE_SECONDS = 8.0
 
 
-def load_models(ctx, zero=False):
+def load_models(ctx, zero=False, fcpe=False):
     def z(state):
         return {k: np.zeros_like(v) for k, v in state.items()} if zero else state
     ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0)))
-    ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, 0)))
+    if fcpe:
+        sd = S.fcpe_state(S.FCPE_CFG_FULL, 0)
+        ctx.load_fcpe(W.fcpe_cfg_struct(W.fcpe_cfg_from_state(sd)), z(sd))
+    else:
+        ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, 0)))
     return ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, 0)))
 
 
-def make_params(seed=0):
+def make_params(seed=0, fcpe=False):
     p = _lib.Params()
+    p.f0_method = _lib.F0_FCPE if fcpe else _lib.F0_RMVPE
     p.pitch, p.f0_min, p.f0_max = 0.0, 50.0, 1100.0
     p.index_rate, p.protect, p.volume_envelope = 0.0, 0.33, 1.0
     p.sid = 0
@@ -143,12 +148,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["c2", "c3"], default="c2")
     ap.add_argument("--batch", type=int, default=None, help="clips per step (c3 default 64, c2 default 1)")
+    ap.add_argument("--f0-method", choices=["rmvpe+", "fcpe"], default="rmvpe+",
+                    help="F0 back-end of VC.get_f0; BASELINE's metric is quoted on rmvpe+ (fcpe: secondary line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default="")
     a = ap.parse_args()
     c3 = a.workload == "c3"
+    fcpe = a.f0_method == "fcpe"
     B = a.batch or (C3_BATCH if c3 else 1)
     if a.steps is None:
         a.steps = 3 if c3 else 10
@@ -163,7 +171,7 @@ def main():
     if torch.cuda.device_count() < max(a.gpus, local + 1):
         raise SystemExit(f"--gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     fp32 = None
-    if world == 1 and not a.no_exact_fp32 and not c3:
+    if world == 1 and not a.no_exact_fp32 and not c3 and not fcpe:
         fp32 = exact_fp32_child(a.steps, a.warmup)       # before the first GPU call of this process
     rank, local, world = D.init("nccl")
     torch.cuda.set_device(local)
@@ -172,7 +180,7 @@ def main():
 
     # rank 0 parses/folds/packs the checkpoints; the folded weight regions go to the other GPUs over RCCL/xGMI
     t0 = time.perf_counter()
-    mid = load_models(ctx, zero=(rank != 0))
+    mid = load_models(ctx, zero=(rank != 0), fcpe=fcpe)
     if c3:
         big = S.make_index(C3_INDEX_ROWS, 768, 0)
         ctx.load_index(np.zeros_like(big) if rank != 0 else big)
@@ -181,7 +189,7 @@ def main():
     nbytes = D.broadcast_weights(ctx, local, 0)
     t_bcast = time.perf_counter() - t0
 
-    params = make_params()
+    params = make_params(fcpe=fcpe)
     if c3:
         params.index_rate = 0.75
     # pinned host buffers: the step's H2D / D2H copies are asynchronous DMA inside the timed region
@@ -250,6 +258,8 @@ def main():
               f"index_rate=0.75 over a resident {C3_INDEX_ROWS} x 768 index, geometry (1,6,38,41)" if c3 else
               ("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
               ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
+        if fcpe:
+            wl = wl.replace("f0_method=rmvpe+", "f0_method=fcpe (secondary line: BASELINE's metric is quoted on rmvpe+)")
         res = {"metric": "real-time-factor (audio-sec/wall-sec) per GPU, 30s@16kHz RMVPE->48kHz",
                "value": rtf, "unit": "x real-time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -265,7 +275,7 @@ def main():
                "stage_ms": stage, "roofline": roofline, "conv_tiles": prof}
         if fp32 is not None:
             res["exact_fp32"] = fp32
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not fcpe:
             res["cpu_baseline"] = cpu_baseline()
         else:
             res["cpu_baseline"] = None

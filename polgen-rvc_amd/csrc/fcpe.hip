@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void performer_kv_kernel(const float* __restri
                                                            float* __restrict__ part, int ntile, float dn, float ratio,
                                                            float eps) {
   extern __shared__ float lds[];
-  float* tile = lds;                      // [64][65]
-  float* kp = lds + PF_D * (PF_T + 1);    // [M][64]
+  float* tile = lds;                      // [64][65] staging of the k, then the v tile; dead once both sit in registers
+  float* kp = lds;                        // [M][64], overlays the staging tile (2 workgroups per CU fit in 160 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = blockIdx.x, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int t0 = tl * PF_T;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void performer_kv_kernel(const float* __restri
     tile[d * (PF_T + 1) + t] = (t0 + t < T) ? kb[(long)d * T + t0 + t] : 0.f;
   }
   __syncthreads();
-  float xr[PF_D];
+  float xr[PF_D], vr[PF_T];
   float diag = 0.f;
 #pragma unroll
   for (int d = 0; d < PF_D; ++d) {
@@ -142,6 +142,15 @@ __global__ __launch_bounds__(256) void performer_kv_kernel(const float* __restri
     xr[d] = dn * x;
   }
   diag = diag / 2.0f * (dn * dn);
+  __syncthreads();
+  for (int i = tid; i < PF_D * PF_T; i += 256) {
+    const int d = i >> 6, t = i & 63;
+    tile[d * (PF_T + 1) + t] = (t0 + t < T) ? vb[(long)d * T + t0 + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < PF_T; ++t) vr[t] = tile[lane * (PF_T + 1) + t];   // v[e = lane][t]
+  __syncthreads();
   const bool valid = t0 + lane < T;
   for (int j = wave; j < M; j += 4) {
     const float* pj = P + (long)j * PF_D;
@@ -151,20 +160,13 @@ __global__ __launch_bounds__(256) void performer_kv_kernel(const float* __restri
     kp[j * PF_T + lane] = valid ? ratio * expf(dot - diag + eps) : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < PF_D * PF_T; i += 256) {
-    const int d = i >> 6, t = i & 63;
-    tile[d * (PF_T + 1) + t] = (t0 + t < T) ? vb[(long)d * T + t0 + t] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < PF_T; ++t) xr[t] = tile[lane * (PF_T + 1) + t];   // v[e = lane][t]
   float* out = part + (((long)b * H + h) * ntile + tl) * ((long)M * (PF_D + 1));
   for (int j = wave; j < M; j += 4) {
     const float* kj = kp + j * PF_T;
     float acc = 0.f, ks = 0.f;
 #pragma unroll
     for (int t = 0; t < PF_T; ++t) {
-      acc += kj[t] * xr[t];
+      acc += kj[t] * vr[t];
       ks += kj[t];
     }
     out[(long)j * PF_D + lane] = acc;
@@ -188,9 +190,9 @@ __global__ __launch_bounds__(256) void performer_q_kernel(const float* __restric
                                                           const float* __restrict__ ctx, float* __restrict__ out,
                                                           long out_bs, float dn, float ratio, float eps) {
   extern __shared__ float lds[];
-  float* tile = lds;                      // [64][65]
-  float* qp = lds + PF_D * (PF_T + 1);    // [M][64]
-  float* red = qp + (long)M * PF_T;       // [4][64]
+  float* tile = lds;                      // [64][65] staging of the q tile, dead once it sits in registers
+  float* qp = lds;                        // [M][64], overlays the staging tile
+  float* red = qp + (long)max(M, PF_D + 2) * PF_T;   // [4][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = blockIdx.x, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int t0 = tl * PF_T;
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256) void performer_q_kernel(const float* __restric
     xr[d] = dn * x;
   }
   diag = diag / 2.0f * (dn * dn);
+  __syncthreads();
   float mx = -INFINITY;
   for (int j = wave; j < M; j += 4) {
     const float* pj = P + (long)j * PF_D;
@@ -574,14 +577,14 @@ void fcpe_forward(Ctx& c, const FcpeModel& m, int B, const float* audio, int64_t
   float* glu = A.alloc<float>((size_t)B * 2 * ci * F);
   float* dw = A.alloc<float>((size_t)B * ci * F);
   const float dn = 1.0f / std::sqrt(std::sqrt((float)cf.dim_head)), ratio = 1.0f / std::sqrt((float)Mf);
-  const size_t lds_kv = (size_t)(PF_D * (PF_T + 1) + Mf * PF_T) * sizeof(float);
-  const size_t lds_q = lds_kv + 4 * PF_T * sizeof(float);
+  const size_t lds_kv = (size_t)std::max(PF_D * (PF_T + 1), Mf * PF_T) * sizeof(float);
+  const size_t lds_q = (size_t)(std::max(PF_D + 2, Mf) + 4) * PF_T * sizeof(float);
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     RVCX_HIP(hipFuncSetAttribute((const void*)performer_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)((PF_D * (PF_T + 1) + PF_MAXM * PF_T) * sizeof(float))));
+                                 (int)(PF_MAXM * PF_T * sizeof(float))));
     RVCX_HIP(hipFuncSetAttribute((const void*)performer_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)((PF_D * (PF_T + 1) + PF_MAXM * PF_T + 4 * PF_T) * sizeof(float))));
+                                 (int)((PF_MAXM + 4) * PF_T * sizeof(float))));
   });
   for (const auto& L : m.layers) {
     // phone = phone + attn(norm(phone))

@@ -373,7 +373,7 @@ def fcpe_file(cfg, seed):
     return path, ck["model"]
 
 
-def fcpe_stable_seed(cfg, x, seed, pitch=0.0, f0_min=50, f0_max=1100, tries=40):
+def fcpe_stable_seed(cfg, x, seed, pitch=0.0, f0_min=50, f0_max=1100, tries=40, min_margin=2e-3):
     """First seed >= `seed` (step 100) whose voiced / unvoiced decisions (salience maximum vs the 0.03 threshold)
     and coarse quantisation are all well-conditioned."""
     mel = O_fcpe.mel_spectrogram(torch.from_numpy(x)[None])
@@ -390,7 +390,7 @@ def fcpe_stable_seed(cfg, x, seed, pitch=0.0, f0_min=50, f0_max=1100, tries=40):
         tie = (q > 0) & (np.abs(qq - np.floor(qq) - 0.5) < 1e-3)
         vf = (conf > 0.03).mean()
         print(f"  seed {seed + 100 * k}: threshold margin {margin:.2e}, coarse ties {int(tie.sum())}, voiced {vf:.2f}")
-        if margin > 2e-3 and not tie.any() and 0.15 < vf < 0.95:
+        if margin > min_margin and not tie.any() and 0.15 < vf < 0.95:
             return seed + 100 * k
     raise RuntimeError("no stable fcpe seed found")
 
@@ -427,13 +427,14 @@ def gold_fcpe(tag, cfg, seconds, clip, seed, pitch, stride=1):
                         coarse=coarse.astype(np.int16), stride=stride)
 
 
-def gold_pipeline_fcpe(tag, cfgs, fcfg, geo, seconds, clip, seed, pitch, volume_envelope, protect, full_store=True):
+def gold_pipeline_fcpe(tag, cfgs, fcfg, geo, seconds, clip, seed, pitch, volume_envelope, protect, full_store=True,
+                       min_margin=2e-3):
     """VC.pipeline(..., f0_method="fcpe") end to end (pipeline.py:169-181 inside :362-380)."""
     hcfg, rcfg, scfg = cfgs
     print(f"[pipeline {tag}] fcpe {seconds}s geo={geo} pitch={pitch}")
     a_ = O_pipe.highpass(S.make_clip(clip, seconds).astype(np.float64))
     a_ = np.pad(a_, (16000 * geo[0], 16000 * geo[0]), mode="reflect").astype(np.float32)
-    seed = fcpe_stable_seed(fcfg, a_, seed, pitch)
+    seed = fcpe_stable_seed(fcfg, a_, seed, pitch, min_margin=min_margin)
     path, fsd = fcpe_file(fcfg, seed)
     hsd, ssd = S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"]))
     tgt_sr = scfg[-1]
@@ -609,7 +610,9 @@ def main():
         steps["pipe_c2"] = lambda: gold_pipeline("c2_30s_48k", full48, (1, 6, 38, 41), 30.0, 0, 0, 0, 1.0, 0.33,
                                                  50, 1100, full_store=False)
         steps["pipe_fcpe_c2"] = lambda: gold_pipeline_fcpe("c2_30s_48k_fcpe", full48, S.FCPE_CFG_FULL, (1, 6, 38, 41), 30.0,
-                                                           0, 0, 0, 1.0, 0.33, full_store=False)
+                                                           0, 2100, 0, 1.0, 0.33, full_store=False,
+                                                           min_margin=2e-4)   # 3200 frames: the salience
+        # maximum of some frame always comes within ~1e-4 of the 0.03 threshold; 2e-4 is ~30x the GPU's error
         steps["pipe_c3"] = gold_pipeline_c3
         steps["pipe_c5"] = gold_pipeline_c5
     for k, fn in steps.items():
