@@ -299,6 +299,7 @@ int rvcx_bench_resblock_pair(rvcx_ctx* ctx, int B, int Cc, int T, int K, int dil
   float* dt = C->arena.alloc<float>(n);
   float* dy = C->arena.alloc<float>(n);
   launch_randn(dx, n, 1, 0, C->stream);
+  if (getenv("RVCX_BENCH_ZERO")) RVCX_HIP(hipMemsetAsync(dx, 0, n * 4, C->stream));   // power / clock experiments only
   PairArgs pa;
   pa.x = dx;
   pa.y = dy;

@@ -29,6 +29,10 @@ namespace {
 
 constexpr int kPairHalo = 64;    // (k - 1) d <= 50 for k <= 11, d <= 5
 constexpr int kPairPadY = 16;    // c2 reads up to k - 1 <= 10 columns past N1 (for output columns that are discarded)
+#ifndef RVCX_PAIR_SCHED_FENCE
+#define RVCX_PAIR_SCHED_FENCE 0
+#endif
+constexpr bool kSchedFence = RVCX_PAIR_SCHED_FENCE != 0;
 
 // K: taps (compile time: the k-loop is straight-line code, fragment reads of slot s+1 are issued ahead of the MFMAs
 // of slot s).  A stage = NCS chunks of 16 input channels x a group of <= KKT taps ("slots"); NCS > 1 only with
@@ -172,6 +176,10 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
     for (int s = 0; s < NS; ++s) {
       const int cur = s & 1;
       if (s + 1 < NS) load(cur ^ 1, s + 1);
+      // -DRVCX_PAIR_SCHED_FENCE=1 pins the reads of slot s+1 AHEAD of the MFMAs of slot s (left alone, the scheduler
+      // sinks every ds_read next to its first use, lgkmcnt(0) in front of each MFMA).  Measured neutral: with three
+      // waves per SIMD the other waves' MFMAs cover the latency, and the kernel is power-limited.
+      if (kSchedFence) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < WM; ++m) {
         const half8 wh = af[cur][0][m] * (_Float16)(1.f / kH3Scale);
@@ -182,6 +190,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
           acc[m][n] = h3_mfma(af[cur][1][m], bf[cur][0][n], acc[m][n]);   // (S wl) xh
         }
       }
+      if (kSchedFence) __builtin_amdgcn_sched_barrier(0);
     }
   };
   using Full = std::integral_constant<int, KKT>;
@@ -309,13 +318,13 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
 }
 
 struct PairCfg {
-  int C, K, n1, threads;
+  int C, K, n1, threads, variant;
   size_t lds;
   void (*kern)(const PairArgs);
 };
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS>
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0>
 constexpr PairCfg make_cfg() {
-  return {C, K, 32 * NT, 64 * WR * WC,
+  return {C, K, 32 * NT, 64 * WR * WC, V,
           (size_t)((C / 16) * 4 * (32 * NT + kPairPadY) + NCS * KKT * 4 * C + NCS * 4 * (32 * NT + kPairHalo)) * 16,
           resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS>};
 }
@@ -327,14 +336,14 @@ const PairCfg kPair[] = {
     // k = 7 keeps 512 threads with all 7 taps resident (the 768-thread form would spill)
     make_cfg<128, 6, 4, 3, 3, 3, 1>(),  make_cfg<128, 4, 4, 2, 7, 7, 1>(),  make_cfg<128, 6, 4, 3, 11, 4, 1>(),
     // RVCX_PAIR_VARIANT=1: the alternatives, for A/B runs
-    make_cfg<128, 4, 4, 2, 3, 3, 2>(),  make_cfg<128, 6, 4, 3, 7, 4, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1>(),
+    make_cfg<128, 4, 4, 2, 3, 3, 2, 1>(),  make_cfg<128, 6, 4, 3, 7, 4, 1, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1, 1>(),
 };
 constexpr int kPairBase = 9;
 const PairCfg* find_cfg(int C, int K) {
   static const int variant = getenv("RVCX_PAIR_VARIANT") ? atoi(getenv("RVCX_PAIR_VARIANT")) : 0;
-  if (variant == 1)
+  if (variant != 0)
     for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
-      if (kPair[i].C == C && kPair[i].K == K) return &kPair[i];
+      if (kPair[i].variant == variant && kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   for (int i = 0; i < kPairBase; ++i)
     if (kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   return nullptr;
