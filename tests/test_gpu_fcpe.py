@@ -207,3 +207,72 @@ def test_c2_fcpe_full_size_vs_reference_golden(ctx):
     assert diff.max() <= 64
     assert ef < 1e-5 and np.mean(coarse != d["coarse"]) < 1e-3
     _check_blocks(f32, d, tgt_sr, tol=2e-3)
+
+
+def test_ragged_batch_with_fcpe_equals_single_runs(ctx):
+    """f0_method="fcpe" through the batched path (rvcx_convert_batch): two clips of equal length form a micro-batch
+    (B = 2 through FCPE, HuBERT and the synthesizer), one clip is cut into chunks by the (1, 1, 2, 3) geometry; each
+    utterance is bit-identical to its single run, and the F0 back-end really is FCPE (rmvpe+ gives another result)."""
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    hcfg, scfg = S.HUBERT_CFG_TINY, S.SYNTH_CFG_TINY
+    ctx.load_hubert(W.hubert_cfg_struct(hcfg), S.hubert_state(hcfg, 7))
+    ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_TINY), S.rmvpe_state(S.RMVPE_CFG_TINY, 7))
+    _load(ctx, S.FCPE_CFG_TINY, 401)
+    mid = ctx.load_synth(W.synth_cfg_struct(scfg, hcfg["embed_dim"]), S.synth_state(scfg, 7, input_dim=hcfg["embed_dim"]))
+
+    def params(seed, method):
+        p = _lib.Params(2.0, 50.0, 1100.0, 0.0, 0.33, 0.5, 0, 1, 1, 2, 3, seed)
+        p.f0_method = method
+        return p
+    clips = [S.make_clip(60, 1.9), S.make_clip(61, 5.3), S.make_clip(62, 1.9)]
+    batch = ctx.convert_batch(mid, clips, params(5, _lib.F0_FCPE))
+    for i, c in enumerate(clips):
+        alone = ctx.convert_batch(mid, [c], params(5 + i, _lib.F0_FCPE))[0]
+        assert np.array_equal(alone, batch[i]), i
+    other = ctx.convert_batch(mid, [clips[0]], params(5, _lib.F0_RMVPE))[0]
+    assert len(other) == len(batch[0]) and not np.array_equal(other, batch[0])
+    _lib.lib().rvcx_unload_synth(ctx._h, mid)
+
+
+def test_f0_file_branch_of_get_f0_with_fcpe(ctx):
+    """pipeline.py:185-191 after the fcpe branch: the (time s, Hz) rows replace the estimate from x_pad seconds on,
+    everything else is compute_f0's interpolated track shifted by the pitch."""
+    from polgen_rvc_amd import synthetic as S
+    from polgen_rvc_amd.infer import infer as I
+    _load(ctx, S.FCPE_CFG_TINY, 401)
+    ctx.fcpe_loaded = True
+    I._CTX[0] = ctx
+    vc = I.VC(4800, I.Config())
+    x = np.pad(S.make_clip(5, 1.5).astype(np.float64), (16000, 16000), mode="reflect")
+    p_len = len(x) // 160
+    inp = np.stack([np.linspace(0.0, 1.0, 11), np.full(11, 200.0)], axis=1)
+    base_c, base_f = vc.get_f0("x", x, p_len, 3.0, "fcpe", 3, 128, None)
+    coarse, f0 = vc.get_f0("x", x, p_len, 3.0, "fcpe", 3, 128, inp)
+    assert coarse.shape == f0.shape == (p_len,)
+    assert np.allclose(f0[100:201], 200.0) and (coarse[100:201] == coarse[100]).all() and coarse[100] > 1
+    keep = np.r_[0:100, 201:p_len]
+    assert np.allclose(f0[keep], base_f[keep], rtol=1e-6) and (coarse[keep] == base_c[keep]).all()
+
+
+def test_fcpe_region_travels_with_the_weight_broadcast(ctx):
+    """The FCPE weights live in their own region, listed after RMVPE's (rvcx_weights_regions): a context that
+    loaded zeros of the same shapes reports the same layout and, after the device-side stand-in for the RCCL
+    broadcast (rvcx_weights_clone), produces the same F0."""
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    sd = S.fcpe_state(S.FCPE_CFG_TINY, 401)
+    cfg = W.fcpe_cfg_struct(W.fcpe_cfg_from_state(sd))
+    src, dst = _lib.Context(0), _lib.Context(0)
+    try:
+        src.load_fcpe(cfg, sd)
+        dst.load_fcpe(cfg, {k: np.zeros_like(v) for k, v in sd.items()})
+        ra, ha = src.weights_regions()
+        rb, hb = dst.weights_regions()
+        assert ha == hb and [n for _, n in ra] == [n for _, n in rb] and len(ra) >= 1
+        dst.weights_clone(src)
+        x = np.pad(S.make_clip(40, 1.7), (16000, 16000), mode="reflect").astype(np.float32)
+        a, sa = src.fcpe_f0(x, 0.03, return_salience=True)
+        b, sb = dst.fcpe_f0(x, 0.03, return_salience=True)
+        assert np.array_equal(sa, sb) and np.array_equal(a, b) and (a > 0).any()
+    finally:
+        src.close()
+        dst.close()
