@@ -58,7 +58,7 @@ def _view(ptr: int, nbytes: int, dev) -> torch.Tensor:
     return torch.from_numpy(np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(ptr)))
 
 
-def broadcast_weights(ctx, device_index: int = 0, src: int = 0) -> int:
+def broadcast_weights(ctx, device_index: int = 0, src: int = 0, force: bool = False) -> int:
     """Broadcast the folded weights of ``ctx`` from rank ``src`` (RCCL over xGMI under backend "nccl"): every
     chunk of every weight region (``ctx.weights_regions()``) is broadcast in place, then ``ctx.weights_adopt()``
     re-reads the value-dependent layer flags that travel in the region headers.
@@ -66,10 +66,11 @@ def broadcast_weights(ctx, device_index: int = 0, src: int = 0) -> int:
     Every rank must have loaded the same model configurations -- non-source ranks with placeholder (zero)
     tensors.  The layouts are compared first (shape-only hash + chunk sizes, all ranks gather all ranks'
     signatures), so a mismatch raises on EVERY rank instead of leaving rank ``src`` blocked in the collective.
-    Returns the number of bytes broadcast."""
+    Returns the number of bytes broadcast.  ``force``: run the collectives in a 1-rank group too (the single-GPU
+    test of the RCCL path: device views of the library's chunks, all_gather, broadcast, adopt)."""
     regions, layout = ctx.weights_regions()
     nbytes = sum(n for _, n in regions)
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return nbytes
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")

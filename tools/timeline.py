@@ -1,26 +1,43 @@
 #!/usr/bin/env python3
-"""Per-stream timeline summary of one bench step from a rocprofv3 rocpd .db (kernel trace)."""
-import sqlite3, sys, collections
-db = sqlite3.connect(sys.argv[1])
-step = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-rows = db.execute("select name,start,end,stream_id from kernels order by start").fetchall()
-starts = [i for i, r in enumerate(rows) if 'iir_slice' in r[0]][::2]
-w = rows[starts[step]:starts[step + 1]] if step + 1 < len(starts) else rows[starts[step]:]
-t0 = w[0][1]
-ms = lambda t: (t - t0) / 1e6
-by = collections.defaultdict(list)
-for r in w:
-    by[r[3]].append(r)
-for sid, l in sorted(by.items()):
-    print(f"stream {sid}: n={len(l)} span {ms(l[0][1]):.2f}..{ms(l[-1][2]):.2f} busy {sum(r[2]-r[1] for r in l)/1e6:.2f}")
-marks = ['bigru_cluster', 'groupnorm_gelu', 'embed_pitch', 'sine_prefix', 'gru_input', 'to_int16', 'decode_f0', 'attn_kernel<2>']
-seen = set()
-for r in w:
-    for m in marks:
-        if m in r[0] and m not in seen:
-            seen.add(m)
-            print(f"  first {m:18s} stream {r[3]} {ms(r[1]):.2f}..{ms(r[2]):.2f}")
-last_attn2 = [r for r in w if 'attn_kernel<2>' in r[0]]
-if last_attn2:
-    print(f"  last attn_kernel<2> ends {ms(last_attn2[-1][2]):.2f}")
-print(f"step total {ms(w[-1][2]):.2f} ms")
+"""Per-queue timeline of the LAST conversion step in a `rocprofv3 --kernel-trace --output-format csv` run of bench.py
+(concurrent mode): for each hardware queue the span, the busy time, the idle time inside the span and the dispatch
+count; chip-wide idle time (no kernel running on any queue); the largest gaps per queue with the kernels around them.
+usage: timeline.py <dir> [out.txt]"""
+import csv, glob, os, sys
+
+rows = []
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]))
+rows.sort()
+# a step starts with the float64 high-pass: the first iir_slice_kernel after a pause
+starts = [i for i, r in enumerate(rows) if "iir_slice" in r[3] and (i == 0 or "iir_slice" not in rows[i - 1][3])]
+starts = [s for j, s in enumerate(starts) if j == 0 or rows[s][0] - rows[starts[j - 1]][0] > 5_000_000]
+lo = starts[-1]
+step = rows[lo:]
+t0 = step[0][0]
+out = [f"last step: {len(step)} dispatches, {(max(r[1] for r in step) - t0) / 1e6:.3f} ms from the first high-pass kernel to the last kernel end"]
+queues = sorted({r[2] for r in step})
+for q in queues:
+    ks = [r for r in step if r[2] == q]
+    busy = sum(r[1] - r[0] for r in ks)
+    span = ks[-1][1] - ks[0][0]
+    out.append(f"queue {q}: {len(ks):4d} dispatches, starts at {(ks[0][0] - t0) / 1e6:7.3f} ms, span {span / 1e6:7.3f} ms, busy {busy / 1e6:7.3f} ms, "
+               f"idle inside span {(span - busy) / 1e6:7.3f} ms  first={ks[0][3][:40]} last={ks[-1][3][:40]}")
+    gaps = sorted(((ks[i + 1][0] - ks[i][1], i) for i in range(len(ks) - 1)), reverse=True)[:6]
+    for g, i in gaps:
+        out.append(f"      gap {g / 1e3:8.1f} us at {(ks[i][1] - t0) / 1e6:7.3f} ms after {ks[i][3][:48]:48s} before {ks[i + 1][3][:48]}")
+# chip-wide idle
+ev = sorted([(r[0], 1) for r in step] + [(r[1], -1) for r in step])
+depth, idle, last = 0, 0, None
+for t, d in ev:
+    if depth == 0 and last is not None:
+        idle += t - last
+    depth += d
+    if depth == 0:
+        last = t
+out.append(f"chip-wide idle inside the step: {idle / 1e6:.3f} ms")
+txt = "\n".join(out)
+print(txt)
+if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write(txt + "\n")
