@@ -89,6 +89,8 @@ int rvcx_create(int device, rvcx_ctx** out) {
     for (auto& e : h->c.ev_src) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_join, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_hub, hipEventDisableTiming));
+    for (auto& e : h->c.ev_hubdone) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : h->c.ev_syn) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_io, hipEventDisableTiming));
     for (auto& e : h->c.ev_front) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : h->c.ev_done) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

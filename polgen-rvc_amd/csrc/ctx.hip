@@ -104,6 +104,10 @@ Ctx::~Ctx() {
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream_h) (void)hipStreamDestroy(stream_h);
   if (ev_hub) (void)hipEventDestroy(ev_hub);
+  for (auto e : ev_hubdone)
+    if (e) (void)hipEventDestroy(e);
+  for (auto e : ev_syn)
+    if (e) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -57,6 +57,7 @@ struct SynthIO {
   // optional taps for parity tests (device, may be null)
   float* stats_out = nullptr;         // (B, 2*inter, T) = [m_p ; logs_p]
   float* z_out = nullptr;             // (B, inter, T)
+  hipEvent_t ev_decoder = nullptr;    // optional: recorded on the main stream when the NSF decoder section begins
 };
 size_t synth_arena_bytes(const SynthModel& m, int B, int T);
 // stage_ev (optional): 4 caller-created events recorded at {start, enc_p done, flow done, decoder done} -- no sync

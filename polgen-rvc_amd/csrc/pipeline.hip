@@ -2,6 +2,7 @@
 // chunking, F0 once per utterance, per-chunk HuBERT -> (index blend) -> x2 upsample / protect ->
 // Synthesizer.infer, trim, RMS envelope, peak normalise, int16.
 #include <algorithm>
+#include <chrono>
 #include <array>
 #include <cmath>
 #include <cstdlib>
@@ -382,6 +383,8 @@ size_t convert_item_bytes(Ctx& c, int model_id, long n, const rvcx_params& p) {
   const long max_chunk = std::min<long>(n_pad, g.t_center + 2 * g.t_query + 2 * g.t_pad + 320);
   const int Tmax = (int)(max_chunk / 160 + 2);
   size_t b = 2 * ((size_t)n_pad * 40 + (1 << 16));                    // two front sets
+  b += 2 * (size_t)c.hubert->cfg.embed_dim *
+       (size_t)((n_pad + (cut_count(n, g) + 1) * (2 * g.t_pad + 640)) / 320 + 8) * 4;   // HuBERT features of both sets
   b += hubert_arena_bytes(*c.hubert, 1, max_chunk) - ((size_t)64 << 20) + (size_t)max_chunk * 4;
   b += synth_arena_bytes(M, 1, Tmax) - ((size_t)64 << 20) +
        (size_t)Tmax * ((size_t)M.cfg.input_dim * 3 + (size_t)M.upp * 3 + M.cfg.inter_channels + 8) * 4;
@@ -484,7 +487,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     mbs.push_back({i, j - i});
     i = j;
   }
-  size_t call_bytes = 0, mb_bytes = 0, f0_bytes = 0;
+  size_t call_bytes = 0, mb_bytes = 0, f0_bytes = 0, hub_bytes = 0;
   for (const auto& u : ios) {
     any_f64 |= u.wav64 != nullptr;
     any_noise |= u.noise != nullptr;
@@ -495,6 +498,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     const long n = ios[order[mb.first]].n;
     mb_bytes = std::max(mb_bytes, (size_t)mb.count * convert_item_bytes(c, model_id, n, p));
     f0_bytes = std::max(f0_bytes, f0_arena_bytes(c, p, mb.count, n + 2 * g.t_pad));
+    const long n_pad = n + 2 * g.t_pad;
+    const long max_chunk = std::min<long>(n_pad, g.t_center + 2 * g.t_query + 2 * g.t_pad + 320);
+    hub_bytes = std::max(hub_bytes, hubert_arena_bytes(*c.hubert, mb.count, max_chunk) + (size_t)mb.count * max_chunk * 8);
   }
   (void)any_f64;
   (void)any_noise;
@@ -507,6 +513,8 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   A.reset();
   c.arena_f0.reset();
   c.arena_f0.reserve(f0_bytes + ((size_t)64 << 20));
+  c.arena_hub.reset();
+  c.arena_hub.reserve(hub_bytes + ((size_t)64 << 20));
 
   // ---- call-long buffers
   std::vector<Utt> utts(NB);
@@ -531,11 +539,13 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     float *a32 = nullptr, *apad = nullptr, *f0 = nullptr;
     int* coarse = nullptr;
     long* cuts = nullptr;
+    float* feats = nullptr;     // HuBERT features of every chunk of the micro-batch, group after group
+    size_t feats_cap = 0;
   } fr[2];
   size_t front_items = 0;
   for (const auto& mb : mbs) front_items = std::max(front_items, (size_t)mb.count);
   {
-    size_t wmax = 0, emax = 0, nmax = 0, pmax = 0, fmax = 0, cmax = 0;
+    size_t wmax = 0, emax = 0, nmax = 0, pmax = 0, fmax = 0, cmax = 0, hmax = 0;
     for (const auto& mb : mbs) {
       const long n = ios[order[mb.first]].n;
       const size_t k = (size_t)mb.count;
@@ -545,6 +555,8 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       pmax = std::max(pmax, k * (size_t)(n + 2 * g.t_pad));
       fmax = std::max(fmax, k * (size_t)((n + 2 * g.t_pad) / 160 + 8));
       cmax = std::max(cmax, k * (size_t)(cut_count(n, g) + 1));
+      // every chunk carries 2 * t_pad samples of context beyond its share of the clip
+      hmax = std::max(hmax, k * (size_t)E * (size_t)((n + 2 * g.t_pad + (cut_count(n, g) + 1) * (2 * g.t_pad + 640)) / 320 + 8));
     }
     for (auto& f : fr) {
       f.wav = A.alloc<char>(wmax);
@@ -555,10 +567,17 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       f.f0 = A.alloc<float>(fmax);
       f.coarse = A.alloc<int>(fmax);
       f.cuts = A.alloc<long>(cmax);
+      f.feats = A.alloc<float>(hmax);
+      f.feats_cap = hmax;
     }
   }
   const size_t work_mark = A.mark();
 
+  // RVCX_FRONT_DELAY (experiments): 0 (default) = the next micro-batch's front end starts as soon as its buffers are
+  // free, 1 = when the main stream reaches this micro-batch's synthesizer, 2 = when it reaches the NSF decoder.
+  // Measured on C3 (64 x 30 s): 1036 / 1030 / 1031 x -- at B = 8 HuBERT and the F0 model are throughput-bound like the
+  // decoder, so WHERE they overlap the main stream does not matter: the sum of the kernel times is what it is.
+  static const int front_delay = getenv("RVCX_FRONT_DELAY") ? atoi(getenv("RVCX_FRONT_DELAY")) : 0;
   // ---- front end of one micro-batch on `sf`: upload, high-pass, cut search, reflect pad.  Returns after the
   // (rare) cut-point read-back, so the chunk plan is known to the host.
   auto front = [&](int k) {
@@ -567,6 +586,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     const long n = ios[order[mb.first]].n, n_pad = n + 2 * g.t_pad;
     const int Bm = mb.count;
     if (sf != s && k >= 2) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_done[k & 1], 0));   // set k&1 was micro-batch k-2's
+    if (sf != s && k >= 1 && front_delay) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_syn[(k - 1) & 1], 0));
     const bool f64 = ios[order[mb.first]].wav64 != nullptr;
     for (int b = 0; b < Bm; ++b) {
       const UttIO& io = ios[order[mb.first + b]];
@@ -631,7 +651,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   };
 
   const int e_begin = clk.mark(s);
-  float t_hp = 0, t_f0 = 0, t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0}, t_post = 0;
+  float t_hp = 0, t_f0 = 0, t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0}, t_post = 0, t_wait_hub = 0, t_wait_f0 = 0;
   struct Span {
     int a, b;
     float* acc;
@@ -646,14 +666,22 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   }
   const bool use_protect = p.protect < 0.5f;
   const bool use_index = c.index && p.index_rate != 0.f;
-  for (int k = 0; k < (int)mbs.size(); ++k) {
-    const MB& mb = mbs[k];
-    const int Bm = mb.count;
-    A.reset(work_mark);
-    if (sf != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_front[k & 1], 0));   // apad of this micro-batch is ready
-    // ---- jobs of this micro-batch, grouped by chunk length (order of first appearance)
+  hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;   // HuBERT's stream
+
+  // ---- chunk jobs of a micro-batch, grouped by chunk length (order of first appearance); group gi's HuBERT
+  // features live at fr[k & 1].feats + feats_off[gi]
+  struct Plan {
     std::vector<Job> jobs;
-    for (int b = 0; b < Bm; ++b) {
+    std::vector<std::vector<int>> groups;
+    std::vector<size_t> feats_off;
+  } plans[2];
+  auto plan_jobs = [&](int k) {
+    const MB& mb = mbs[k];
+    Plan& P = plans[k & 1];
+    P.jobs.clear();
+    P.groups.clear();
+    P.feats_off.clear();
+    for (int b = 0; b < mb.count; ++b) {
       Utt& u = utts[order[mb.first + b]];
       long out_off = 0, noise_off = 0;
       for (size_t ci = 0; ci < u.plan.size(); ++ci) {
@@ -665,7 +693,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         // a cut may land within x_pad seconds of the clip's end: the reference then trims that chunk's output to
         // nothing (audio1[t_pad_tgt:-t_pad_tgt], pipeline.py:441-447) but still runs it -- so do we
         RVCX_CHECK((long)T * M.upp >= 2 * g.t_pad_tgt, "convert: chunk shorter than its padding");
-        jobs.push_back({b, (int)ci, ch.s, ch.e, ch.f0_off, out_off, noise_off, Th, T});
+        P.jobs.push_back({b, (int)ci, ch.s, ch.e, ch.f0_off, out_off, noise_off, Th, T});
         out_off += (long)T * M.upp - 2 * g.t_pad_tgt;
         noise_off += (long)T * (inter + M.upp);
       }
@@ -673,61 +701,105 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       RVCX_CHECK(!u.noise || noise_off <= u.noise_cap, "convert: parity noise buffer shorter than the chunk plan needs");
       u.out_n = out_off;
     }
-    std::vector<std::vector<int>> groups;
-    for (int j = 0; j < (int)jobs.size(); ++j) {
+    for (int j = 0; j < (int)P.jobs.size(); ++j) {
       size_t gi = 0;
-      for (; gi < groups.size(); ++gi)
-        if (jobs[groups[gi][0]].e - jobs[groups[gi][0]].s == jobs[j].e - jobs[j].s) break;
-      if (gi == groups.size()) groups.emplace_back();
-      groups[gi].push_back(j);
+      for (; gi < P.groups.size(); ++gi)
+        if (P.jobs[P.groups[gi][0]].e - P.jobs[P.groups[gi][0]].s == P.jobs[j].e - P.jobs[j].s) break;
+      if (gi == P.groups.size()) P.groups.emplace_back();
+      P.groups[gi].push_back(j);
     }
-    bool joined = false, f0_enqueued = false;
+    size_t off = 0;
+    for (const auto& grp : P.groups) {
+      P.feats_off.push_back(off);
+      off += (size_t)grp.size() * E * P.jobs[grp[0]].Th;
+    }
+    RVCX_CHECK(off <= fr[k & 1].feats_cap, "internal: HuBERT feature buffer smaller than the chunk plan");
+  };
+
+  // ---- HuBERT of one micro-batch on its own stream and out of its own arena: it depends on the micro-batch's front
+  // end only, so for k >= 1 it runs beside the synthesizer of micro-batch k-1.  One host thread feeds both branches:
+  // the F0 model's small launches are enqueued right after the first conv extractor (long kernels), otherwise HuBERT
+  // would idle while the host enqueues them.
+  std::vector<int> hub_ev0(mbs.size(), -1), hub_ev1(mbs.size(), -1);
+  auto enqueue_hubert = [&](int k) {
+    const MB& mb = mbs[k];
+    Plan& P = plans[k & 1];
+    Front& f = fr[k & 1];
+    bool f0_enqueued = false;
     const std::function<void()> after_extractor = [&]() {
-      // One host thread feeds both branches: RMVPE's small launches are enqueued right after the first HuBERT conv
-      // extractor of the micro-batch (long kernels), otherwise HuBERT would idle while the host enqueues RMVPE.
       if (f0_enqueued) return;
       f0_enqueued = true;
       enqueue_f0(k);
     };
-    for (const auto& grp : groups) {
+    if (sh != sf) RVCX_HIP(hipStreamWaitEvent(sh, c.ev_front[k & 1], 0));   // apad of this micro-batch is ready
+    hub_ev0[k] = clk.mark(sh);
+    c.arena_hub.reset();
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+      const auto& grp = P.groups[gi];
+      const int G = (int)grp.size();
+      const Job& j0 = P.jobs[grp[0]];
+      const long ns = j0.e - j0.s;
+      c.arena.swap(c.arena_hub);       // allocations below come from HuBERT's arena (stream-ordered on `sh`)
+      try {
+        const size_t mk = c.arena.mark();
+        // chunk audio (G, ns): strided view of apad when the items are consecutive utterances cut at the same place
+        const float* wav = utts[order[mb.first + j0.u]].apad + j0.s;
+        long wav_bs = ns;
+        bool uniform = true;
+        for (int q = 1; q < G; ++q) uniform &= P.jobs[grp[q]].s == j0.s && P.jobs[grp[q]].u == j0.u + q;
+        if (G > 1 && uniform) {
+          wav_bs = utts[order[mb.first + j0.u]].n_pad;
+        } else if (G > 1) {
+          float* wg = c.arena.alloc<float>((size_t)G * ns);
+          for (int q = 0; q < G; ++q)
+            RVCX_HIP(hipMemcpyAsync(wg + (size_t)q * ns, utts[order[mb.first + P.jobs[grp[q]].u]].apad + P.jobs[grp[q]].s,
+                                    (size_t)ns * 4, hipMemcpyDeviceToDevice, sh));
+          wav = wg;
+        }
+        hubert_forward(c, *c.hubert, G, wav, ns, 12, f.feats + P.feats_off[gi], sh, &after_extractor, wav_bs);
+        c.arena.reset(mk);
+      } catch (...) {
+        c.arena.swap(c.arena_hub);
+        throw;
+      }
+      c.arena.swap(c.arena_hub);
+    }
+    hub_ev1[k] = clk.mark(sh);
+    if (sh != s) RVCX_HIP(hipEventRecord(c.ev_hubdone[k & 1], sh));
+    if (!f0_enqueued) after_extractor();
+  };
+
+  static const bool host_trace = getenv("RVCX_HOST_TRACE") != nullptr;   // where does the enqueueing thread spend its time?
+  const auto ht0 = std::chrono::steady_clock::now();
+  auto ht = [&](const char* what, int k) {
+    if (host_trace)
+      fprintf(stderr, "[host] mb %d %-14s %9.3f ms\n", k, what,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count());
+  };
+  plan_jobs(0);
+  enqueue_hubert(0);
+  ht("hubert+f0", 0);
+  for (int k = 0; k < (int)mbs.size(); ++k) {
+    const MB& mb = mbs[k];
+    const int Bm = mb.count;
+    Plan& P = plans[k & 1];
+    const std::vector<Job>& jobs = P.jobs;
+    A.reset(work_mark);
+    const int w0 = clk.mark(s);
+    if (sf != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_front[k & 1], 0));   // a64 (envelope) of this micro-batch is ready
+    if (sh != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_hubdone[k & 1], 0)); // and its HuBERT features
+    const int w1 = clk.mark(s);
+    spans.push_back({w0, w1, &t_wait_hub});
+    bool joined = false;
+    for (size_t gi = 0; gi < P.groups.size(); ++gi) {
+      const auto& grp = P.groups[gi];
       const size_t mk = A.mark();
       const int G = (int)grp.size();
       const Job& j0 = jobs[grp[0]];
-      const long ns = j0.e - j0.s;
       const int Th = j0.Th, T = j0.T;
       const size_t nz = (size_t)inter * T, nsrc = (size_t)T * M.upp;
-      // chunk audio (G, ns): strided view of apad when the items are consecutive utterances cut at the same place
-      const float* wav = utts[order[mb.first + j0.u]].apad + j0.s;
-      long wav_bs = ns;
-      bool uniform = true;
-      for (int q = 1; q < G; ++q) uniform &= jobs[grp[q]].s == j0.s && jobs[grp[q]].u == j0.u + q;
-      if (G > 1 && uniform) {
-        wav_bs = utts[order[mb.first + j0.u]].n_pad;
-      } else if (G > 1) {
-        float* wg = A.alloc<float>((size_t)G * ns);
-        for (int q = 0; q < G; ++q)
-          RVCX_HIP(hipMemcpyAsync(wg + (size_t)q * ns, utts[order[mb.first + jobs[grp[q]].u]].apad + jobs[grp[q]].s,
-                                  (size_t)ns * 4, hipMemcpyDeviceToDevice, s));
-        wav = wg;
-      }
-      const int h0 = clk.mark(s);
-      float* feats = A.alloc<float>((size_t)G * E * Th);
-      {
-        const size_t mk2 = A.mark();
-        hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;
-        if (sh != s) {
-          RVCX_HIP(hipEventRecord(c.ev_hub, s));
-          RVCX_HIP(hipStreamWaitEvent(sh, c.ev_hub, 0));
-        }
-        hubert_forward(c, *c.hubert, G, wav, ns, 12, feats, sh, &after_extractor, wav_bs);
-        if (sh != s) {
-          RVCX_HIP(hipEventRecord(c.ev_hub, sh));
-          RVCX_HIP(hipStreamWaitEvent(s, c.ev_hub, 0));
-        }
-        A.reset(mk2);
-      }
       const int h1 = clk.mark(s);
-      spans.push_back({h0, h1, &t_hub});
+      float* feats = fr[k & 1].feats + P.feats_off[gi];
       const float* feats0 = feats;
       if (use_index) {
         if (use_protect) {
@@ -743,9 +815,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       }
       const int h2 = clk.mark(s);
       spans.push_back({h1, h2, &t_idx});
+      ht("index", k);
       if (!joined) {   // first consumer of f0 / coarse
-        if (!f0_enqueued) after_extractor();
+        const int j0m = clk.mark(s);
         if (sf != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
+        spans.push_back({j0m, clk.mark(s), &t_wait_f0});
         joined = true;
       }
       float* phone = A.alloc<float>((size_t)G * E * T);
@@ -774,7 +848,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         }
       }
       float* wavout = A.alloc<float>((size_t)G * nsrc);
+      if (gi == 0 && sf != s && front_delay == 1) RVCX_HIP(hipEventRecord(c.ev_syn[k & 1], s));
       SynthIO io;
+      if (gi == 0 && sf != s && front_delay == 2) io.ev_decoder = c.ev_syn[k & 1];
       io.B = G;
       io.T = T;
       io.phone_ct = phone;
@@ -788,7 +864,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         syn_ev.emplace_back();
         for (auto& e : syn_ev.back()) RVCX_HIP(hipEventCreate(&e));
       }
+      ht("pre-synth", k);
       synth_forward(c, M, io, stage_ms ? syn_ev.back().data() : nullptr);
+      ht("synth", k);
       const long keep_n = (long)nsrc - 2 * g.t_pad_tgt;
       for (int q = 0; q < G; ++q) {
         const Job& j = jobs[grp[q]];
@@ -838,11 +916,16 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       io.out_n = u.out_n;
     }
     if (sf != s) RVCX_HIP(hipEventRecord(c.ev_done[k & 1], s));
+    ht("post+d2h", k);
     // ---- front end of the next micro-batch (the main stream still has this one's synthesizer queued)
     if (k + 1 < (int)mbs.size()) {
       const int h0 = clk.mark(sf);
       front(k + 1);
       spans.push_back({h0, clk.mark(sf), &t_hp});
+      ht("front", k + 1);
+      plan_jobs(k + 1);
+      enqueue_hubert(k + 1);
+      ht("hubert+f0", k + 1);
     }
   }
   const int e_end = clk.mark(s);
@@ -852,6 +935,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   if (stage_ms) {
     for (const auto& sp : spans) *sp.acc += clk.between(sp.a, sp.b);
     for (size_t k = 0; k < mbs.size(); ++k) t_f0 += clk.between(f0_ev0[k], f0_ev1[k]);
+    for (size_t k = 0; k < mbs.size(); ++k) t_hub += clk.between(hub_ev0[k], hub_ev1[k]);
     for (auto& ev : syn_ev) {
       for (int i = 0; i < 3; ++i) {
         float t = 0.f;
@@ -860,9 +944,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       }
       for (auto& e : ev) (void)hipEventDestroy(e);
     }
+    if (getenv("RVCX_HOST_TRACE"))
+      fprintf(stderr, "[wait] main stream waited %.1f ms for HuBERT / front sets and %.1f ms for F0\n", t_wait_hub, t_wait_f0);
     stage_ms[0] = t_hp;
     stage_ms[1] = t_f0;     // on the front stream, overlapped with HuBERT / the previous micro-batch's decoder
-    stage_ms[2] = t_hub;
+    stage_ms[2] = t_hub;    // on HuBERT's stream, beside the F0 model and (k >= 1) the previous micro-batch's decoder
     stage_ms[3] = t_idx;
     stage_ms[4] = t_syn[0];
     stage_ms[5] = t_syn[1];

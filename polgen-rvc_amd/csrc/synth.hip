@@ -325,6 +325,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   if (io.z_out)
     RVCX_HIP(hipMemcpyAsync(io.z_out, z, (size_t)B * inter * T * sizeof(float), hipMemcpyDeviceToDevice, s));
   tm.mark(2);
+  if (io.ev_decoder) RVCX_HIP(hipEventRecord(io.ev_decoder, s));
 
   // ================================================================ NSF-HiFi-GAN decoder
   // The decoder runs `db` utterances at a time (default ONE) even inside a batch: its activations are ~200 MB
