@@ -173,7 +173,8 @@ int rvcx_index_blend(rvcx_ctx*, float* feats_hd, int T, float index_rate, int64_
  * (n/160)*upp - 2*upp... for single-chunk clips); rvcx_convert_batch reports it in out_n */
 int64_t rvcx_out_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* VC.pipeline for a batch of utterances -- rvc/infer/pipeline.py:289-467 with
- * f0_method="rmvpe+", pitch_guidance=1, resample_sr=0, f0_file=None.
+ * f0_method = p->f0_method ("rmvpe+" or "fcpe"; that model must be loaded), pitch_guidance=1, resample_sr=0,
+ * f0_file=None.
  * wav16k[i] (n[i] samples, 16 kHz mono f32, host or device); out[i] caller-allocated int16
  * buffers of rvcx_out_len samples (host or device); out_f32[i] optional (same capacity) float
  * waveform before int16 quantisation; out_n[i] receives the number of samples produced; noise[i] optional
@@ -195,8 +196,8 @@ int rvcx_micro_batch(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* floats of parity noise rvcx_convert_batch consumes for one n-sample utterance: for each
  * chunk in order, z_noise (inter*T) then src_noise (T*upp) -- the draw order of the reference */
 int64_t rvcx_noise_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
-/* VC.get_f0 -- rvc/infer/pipeline.py:132-201 on the reflect-padded, high-passed signal:
- * returns coarse (int32) and f0 (Hz) of p_len frames for one utterance */
+/* VC.get_f0 -- rvc/infer/pipeline.py:132-201 on the reflect-padded, high-passed signal (the F0 model is chosen by
+ * p->f0_method): returns coarse (int32) and f0 (Hz) of p_len frames for one utterance */
 int rvcx_get_f0(rvcx_ctx*, const float* wav16k_hd, int64_t n, const rvcx_params* p,
                 int32_t* coarse, float* f0, int64_t* p_len);
 /* VC.get_f0(input_audio_path, x, p_len, pitch, "rmvpe+", ...) -- rvc/infer/pipeline.py:132-201 with the
