@@ -59,15 +59,16 @@ __global__ __launch_bounds__(3 * H) void bigru_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------
 constexpr int GRU_H = 256;
-constexpr int GRU_NC = 4;                 // workgroups per (direction, item)
-constexpr int GRU_U = GRU_H / GRU_NC;     // hidden units owned by a workgroup (64)
-constexpr int GRU_ROWS = 3 * GRU_U;       // gate rows owned (192)
-constexpr int GRU_THREADS = 2 * GRU_ROWS; // 384 threads, 128 weights each in registers
-constexpr int GRU_RPT = 4;                // a thread owns 4 gate rows x 32 columns: 8 broadcast LDS reads of h per step
-constexpr int GRU_CPT = 32;               // (1 row x 128 columns needed 32 and made the LDS the longest part of a step)
-constexpr int GRU_NCS = GRU_H / GRU_CPT;  // column slices (8)
-constexpr int GRU_NRG = GRU_ROWS / GRU_RPT;   // row groups (48)
-static_assert(GRU_NRG * GRU_NCS == GRU_THREADS, "thread mapping");
+// Cluster geometry <NC, CPT>: NC workgroups per (direction, item), each owning U = H/NC hidden units = 3U gate rows; a
+// thread owns RPT = 4 gate rows x CPT columns of W_hh in registers (h arrives as CPT/4 broadcast 16-byte LDS reads).
+//   <4, 32>: 192 rows x 8 column slices = 384 threads, 128 weights each   (default)
+//   <8, 16>:  96 rows x 16 column slices = 384 threads, 64 weights each   (RVCX_GRU_NC=8: half the dot-product length)
+template <int NC, int CPT>
+struct GruGeom {
+  static constexpr int U = GRU_H / NC, ROWS = 3 * U, RPT = 4, NCS = GRU_H / CPT, NRG = ROWS / RPT, THREADS = NRG * NCS;
+  static_assert(THREADS - U >= GRU_H - U, "one thread per foreign unit in the gather phase");
+};
+constexpr int GRU_NC = 4;                 // default cluster size (scratch / co-residency bounds use the maximum, 8)
 constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;   // ~seconds: a lost partner ends the kernel instead of hanging the GPU
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
@@ -94,13 +95,19 @@ union Granule {
   } s;
 };
 
-__global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float* __restrict__ gi,
+template <int NC, int CPT>
+__global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restrict__ gi,
                                                                     const float* __restrict__ whh_t,  // (2,H,3H)
                                                                     const float* __restrict__ bhh,
                                                                     float* __restrict__ y,
                                                                     unsigned long long* xbuf,  // (B,2,2,H) granules
                                                                     int* err, int T, int nq, int colocate) {
-  constexpr int H = GRU_H;
+  using G = GruGeom<NC, CPT>;
+  static_assert(G::THREADS == 384, "launch bounds");
+  constexpr int GATHER0 = (G::U + 63) / 64 * 64;     // first polling thread: the wave after the publishing lanes
+  static_assert(G::THREADS - GATHER0 >= GRU_H - G::U, "one polling thread per foreign unit");
+  constexpr int H = GRU_H, GRU_U = G::U, GRU_ROWS = G::ROWS, GRU_RPT = G::RPT, GRU_CPT = CPT, GRU_NCS = G::NCS,
+                GRU_NRG = G::NRG, GRU_THREADS = G::THREADS, GRU_NC = NC;
   __shared__ __attribute__((aligned(16))) float hs[H];
   __shared__ float part[GRU_NCS][GRU_ROWS];
   __shared__ int sfail;
@@ -199,9 +206,10 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_cluster_kernel(const float*
       __hip_atomic_store(xb + (step & 1) * H + ju, gr.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       yb[(long)ju * T + t] = hn;
       hs[ju] = hn;   // own slice: no other thread reads hs[ju] before the barrier below
-    } else if (tid < GRU_U + (H - GRU_U)) {
-      // ---- gather the other workgroups' units of h_t
-      int k = tid - GRU_U;                     // 0 .. H-U-1 over the foreign units
+    } else if (tid >= GATHER0 && tid < GATHER0 + (H - GRU_U)) {
+      // ---- gather the other workgroups' units of h_t (whole waves only: a wave that held both publishing and polling
+      // lanes could run its polling branch first and never publish -- every workgroup of the cluster would wait)
+      int k = tid - GATHER0;                   // 0 .. H-U-1 over the foreign units
       if (k >= c * GRU_U) k += GRU_U;          // skip the own slice
       Granule gr;
       unsigned spins = 0;
@@ -227,15 +235,20 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
                   void* scratch, int* err, hipStream_t stream) {
   RVCX_CHECK(H == GRU_H, "bigru: hidden size must be 256 (RMVPE)");
   // the cluster kernel needs all 2*B*NC workgroups co-resident (they spin on each other)
-  if (scratch && err && 2 * B * GRU_NC <= 128) {
+  static const int nc = getenv("RVCX_GRU_NC") ? atoi(getenv("RVCX_GRU_NC")) : GRU_NC;
+  if (scratch && err && 2 * B * nc <= 128) {
     unsigned long long* xbuf = static_cast<unsigned long long*>(scratch);
     RVCX_HIP(hipMemsetAsync(scratch, 0, bigru_scratch_bytes(B), stream));
     static int colocate = -1;
     if (colocate < 0) colocate = getenv("RVCX_GRU_COLOCATE") ? atoi(getenv("RVCX_GRU_COLOCATE")) : 1;
     const int nq = 2 * B;
-    const int grid = colocate ? 8 * GRU_NC * cdiv(nq, 8) : GRU_NC * nq;
-    hipLaunchKernelGGL(bigru_cluster_kernel, dim3(grid), dim3(GRU_THREADS), 0, stream, gi, whh_t, bhh, y, xbuf, err, T,
-                       nq, colocate);
+    const int grid = colocate ? 8 * nc * cdiv(nq, 8) : nc * nq;
+    if (nc == 8)
+      hipLaunchKernelGGL((bigru_cluster_kernel<8, 16>), dim3(grid), dim3(GruGeom<8, 16>::THREADS), 0, stream, gi, whh_t, bhh,
+                         y, xbuf, err, T, nq, colocate);
+    else
+      hipLaunchKernelGGL((bigru_cluster_kernel<4, 32>), dim3(grid), dim3(GruGeom<4, 32>::THREADS), 0, stream, gi, whh_t, bhh,
+                         y, xbuf, err, T, nq, colocate);
   } else {
     hipLaunchKernelGGL(bigru_kernel<GRU_H>, dim3(2, B), dim3(3 * GRU_H), 0, stream, gi, whh_t, bhh, y, T);
   }
