@@ -424,6 +424,9 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   // -- is then chosen for the real batch under that factor.  A batched conversion is therefore bit-identical to
   // converting its utterances one by one.
   const long cap_item = a.part_cap_item > 0 ? a.part_cap_item : a.part_cap;
+  // The 32 x 256 / 32 x 512 3x3 tiles stay selectable by override (and tested) but out of the automatic choice: measured
+  // on the U-Net level-0 shape 77 / 111 us against 40 us for 32 x 128 (tools/bench_unet_l0.py); with them C3 ran 5 % slower
+  static const bool wide3x3 = getenv("RVCX_WIDE3X3") && atoi(getenv("RVCX_WIDE3X3")) != 0;
   auto select = [&](int Bsel, int forcedS, int* tile_out, int* s_out) {
     int best = -1, S = 1;
     double best_t = 1e300;
@@ -432,6 +435,7 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
       if (g_conv_override.tile >= 100 && g_conv_override.tile - 100 != t) continue;
       if (F.lin != lin || F.stride != a.stride) continue;
       if (a.x_split && !F.kern_xs) continue;
+      if (!wide3x3 && g_conv_override.tile < 100 && F.halo == 320 && F.bn >= 256) continue;
       if (!lin && (halo > F.halo || (F.halo == 320 && halo <= 64))) continue;
       const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * Bsel;
       const double ksteps = (double)a.ksize * nchunk;
