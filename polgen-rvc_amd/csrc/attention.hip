@@ -603,7 +603,12 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
   const long blocks = (long)cdiv(T, 128) * H;
   (void)B;
   int nsplit = 1;
-  while (nsplit < 8 && blocks * nsplit < 384 && T / (nsplit * 2) >= 256) nsplit *= 2;
+  // swept in serial mode (the three knobs are for that): TextEncoder (T 3198, 2 heads) 4 splits 2.27 ms / 8 splits
+  // 2.45 / 16 splits 2.74 / 2 splits 2.83 for its six layers; HuBERT (T 1599, 12 heads) 2 and 4 splits equal
+  static const int max_split = std::min(8, getenv("RVCX_ATT_MAXSPLIT") ? atoi(getenv("RVCX_ATT_MAXSPLIT")) : 8);   // scratch: 8
+  static const int want_blocks = getenv("RVCX_ATT_BLOCKS") ? atoi(getenv("RVCX_ATT_BLOCKS")) : 200;
+  static const int min_keys = getenv("RVCX_ATT_MINKEYS") ? atoi(getenv("RVCX_ATT_MINKEYS")) : 256;
+  while (nsplit < max_split && blocks * nsplit < want_blocks && T / (nsplit * 2) >= min_keys) nsplit *= 2;
   float* opart = nullptr;
   if (nsplit > 1) {
     if (split_scratch) opart = split_scratch;
