@@ -522,7 +522,7 @@ size_t fcpe_arena_bytes(const FcpeModel& m, int B, int64_t n) {
 }
 
 void fcpe_forward(Ctx& c, const FcpeModel& m, int B, const float* audio, int64_t n, float threshold, float* f0,
-                  float* sal_out, float* mel_out, hipStream_t s) {
+                  float* sal_out, float* mel_out, hipStream_t s, const std::function<void()>* after_stack) {
   Arena& A = c.arena;
   const auto& cf = m.cfg;
   RVCX_CHECK(n > N_FFT, "fcpe: clip shorter than one analysis window");   // the reference would zero-pad instead (FCPE.py:125-129)
@@ -566,6 +566,7 @@ void fcpe_forward(Ctx& c, const FcpeModel& m, int B, const float* audio, int64_t
     a = conv1d_args(m.stack3, ln, x, B, F, F, 1, 1, 1);
     c.conv_on(a, s);
   }
+  if (after_stack) (*after_stack)();
   // ---- PCmer encoder   (FCPE.py:227-268)
   const int ntile = fcpe_tiles(F);
   const long plen = (long)Mf * (PF_D + 1);

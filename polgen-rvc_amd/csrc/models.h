@@ -92,8 +92,11 @@ std::unique_ptr<RmvpeModel> rmvpe_load(Ctx& c, const rvcx_rmvpe_cfg& cfg, const 
 size_t rmvpe_arena_bytes(const RmvpeModel& m, int B, int64_t n);
 // audio: device (B,n) f32.  f0: device (B, 1+n/160).  hidden: device (B, frames, 360) or null.
 // mel_out (optional): device (B, 128, frames) log-mel spectrogram (MelSpectrogram.forward, RMVPE.py:412-439)
+// `after_shallow` (optional) runs on the host once the mel front end and the first U-Net encoder levels (the long
+// launches) are enqueued: the pipeline enqueues HuBERT there, so that neither branch waits for the host
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
-                   float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out = nullptr);
+                   float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out = nullptr,
+                   const std::function<void()>* after_shallow = nullptr);
 
 // ------------------------------------------------------------------------------ FCPE
 struct FcpeModel {
@@ -120,7 +123,7 @@ size_t fcpe_arena_bytes(const FcpeModel& m, int B, int64_t n);
 // FCPEInfer.__call__ (FCPE.py:739-745): audio device (B,n) f32 -> f0 device (B, n/160 + 1) Hz, 0 = below `threshold`.
 // sal_out (optional): (B, frames, 360) sigmoid salience;  mel_out (optional): (B, 128, frames) log-mel
 void fcpe_forward(Ctx& c, const FcpeModel& m, int B, const float* audio, int64_t n, float threshold, float* f0,
-                  float* sal_out, float* mel_out, hipStream_t s);
+                  float* sal_out, float* mel_out, hipStream_t s, const std::function<void()>* after_stack = nullptr);
 // FCPEF0Predictor.post_process (FCPE.py:841-867) + the tail of VC.get_f0 (pipeline.py:183-201): raw Hz (B, F_in) ->
 // f0 (float32 of the float64 result) and coarse (1..255), p_len frames each, rows `out_stride` apart
 void fcpe_post_coarse(Ctx& c, const float* f0raw, int B, int F_in, int p_len, float* f0_out, int* coarse, long out_stride,

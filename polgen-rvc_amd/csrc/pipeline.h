@@ -1,5 +1,6 @@
 // VC.pipeline orchestration (rvc/infer/pipeline.py:289-467).
 #pragma once
+#include <functional>
 #include "models.h"
 
 namespace rvcx {
@@ -42,6 +43,6 @@ void check_f0_backend(const Ctx& c, const rvcx_params& p);
 size_t f0_arena_bytes(const Ctx& c, const rvcx_params& p, int B, long n_pad);
 // VC.get_f0 on device for B equal-length reflect-padded signals: coarse/f0 rows of out_stride elements
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s, int B = 1, long out_stride = 0);
+                   hipStream_t s, int B = 1, long out_stride = 0, const std::function<void()>* mid = nullptr);
 
 }  // namespace rvcx

@@ -425,17 +425,17 @@ size_t f0_arena_bytes(const Ctx& c, const rvcx_params& p, int B, long n_pad) {
 }
 
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s, int B, long out_stride) {
+                   hipStream_t s, int B, long out_stride, const std::function<void()>* mid) {
   // VC.get_f0 (pipeline.py:132-201) on already reflect-padded signals (B, n_pad); coarse / f0 rows of out_stride
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
   check_f0_backend(c, p);
   float* f0raw = c.arena.alloc<float>((size_t)B * F);
   if (p.f0_method == RVCX_F0_FCPE) {   // pipeline.py:169-181: threshold 0.03, compute_f0(x, p_len)
-    fcpe_forward(c, *c.fcpe, B, apad, n_pad, 0.03f, f0raw, nullptr, nullptr, s);
+    fcpe_forward(c, *c.fcpe, B, apad, n_pad, 0.03f, f0raw, nullptr, nullptr, s, mid);
     fcpe_post_coarse(c, f0raw, B, (int)F, (int)p_len, f0, coarse, out_stride, p.pitch, p.f0_min, p.f0_max, s);
     return p_len;
   }
-  rmvpe_forward(c, *c.rmvpe, B, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s);
+  rmvpe_forward(c, *c.rmvpe, B, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s, nullptr, mid);
   for (int b = 0; b < B; ++b)
     launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)p_len,
                      p.pitch, p.f0_min, p.f0_max, s);
@@ -632,7 +632,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
 
   // ---- F0 of one micro-batch on `sf` out of its own arena (pipeline.py:362-380: once per utterance)
   std::vector<int> f0_ev0(mbs.size(), -1), f0_ev1(mbs.size(), -1);
-  auto enqueue_f0 = [&](int k) {
+  auto enqueue_f0 = [&](int k, const std::function<void()>* mid) {
     const MB& mb = mbs[k];
     Front& f = fr[k & 1];
     const long n_pad = ios[order[mb.first]].n + 2 * g.t_pad;
@@ -640,7 +640,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     c.arena_f0.reset();
     c.arena.swap(c.arena_f0);
     try {
-      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8);
+      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8, mid);
     } catch (...) {
       c.arena.swap(c.arena_f0);
       throw;
@@ -717,20 +717,12 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   };
 
   // ---- HuBERT of one micro-batch on its own stream and out of its own arena: it depends on the micro-batch's front
-  // end only, so for k >= 1 it runs beside the synthesizer of micro-batch k-1.  One host thread feeds both branches:
-  // the F0 model's small launches are enqueued right after the first conv extractor (long kernels), otherwise HuBERT
-  // would idle while the host enqueues them.
+  // end only, so for k >= 1 it runs beside the synthesizer of micro-batch k-1.
   std::vector<int> hub_ev0(mbs.size(), -1), hub_ev1(mbs.size(), -1);
   auto enqueue_hubert = [&](int k) {
     const MB& mb = mbs[k];
     Plan& P = plans[k & 1];
     Front& f = fr[k & 1];
-    bool f0_enqueued = false;
-    const std::function<void()> after_extractor = [&]() {
-      if (f0_enqueued) return;
-      f0_enqueued = true;
-      enqueue_f0(k);
-    };
     if (sh != sf) RVCX_HIP(hipStreamWaitEvent(sh, c.ev_front[k & 1], 0));   // apad of this micro-batch is ready
     hub_ev0[k] = clk.mark(sh);
     c.arena_hub.reset();
@@ -756,7 +748,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
                                     (size_t)ns * 4, hipMemcpyDeviceToDevice, sh));
           wav = wg;
         }
-        hubert_forward(c, *c.hubert, G, wav, ns, 12, f.feats + P.feats_off[gi], sh, &after_extractor, wav_bs);
+        hubert_forward(c, *c.hubert, G, wav, ns, 12, f.feats + P.feats_off[gi], sh, nullptr, wav_bs);
         c.arena.reset(mk);
       } catch (...) {
         c.arena.swap(c.arena_hub);
@@ -766,7 +758,20 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     }
     hub_ev1[k] = clk.mark(sh);
     if (sh != s) RVCX_HIP(hipEventRecord(c.ev_hubdone[k & 1], sh));
-    if (!f0_enqueued) after_extractor();
+  };
+  // One host thread feeds both branches of the front end.  The F0 model goes first, but only as far as its long
+  // launches (mel, the shallow U-Net levels): then all of HuBERT is enqueued (its transformer launches queue up behind
+  // the conv extractor), then the rest of the F0 model's ~300 small launches.  Neither stream waits for the host:
+  // enqueued the other way round HuBERT sat idle for 2.6 ms of a single clip's 10 ms front end.
+  auto enqueue_models = [&](int k) {
+    bool hub_done = false;
+    const std::function<void()> mid = [&]() {
+      if (hub_done) return;
+      hub_done = true;
+      enqueue_hubert(k);
+    };
+    enqueue_f0(k, &mid);
+    if (!hub_done) mid();
   };
 
   static const bool host_trace = getenv("RVCX_HOST_TRACE") != nullptr;   // where does the enqueueing thread spend its time?
@@ -777,7 +782,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count());
   };
   plan_jobs(0);
-  enqueue_hubert(0);
+  enqueue_models(0);
   ht("hubert+f0", 0);
   for (int k = 0; k < (int)mbs.size(); ++k) {
     const MB& mb = mbs[k];
@@ -924,7 +929,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       spans.push_back({h0, clk.mark(sf), &t_hp});
       ht("front", k + 1);
       plan_jobs(k + 1);
-      enqueue_hubert(k + 1);
+      enqueue_models(k + 1);
       ht("hubert+f0", k + 1);
     }
   }

@@ -245,7 +245,8 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
 }  // namespace
 
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
-                   float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out) {
+                   float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out,
+                   const std::function<void()>* after_shallow) {
   Arena& A = c.arena;
   const int F = (int)(1 + n / HOP), Tp = padded_frames(F);
   const int nenc = m.cfg.en_de_layers;
@@ -321,6 +322,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
                         (long)Hs[l + 1] * Ws[l + 1], s);
     }
     x = y;
+    if (after_shallow && l == std::min(2, nenc - 1)) (*after_shallow)();
   }
   for (const auto& layer : m.inter)
     for (const auto& blk : layer) {
