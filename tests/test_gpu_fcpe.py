@@ -276,3 +276,15 @@ def test_fcpe_region_travels_with_the_weight_broadcast(ctx):
     finally:
         src.close()
         dst.close()
+
+
+def test_fcpe_rejects_clips_shorter_than_one_window(ctx):
+    """The reference zero-pads such clips (FCPE.py:125-129) -- VC.pipeline never produces them (x_pad seconds of
+    padding on both sides) -- and rvcx says so instead of computing something else."""
+    from polgen_rvc_amd import _lib, synthetic as S
+    _load(ctx, S.FCPE_CFG_TINY, 401)
+    with pytest.raises(_lib.RvcxError, match="shorter than one analysis window"):
+        ctx.fcpe_f0(np.zeros(800, np.float32), 0.03)
+    # the context stays usable after the error
+    f0 = ctx.fcpe_f0(S.make_clip(1, 1.0), 0.03)
+    assert f0.shape == (1, 101) and np.isfinite(f0).all()
