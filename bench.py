@@ -2,21 +2,31 @@
 """bench.py -- real-time factor of the rvc/infer hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+N > 1 works both ways: invoked plainly, this process -- before it touches any GPU -- starts N worker processes (one
+per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, RCCL rendezvous on 127.0.0.1), relays rank 0's JSON line and
+exits non-zero if any worker did; invoked by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+it is a worker already (WORLD_SIZE in the environment).
 
 Workload c2 (default, BASELINE.json configs[1]): one 30 s 16 kHz mono clip per step per GPU, RVC v2 48 kHz voice
 model, rmvpe+ F0, contentvec-shaped HuBERT-base, index_rate 0, fp32, chunk geometry (1,6,38,41);
 synthetic clip + synthetic weights in the real checkpoint layouts (no real weights exist offline).
 Workload c3 (--workload c3, BASELINE.json configs[2]): a batch of 64 x 30 s clips per step, index_rate 0.75 with
-a 65 536 x 768 retrieval matrix resident in HBM.
+a 65 536 x 768 retrieval matrix resident in HBM.  The default (c2, N = 1) run also carries a "c3" object measured by
+a child process of the same run, like "exact_fp32".
+Workload c5 (--workload c5, BASELINE.json configs[4]): 256 utterances of U(3, 15) s per step for the whole job, a
+40 k and a 48 k voice model resident beside one HuBERT and one RMVPE; the utterances are sharded over the ranks by
+length (dist.shard), odd ones go to the 48 k model, even ones to the 40 k model.
 A step = VC.pipeline on the step's clip(s) as SURVEY.md 8(d) defines the metric: H2D of the float PCM (pinned
 host memory), every kernel, D2H of the int16 PCM -- all inside the timed region.
-Weak scaling: every rank converts its own clip(s) per step; value = all ranks' audio seconds / max-rank wall
-(whole-job aggregate, as the driver contract asks; value_per_gpu = value / n_gpus).
+Weak scaling (c2 / c3): every rank converts its own clip(s) per step; value = all ranks' audio seconds / max-rank wall
+(whole-job aggregate, as the driver contract asks; value_per_gpu = value / n_gpus).  c5 is strong scaling.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,10 +47,12 @@ PEAK_H3_TFLOPS = PEAK_F16_TFLOPS / 3.0
 CLIP_SECONDS = 30.0
 C3_BATCH = 64
 C3_INDEX_ROWS = 65536
+C5_UTTERANCES = 256
 CPU_SAMPLE_SECONDS = 8.0
+PMC_FILES = ("pmc_traffic_r03.json", "pmc_traffic_r02.json")     # newest first
 
 
-def load_models(ctx, zero=False, fcpe=False):
+def load_models(ctx, zero=False, fcpe=False, also_40k=False):
     def z(state):
         return {k: np.zeros_like(v) for k, v in state.items()} if zero else state
     ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0)))
@@ -49,7 +61,11 @@ def load_models(ctx, zero=False, fcpe=False):
         ctx.load_fcpe(W.fcpe_cfg_struct(W.fcpe_cfg_from_state(sd)), z(sd))
     else:
         ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, 0)))
-    return ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, 0)))
+    mid48 = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, 0)))
+    if not also_40k:
+        return mid48
+    mid40 = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_40K, 768), z(S.synth_state(S.SYNTH_CFG_40K, 1)))
+    return mid48, mid40
 
 
 def make_params(seed=0, fcpe=False):
@@ -61,6 +77,12 @@ def make_params(seed=0, fcpe=False):
     p.x_pad, p.x_query, p.x_center, p.x_max = 1, 6, 38, 41
     p.seed = seed
     return p
+
+
+def c5_lengths():
+    """BASELINE configs[4]'s stand-in for TTS utterances: 256 lengths U(3, 15) s, whole 10 ms frames."""
+    g = np.random.Generator(np.random.PCG64(5))
+    return [int(round(s * 100)) * 160 for s in g.uniform(3.0, 15.0, C5_UTTERANCES)]
 
 
 def cpu_baseline():
@@ -84,11 +106,13 @@ def pmc_traffic(tile_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE are separate profiler runs of this same command; bench.py cannot collect them itself)."""
     import re
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
-    if not os.path.exists(path):
+    path = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES
+                 if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    if path is None:
         return None, None
     kernels = json.load(open(path))["kernels"]
-    src = "profiles/pmc_traffic_r02.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, RVCX_SERIAL=1)"
+    rel = "profiles/" + os.path.basename(path)
+    src = f"{rel} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, RVCX_SERIAL=1)"
     mp = re.match(r"resblock_pair<C=(\d+),N1=(\d+)>", tile_name)
     if mp:
         want = f"resblock_pair_kernel<{mp.group(1)},"
@@ -106,8 +130,17 @@ def pmc_traffic(tile_name):
             mh.group(3), f", {mh.group(4)}, 1, false, false>")
         for k, v in kernels.items():
             if want in k and tail in k:
-                return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r02.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                return v["hbm_bytes_per_launch"], src
         return None, None
+    mg = re.match(r"gemm_h3<(\d+),(\d+)>", tile_name)
+    if mg:
+        want = f"gemm_h3_kernel<{mg.group(1)}, {mg.group(2)},"
+        tot_b, tot_n = 0.0, 0
+        for k, v in kernels.items():
+            if want in k:
+                tot_b += v["hbm_bytes_per_launch"] * v["launches"]
+                tot_n += v["launches"]
+        return (tot_b / tot_n, src) if tot_n else (None, None)
     m = re.match(r"conv_fast_(sb|db)<(\d+),(\d+),(halo(\d+)|linear|stride2)>", tile_name)
     if not m:
         return None, None
@@ -118,27 +151,116 @@ def pmc_traffic(tile_name):
         tail += ", 1>"   # trailing STRIDE template argument of conv_fast_sb_kernel
     for k, v in kernels.items():
         if want in k and tail in k:
-            return v["hbm_bytes_per_launch"], "profiles/pmc_traffic_r02.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            return v["hbm_bytes_per_launch"], src
     return None, None
 
 
-def exact_fp32_child(steps, warmup):
-    """The same workload with every product on the exact-fp32 MFMA (RVCX_H3=0 RVCX_ATT_H3=0) in a FRESH child
-    process, started before this process touches the GPU and run to completion (never an exec of a GPU-initialised
-    process, never two benches sharing the device)."""
-    import subprocess
-    env = dict(os.environ, RVCX_H3="0", RVCX_ATT_H3="0")
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
-           "--no-cpu-baseline", "--no-exact-fp32", "--no-roofline"]
+def child_bench(extra_args, env_extra, label):
+    """One more bench of this run in a FRESH child process, started before this process touches the GPU and run to
+    completion (never an exec of a GPU-initialised process, never two benches sharing the device)."""
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args + ["--no-cpu-baseline", "--no-children", "--no-roofline"]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-                "warmup": d["warmup"], "dtype": "f32 (v_mfma_f32_32x32x2_f32 products, exact fp32)",
-                "env": "RVCX_H3=0 RVCX_ATT_H3=0", "how": "child process of this bench run, same workload"}
+        out = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+               "warmup": d["warmup"], "how": "child process of this bench run (started before the parent touched the GPU)"}
+        out.update(label)
+        return out, d
     except Exception as e:  # noqa: BLE001
-        return {"error": f"{type(e).__name__}: {e}"}
+        return {"error": f"{type(e).__name__}: {e}"}, None
+
+
+def exact_fp32_child(steps, warmup):
+    """The same workload with every product on the exact-fp32 MFMA (RVCX_H3=0 RVCX_ATT_H3=0)."""
+    out, _ = child_bench(["--steps", str(steps), "--warmup", str(warmup)], {"RVCX_H3": "0", "RVCX_ATT_H3": "0"},
+                         {"dtype": "f32 (v_mfma_f32_32x32x2_f32 products, exact fp32)", "env": "RVCX_H3=0 RVCX_ATT_H3=0",
+                          "workload": "c2"})
+    return out
+
+
+def c3_child():
+    """BASELINE configs[2] at its stated size: 64 x 30 s per step, index_rate 0.75 over 65 536 x 768."""
+    out, d = child_bench(["--workload", "c3", "--steps", "3", "--warmup", "1"], {},
+                         {"workload": "c3: batch of 64 x 30 s clips per step, index_rate 0.75, 65 536 x 768 index resident"})
+    if d is not None:
+        out["clips_per_step"] = d["config"]["clips_per_step"]
+        out["micro_batch"] = d["config"]["micro_batch"]
+        out["ms_per_clip"] = d["ms_per_step"] / d["config"]["clips_per_step"]
+        out["stage_ms_note"] = d.get("stage_ms_note")
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(n, argv):
+    """`python bench.py --gpus N` invoked plainly: start N worker processes of this same command (one per GPU) BEFORE
+    this process makes any GPU call, wait for all of them, relay rank 0's JSON line.  Returns the exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   RVCX_BENCH_WORKER="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):   # a rank died: the others would wait in a collective forever
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                           # exactly the processes started above, by handle
+        time.sleep(0.05)
+    reader.join(10)
+    codes = [p.returncode for p in procs]
+    out0 = buf[0] if buf else ""
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1])
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad or not lines:
+        print(f"bench.py: workers failed (rank, exit code): {bad}" if bad else "bench.py: rank 0 printed no result",
+              file=sys.stderr)
+        return next((c for _, c in bad), 1) or 1
+    return 0
+
+
+def dry_run(a, rank, world):
+    """The multi-process plumbing without a GPU (tests/test_dist_gloo.py drives it through the launcher): gloo
+    rendezvous, the c5 shard, barrier + max-over-ranks timing, rank 0's JSON line, a failing rank's exit code."""
+    D.init("gloo")
+    lengths = c5_lengths()
+    mine = D.shard(len(lengths), rank, world, lengths)
+    if a.dry_run_fail_rank == rank:
+        raise SystemExit(3)
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.001 * len(mine))
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    counts = torch.zeros(world, dtype=torch.int64)
+    counts[rank] = len(mine)
+    secs = torch.zeros(world, dtype=torch.float64)
+    secs[rank] = sum(lengths[i] for i in mine) / 16000.0
+    if world > 1:
+        torch.distributed.all_reduce(counts)
+        torch.distributed.all_reduce(secs)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps or 1, "utterances_per_rank": counts.tolist(),
+                          "audio_seconds_per_rank": secs.tolist(), "value": float(secs.sum()) / dt, "workload": "c5"}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main():
@@ -146,33 +268,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2")
     ap.add_argument("--batch", type=int, default=None, help="clips per step (c3 default 64, c2 default 1)")
     ap.add_argument("--f0-method", choices=["rmvpe+", "fcpe"], default="rmvpe+",
                     help="F0 back-end of VC.get_f0; BASELINE's metric is quoted on rmvpe+ (fcpe: secondary line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-fp32", action="store_true")
+    ap.add_argument("--no-children", "--no-exact-fp32", dest="no_children", action="store_true",
+                    help="skip the exact_fp32 and c3 child benches of the default run")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default="")
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing run (gloo): launcher, shard, timing")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1)
     a = ap.parse_args()
-    c3 = a.workload == "c3"
+    c3, c5 = a.workload == "c3", a.workload == "c5"
     fcpe = a.f0_method == "fcpe"
     B = a.batch or (C3_BATCH if c3 else 1)
     if a.steps is None:
-        a.steps = 3 if c3 else 10
+        a.steps = 3 if (c3 or c5) else 10
 
     rank, local, world = D.env_rank()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit(f"--gpus {a.gpus} needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
-                         f"--nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
     # torch.cuda.device_count() does not initialise the GPU on this image
-    if torch.cuda.device_count() < max(a.gpus, local + 1):
+    if not a.dry_run and torch.cuda.device_count() < max(a.gpus, local + 1):
         raise SystemExit(f"--gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
-    fp32 = None
-    if world == 1 and not a.no_exact_fp32 and not c3 and not fcpe:
-        fp32 = exact_fp32_child(a.steps, a.warmup)       # before the first GPU call of this process
+    if a.gpus > 1 and world == 1:
+        # plain invocation: become the launcher -- no GPU call has been made by this process
+        raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
+    if a.dry_run:
+        return dry_run(a, rank, world)
+    fp32 = c3_obj = None
+    if world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe:
+        fp32 = exact_fp32_child(a.steps, a.warmup)       # both before the first GPU call of this process
+        c3_obj = c3_child()
     rank, local, world = D.init("nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -180,7 +308,8 @@ def main():
 
     # rank 0 parses/folds/packs the checkpoints; the folded weight regions go to the other GPUs over RCCL/xGMI
     t0 = time.perf_counter()
-    mid = load_models(ctx, zero=(rank != 0), fcpe=fcpe)
+    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5)
+    mid = mids[0] if c5 else mids
     if c3:
         big = S.make_index(C3_INDEX_ROWS, 768, 0)
         ctx.load_index(np.zeros_like(big) if rank != 0 else big)
@@ -193,16 +322,32 @@ def main():
     if c3:
         params.index_rate = 0.75
     # pinned host buffers: the step's H2D / D2H copies are asynchronous DMA inside the timed region
-    clips = [S.make_clip(rank * B + i, CLIP_SECONDS) for i in range(B)]
-    n = clips[0].shape[0]
+    if c5:
+        lengths = c5_lengths()
+        mine = D.shard(len(lengths), rank, world, lengths)
+        clips = [S.make_clip(5000 + i, lengths[i] / 16000.0) for i in mine]
+        model_of = [mids[1] if i % 2 == 0 else mids[0] for i in mine]       # even -> 40 k, odd -> 48 k
+        audio_seconds_per_step = sum(lengths) / 16000.0                     # the whole job's, all ranks
+    else:
+        clips = [S.make_clip(rank * B + i, CLIP_SECONDS) for i in range(B)]
+        model_of = [mid] * B
+        audio_seconds_per_step = world * B * CLIP_SECONDS
     wavs = [torch.from_numpy(c).pin_memory() for c in clips]
-    cap = ctx.out_capacity(mid, n, params)
-    outs = [torch.empty(cap, dtype=torch.int16).pin_memory() for _ in range(B)]
-    wp, op, ns = [w.data_ptr() for w in wavs], [o.data_ptr() for o in outs], [n] * B
+    outs = [torch.empty(ctx.out_capacity(m, c.shape[0], params), dtype=torch.int16).pin_memory()
+            for c, m in zip(clips, model_of)]
+    calls = []                                            # one convert_batch call per resident voice model
+    for m in sorted(set(model_of)):
+        sel = [i for i, mm in enumerate(model_of) if mm == m]
+        calls.append((m, [wavs[i].data_ptr() for i in sel], [clips[i].shape[0] for i in sel],
+                      [outs[i].data_ptr() for i in sel]))
+    n = clips[0].shape[0]
     torch.cuda.synchronize()
 
     def step():
-        return ctx.convert_batch_raw(mid, wp, ns, params, op)[0]
+        got = []
+        for m, wp, ns, op in calls:
+            got += ctx.convert_batch_raw(m, wp, ns, params, op)
+        return got
 
     for _ in range(a.warmup):
         step()
@@ -215,15 +360,15 @@ def main():
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = dt / a.steps * 1e3
-    rtf = world * a.steps * B * CLIP_SECONDS / dt
+    rtf = a.steps * audio_seconds_per_step / dt
     stage = ctx.last_timing()
 
     # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv): one extra, untimed step in SERIAL mode
     # (every launch on the library's one stream, so a launch's duration is its own) with a HIP event pair around
     # every conv launch.  `rocprofv3 --kernel-trace --stats` of `RVCX_SERIAL=1 python bench.py ...` gives the same
-    # per-kernel averages (profiles/rocprof_r02_*).
+    # per-kernel averages (profiles/rocprof_r03_*).
     roofline, prof = None, None
-    if not a.no_roofline:
+    if not a.no_roofline and not c5:
         ctx.flop_counter(reset=True)
         ctx.conv_profile_begin()
         step()
@@ -238,7 +383,7 @@ def main():
         conv_flops = sum(r["flops"] for r in prof)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dom["tile"])
-        h3 = dom["tile"].startswith("conv_h3") or dom["tile"].startswith("resblock_pair")
+        h3 = dom["tile"].startswith(("conv_h3", "resblock_pair", "gemm_h3"))
         peak = PEAK_H3_TFLOPS if h3 else PEAK_F32_TFLOPS
         roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -254,27 +399,41 @@ def main():
                     "whole_path_tflops": total_flops / (ms_per_step * 1e-3) / 1e12}
 
     if rank == 0:
-        wl = (f"batch of {B} x 30 s 16 kHz clips per GPU per step, RVC v2 48k, f0_method=rmvpe+, HuBERT-base, "
-              f"index_rate=0.75 over a resident {C3_INDEX_ROWS} x 768 index, geometry (1,6,38,41)" if c3 else
-              ("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
-              ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
+        if c5:
+            wl = (f"{C5_UTTERANCES} utterances of U(3,15) s per step for the whole job ({len(clips)} on this rank, sharded by "
+                  "length), a 40 k and a 48 k RVC v2 voice model resident beside one HuBERT-base and one RMVPE, "
+                  "f0_method=rmvpe+, index_rate=0, geometry (1,6,38,41)")
+        elif c3:
+            wl = (f"batch of {B} x 30 s 16 kHz clips per GPU per step, RVC v2 48k, f0_method=rmvpe+, HuBERT-base, "
+                  f"index_rate=0.75 over a resident {C3_INDEX_ROWS} x 768 index, geometry (1,6,38,41)")
+        else:
+            wl = (("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
+                  ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
         if fcpe:
             wl = wl.replace("f0_method=rmvpe+", "f0_method=fcpe (secondary line: BASELINE's metric is quoted on rmvpe+)")
+        multi = len(clips) > 1
         res = {"metric": "real-time-factor (audio-sec/wall-sec) per GPU, 30s@16kHz RMVPE->48kHz",
                "value": rtf, "unit": "x real-time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if c5 else "weak",
+               "vs_baseline": None,
                "dtype": ("f32 (conv products as 3 fp16 MFMAs of a hi/lo split, fp32 accumulate; fp32 elsewhere)"
                          if os.environ.get("RVCX_H3", "1") != "0" else "f32 (exact fp32 MFMA products)"),
                "data": "synthetic",
                "value_per_gpu": rtf / world,
                "value_is": "whole-job aggregate over n_gpus (driver contract); value_per_gpu = value / n_gpus",
                "config": {"workload": wl + "; timed region = H2D of float PCM (pinned host) + all kernels + D2H of int16",
-                          "clips_per_step": B, "micro_batch": ctx.micro_batch(mid, n, params),
-                          "out_samples": got, "weights_bcast_bytes": nbytes, "weights_bcast_s": t_bcast,
-                          "load_s": t_load},
-               "stage_ms": stage, "roofline": roofline, "conv_tiles": prof}
+                          "clips_per_step": len(clips), "micro_batch": ctx.micro_batch(mid, n, params),
+                          "out_samples": got[0] if len(got) == 1 else sum(got), "weights_bcast_bytes": nbytes,
+                          "weights_bcast_s": t_bcast, "load_s": t_load},
+               "stage_ms": stage,
+               "stage_ms_note": ("sums over the call's micro-batches of each stage's own span on its own stream; the "
+                                 "streams overlap, so the stages do not add up to `total`" if multi else
+                                 "single clip: rmvpe and hubert run side by side, the rest in sequence"),
+               "roofline": roofline, "conv_tiles": prof}
         if fp32 is not None:
             res["exact_fp32"] = fp32
+        if c3_obj is not None:
+            res["c3"] = c3_obj
         if not a.no_cpu_baseline and world == 1 and not fcpe:
             res["cpu_baseline"] = cpu_baseline()
         else:

@@ -573,6 +573,12 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   }
   const size_t work_mark = A.mark();
 
+  float t_hp = 0, t_f0 = 0, t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0}, t_post = 0, t_wait_hub = 0, t_wait_f0 = 0;
+  struct Span {
+    int a, b;
+    float* acc;
+  };
+  std::vector<Span> spans;
   // RVCX_FRONT_DELAY (experiments): 0 (default) = the next micro-batch's front end starts as soon as its buffers are
   // free, 1 = when the main stream reaches this micro-batch's synthesizer, 2 = when it reaches the NSF decoder.
   // Measured on C3 (64 x 30 s): 1036 / 1030 / 1031 x -- at B = 8 HuBERT and the F0 model are throughput-bound like the
@@ -587,6 +593,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     const int Bm = mb.count;
     if (sf != s && k >= 2) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_done[k & 1], 0));   // set k&1 was micro-batch k-2's
     if (sf != s && k >= 1 && front_delay) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_syn[(k - 1) & 1], 0));
+    const int h0 = clk.mark(sf);        // behind the waits: the span is the front end's own work, not its queueing
     const bool f64 = ios[order[mb.first]].wav64 != nullptr;
     for (int b = 0; b < Bm; ++b) {
       const UttIO& io = ios[order[mb.first + b]];
@@ -617,6 +624,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     }
     launch_reflect_pad(f.a32, f.apad, Bm, (int)n, (int)g.t_pad, n_pad, sf);
     if (sf != s) RVCX_HIP(hipEventRecord(c.ev_front[k & 1], sf));
+    spans.push_back({h0, clk.mark(sf), &t_hp});
     if (ncut > 0) RVCX_HIP(hipStreamSynchronize(sf));
     const long stride = n_pad / 160 + 8;
     for (int b = 0; b < Bm; ++b) {
@@ -651,19 +659,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   };
 
   const int e_begin = clk.mark(s);
-  float t_hp = 0, t_f0 = 0, t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0}, t_post = 0, t_wait_hub = 0, t_wait_f0 = 0;
-  struct Span {
-    int a, b;
-    float* acc;
-  };
-  std::vector<Span> spans;
   std::vector<std::array<hipEvent_t, 4>> syn_ev;   // synth_forward's own stage events (resolved after the final sync)
 
-  {
-    const int h0 = clk.mark(sf);
-    front(0);
-    spans.push_back({h0, clk.mark(sf), &t_hp});
-  }
+  front(0);
   const bool use_protect = p.protect < 0.5f;
   const bool use_index = c.index && p.index_rate != 0.f;
   hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;   // HuBERT's stream
@@ -924,9 +922,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     ht("post+d2h", k);
     // ---- front end of the next micro-batch (the main stream still has this one's synthesizer queued)
     if (k + 1 < (int)mbs.size()) {
-      const int h0 = clk.mark(sf);
       front(k + 1);
-      spans.push_back({h0, clk.mark(sf), &t_hp});
       ht("front", k + 1);
       plan_jobs(k + 1);
       enqueue_models(k + 1);

@@ -123,3 +123,40 @@ def test_broadcast_weights_layout_mismatch_fails_on_every_rank():
     res = _run_bcast(2, mismatch=True)
     assert [r[1] for r in res] == ["raised", "raised"]
     assert all(r[4] == 0 for r in res)
+
+
+def _bench(*args, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=timeout, env=env)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` invoked plainly (the shape of the driver's N = 1 command, VERDICT r2 missing#6): the
+    parent starts one worker per rank before touching any GPU, the workers rendezvous (gloo in this CPU dry run, RCCL
+    on a GPU node), shard BASELINE configs[4]'s 256 utterances by length without overlap, and the parent relays
+    exactly ONE JSON line -- rank 0's."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run", "--workload", "c5")
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True
+    assert d["utterances_per_rank"] == [128, 128]                       # +-0 items per rank
+    a, b = d["audio_seconds_per_rank"]
+    assert abs(a - b) / (a + b) < 0.02                                  # length-sorted round-robin balances audio
+    assert abs(a + b - 256 * 9.0) < 256 * 1.0                           # U(3, 15) s
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    r = _bench("--gpus", "2", "--dry-run", "--dry-run-fail-rank", "1")
+    assert r.returncode != 0
+    assert "workers failed" in r.stderr
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    r = _bench("--gpus", "3")                    # no GPU in the CPU container / one on the test box
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)

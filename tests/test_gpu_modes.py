@@ -1,0 +1,46 @@
+"""The non-default arithmetic modes, end to end against the REFERENCE goldens.
+
+The library chooses its kernels from environment variables read once per process, so each mode runs the golden tests of
+tests/test_gpu_pipeline.py in a fresh child process (started as a child, never an exec of this GPU-initialised one):
+
+  RVCX_H3=0 RVCX_ATT_H3=0   every product on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the mode bench.py reports
+                            as `exact_fp32`, and the mode an fp16-range overflow falls back to
+  RVCX_FUSE=0               the NSF ResBlock steps as two conv launches instead of the fused kernel
+  RVCX_GEMM=0               Linear layers on the channel-first conv tiles instead of the time-major GEMM kernel
+
+Each child runs: the multi-chunk tiny golden, the CI-argument tiny golden, C2 at full size (30 s, 48 k) and the
+float-waveform-vs-oracle test -- the same assertions as the default mode (float <= 1e-4 RMS, PCM <= 8 LSB)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+SELECT = "tiny_chunked or tiny_ciargs or c2_30s_48k or float_waveform_vs_oracle"
+
+
+def _run_mode(env_extra):
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(HERE, "test_gpu_pipeline.py"), "-k", SELECT, "-s"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(HERE))
+    tail = (r.stdout[-3000:] + "\n" + r.stderr[-2000:])
+    print(tail)
+    assert r.returncode == 0, tail
+    assert "4 passed" in r.stdout, tail
+    return r.stdout
+
+
+def test_exact_fp32_mode_passes_the_reference_goldens():
+    out = _run_mode({"RVCX_H3": "0", "RVCX_ATT_H3": "0"})
+    assert "float rms err" in out
+
+
+def test_unfused_resblock_mode_passes_the_reference_goldens():
+    _run_mode({"RVCX_FUSE": "0"})
+
+
+def test_channel_first_linear_mode_passes_the_reference_goldens():
+    _run_mode({"RVCX_GEMM": "0"})
