@@ -81,6 +81,16 @@ typedef struct {
 } rvcx_params;
 enum { RVCX_F0_RMVPE = 0, RVCX_F0_FCPE = 1 };
 
+/* per-utterance extras of rvcx_convert_batch_ex */
+typedef struct {
+  /* VC.pipeline's f0_file (rvc/infer/pipeline.py:349-360): the parsed rows "time [s], f0 [Hz]" as float32 pairs in HOST
+   * memory, or NULL.  VC.get_f0 turns them into a 100 Hz track with np.interp and overwrites the estimate from frame
+   * x_pad * 100 on (pipeline.py:185-191); the library does exactly that (float32 / float64 steps as numpy takes them). */
+  const float* inp_f0;
+  int32_t inp_f0_rows;
+  int32_t reserved;
+} rvcx_utt_extra;
+
 /* ---- lifecycle ------------------------------------------------------------------------ */
 int rvcx_create(int device, rvcx_ctx** out);
 void rvcx_destroy(rvcx_ctx* ctx);
@@ -191,6 +201,10 @@ int rvcx_convert_batch(rvcx_ctx*, int model_id, int B, const float* const* wav16
 int rvcx_convert_batch_f64(rvcx_ctx*, int model_id, int B, const double* const* wav16k_hd,
                            const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
                            int16_t* const* out_hd, float* const* out_f32_hd, int64_t* out_n);
+/* the same with per-utterance extras (`extra`: B entries or NULL); wav16k_hd[i] is float64 when wav_is_f64 != 0 */
+int rvcx_convert_batch_ex(rvcx_ctx*, int model_id, int B, const void* const* wav16k_hd, int wav_is_f64,
+                          const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
+                          const rvcx_utt_extra* extra, int16_t* const* out_hd, float* const* out_f32_hd, int64_t* out_n);
 /* utterances of n samples converted per launch sequence (memory-bounded; RVCX_MAX_BATCH, RVCX_ARENA_GB) */
 int rvcx_micro_batch(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* floats of parity noise rvcx_convert_batch consumes for one n-sample utterance: for each
@@ -204,6 +218,14 @@ int rvcx_get_f0(rvcx_ctx*, const float* wav16k_hd, int64_t n, const rvcx_params*
  * reference's meaning of x: the ALREADY reflect-padded, high-passed signal (n samples).  Writes 1 + n/160 frames
  * of coarse (1..255) and f0 (Hz, shifted by p->pitch semitones), un-truncated like the reference's return. */
 int rvcx_get_f0_x(rvcx_ctx*, const float* x_hd, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0);
+/* VC.get_f0 with everything the reference's does (pipeline.py:132-201): the F0 model p->f0_method names on the padded
+ * signal x, pitch shift, the optional f0-file table inp_f0 (rows of (time, f0) float32 pairs in host memory, see
+ * rvcx_utt_extra), coarse quantisation.  rmvpe+ returns 1 + n/160 frames, fcpe p_len frames (*frames). */
+int rvcx_get_f0_x_ex(rvcx_ctx*, const float* x_hd, int64_t n, int64_t p_len, const rvcx_params* p, const float* inp_f0,
+                     int inp_f0_rows, int32_t* coarse, float* f0, int64_t* frames);
+/* host only (no GPU needed): the 100 Hz track VC.get_f0 builds from an f0 file's rows (pipeline.py:186-189: delta_t in
+ * float32, np.interp in float64).  Writes min(count, cap) values, returns count. */
+int rvcx_f0_file_track(const float* inp_f0, int rows, double* track, int cap);
 /* VC.vc(model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version="v2", protect) --
  * rvc/infer/pipeline.py:203-287: HuBERT -> (retrieval blend with the resident index when index_rate != 0) ->
  * x2 upsample / protect mix -> Synthesizer.infer.  audio0 (n samples of audio_pad); pitch / pitchf (n_pitch
@@ -229,10 +251,18 @@ int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, do
 const char* rvcx_conv_profile_csv(rvcx_ctx*);
 /* free / total bytes of the context's GPU (hipMemGetInfo): what is left for further voice models and indices */
 int rvcx_mem_info(rvcx_ctx*, int64_t* free_bytes, int64_t* total_bytes);
-/* calls this context repeated on the exact-fp32 kernels because a split-fp16 kernel met an activation beyond
+/* calls this context repeated because a split-fp16 kernel met an activation beyond
  * fp16 range (|x| >= 6e4; attention K / V >= 234): the default kernels form fp32-grade products from fp16 hi/lo
  * halves, which have fp16's exponent range.  The repeat is automatic and transparent; this counter reports it. */
 int64_t rvcx_fp32_reruns(rvcx_ctx*);
+/* layers (and attention calls) pinned to the exact-fp32 kernels since their models were loaded: a split-fp16 kernel that
+ * meets an activation beyond fp16 range stamps its layer; the entry point pins the first offender of the call (launch
+ * order) for the life of the model and repeats the call once -- later requests pay nothing. */
+int64_t rvcx_fp32_layers(rvcx_ctx*);
+/* calls repeated with the single-workgroup BiGRU kernel because the cluster kernel's workgroups were not co-resident */
+int64_t rvcx_gru_fallbacks(rvcx_ctx*);
+/* test hook: what = 1 makes the next call behave as if the BiGRU cluster kernel had timed out */
+int rvcx_debug_inject(rvcx_ctx*, int what);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */
 double rvcx_flop_counter(rvcx_ctx*, int reset);
 void* rvcx_stream(rvcx_ctx*); /* hipStream_t the library launches on */

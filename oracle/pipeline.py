@@ -61,11 +61,18 @@ def chunk_points(audio: np.ndarray, geo: Geometry):
     return opt_ts
 
 
-def f0_to_coarse(f0: np.ndarray, pitch: float, f0_min=50, f0_max=1100):
-    """pipeline.py:148-150,183,193-201 (inp_f0 is None on this path).  Returns (coarse int, f0 Hz)."""
+def f0_to_coarse(f0: np.ndarray, pitch: float, f0_min=50, f0_max=1100, inp_f0=None, x_pad: int = 1):
+    """pipeline.py:148-150,183-201.  ``inp_f0``: the (rows, 2) float32 table VC.pipeline parses from an f0 file
+    (pipeline.py:349-360), applied exactly as pipeline.py:185-191 does.  Returns (coarse int, f0 Hz)."""
     f0_mel_min = 1127 * np.log(1 + f0_min / 700)
     f0_mel_max = 1127 * np.log(1 + f0_max / 700)
     f0 = f0 * pow(2, pitch / 12)
+    tf0 = SR // WINDOW
+    if inp_f0 is not None:
+        delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
+        replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
+        shape = f0[x_pad * tf0: x_pad * tf0 + len(replace_f0)].shape[0]
+        f0[x_pad * tf0: x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
     f0bak = f0.copy()
     f0_mel = 1127 * np.log(1 + f0 / 700)
     f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - f0_mel_min) * 254 / (f0_mel_max - f0_mel_min) + 1
@@ -223,7 +230,7 @@ def hubert_frames(n: int, cfg) -> int:
 def pipeline(models: Models, geo: Geometry, audio: np.ndarray, pitch: float = 0, sid: int = 0,
              big_npy=None, index_rate: float = 0.0, volume_envelope: float = 1.0,
              protect: float = 0.33, f0_min=50, f0_max=1100, noises=None, seed: int = 0,
-             return_parts=False, f0_method: str = "rmvpe+"):
+             return_parts=False, f0_method: str = "rmvpe+", inp_f0=None):
     """VC.pipeline (pipeline.py:289-467) with f0_method="rmvpe+" or "fcpe" (models.fcpe_sd), pitch_guidance=1,
     resample_sr=0, f0_file=None.  ``noises`` = list of (z_noise, src_noise) per chunk; drawn from
     torch.manual_seed(seed) in the reference's order (z first, then source) if None."""
@@ -235,7 +242,7 @@ def pipeline(models: Models, geo: Geometry, audio: np.ndarray, pitch: float = 0,
         f0 = O_fcpe.compute_f0(models.fcpe_sd, audio_pad.astype(np.float32), p_len, 0.03)
     else:
         f0 = O_rmvpe.infer_f0(models.rmvpe_sd, models.rmvpe_cfg, audio_pad, 0.03, f0_min, f0_max)
-    coarse, f0bak = f0_to_coarse(f0, pitch, f0_min, f0_max)
+    coarse, f0bak = f0_to_coarse(f0, pitch, f0_min, f0_max, inp_f0, geo.t_pad // SR)
     coarse, f0bak = coarse[:p_len], f0bak[:p_len]
     plan = chunk_plan(audio.shape[0], opt_ts, geo)
     if noises is None:

@@ -61,6 +61,10 @@ class Params(C.Structure):
                 ("f0_method", C.c_int32), ("reserved", C.c_int32)]
 
 
+class UttExtra(C.Structure):
+    _fields_ = [("inp_f0", C.POINTER(C.c_float)), ("inp_f0_rows", C.c_int32), ("reserved", C.c_int32)]
+
+
 F0_RMVPE, F0_FCPE = 0, 1        # rvcx_params.f0_method
 
 
@@ -76,7 +80,8 @@ SYMBOLS = [
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
-    "rvcx_op_bigru", "rvcx_op_highpass",
+    "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
+    "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track",
 ]
 
 
@@ -94,8 +99,21 @@ def lib() -> C.CDLL:
         _lib.rvcx_conv_profile_csv.restype = C.c_char_p
         _lib.rvcx_out_len.restype = C.c_int64
         _lib.rvcx_fp32_reruns.restype = C.c_int64
+        _lib.rvcx_fp32_layers.restype = C.c_int64
+        _lib.rvcx_gru_fallbacks.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
     return _lib
+
+
+def f0_file_track(inp_f0) -> np.ndarray:
+    """host-side piece of VC.get_f0's f0-file branch as the library computes it (no GPU needed)"""
+    tab = np.ascontiguousarray(inp_f0, dtype=np.float32).reshape(-1, 2)
+    out = np.empty(65536, np.float64)
+    n = lib().rvcx_f0_file_track(tab.ctypes.data_as(C.POINTER(C.c_float)), tab.shape[0],
+                                 out.ctypes.data_as(C.POINTER(C.c_double)), out.shape[0])
+    if n < 0:
+        raise RvcxError("f0_file_track: " + (lib().rvcx_last_error(None) or b"").decode())
+    return out[:n].copy()
 
 
 def _p(a: Optional[np.ndarray], ctype=C.c_float):
@@ -142,6 +160,8 @@ def make_table(state: dict):
 
 class Context:
     """One rvcx context (= one GPU)."""
+
+    regions_on_device = True       # weights_regions() returns device pointers (dist.broadcast_weights checks this)
 
     def __init__(self, device: int = 0):
         self._h = C.c_void_p()
@@ -446,7 +466,7 @@ class Context:
     def noise_capacity(self, model_id, n, params) -> int:
         return int(lib().rvcx_noise_len(self._h, model_id, C.c_int64(n), C.byref(params)))
 
-    def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False):
+    def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False, inp_f0=None):
         """VC.pipeline for a list of 16 kHz mono clips -> list of int16 arrays (and the pre-quantisation
         float waveforms when want_f32).  float64 clips (what the reference's load_audio returns) cross the
         ABI as float64; anything else as float32.  Equal-length clips are converted as micro-batches."""
@@ -479,8 +499,15 @@ class Context:
                 nz.append(buf)
             npp = (C.POINTER(C.c_float) * B)(*[_p(b) for b in nz])
         out_n = (C.c_int64 * B)()
-        fn = lib().rvcx_convert_batch_f64 if is64 else lib().rvcx_convert_batch
-        self._ck(fn(self._h, model_id, B, wp, ns, C.byref(params), npp, op, fp, out_n), "convert_batch")
+        if inp_f0 is not None:                 # f0 files: (rows, 2) float32 tables of (time [s], f0 [Hz]) per utterance
+            tabs = [None if t is None else np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2) for t in inp_f0]
+            ex = (UttExtra * B)(*[UttExtra(None, 0, 0) if t is None else UttExtra(_p(t), t.shape[0], 0) for t in tabs])
+            wv = (C.c_void_p * B)(*[w.ctypes.data for w in wavs])
+            self._ck(lib().rvcx_convert_batch_ex(self._h, model_id, B, wv, 1 if is64 else 0, ns, C.byref(params), npp, ex,
+                                                 op, fp, out_n), "convert_batch_ex")
+        else:
+            fn = lib().rvcx_convert_batch_f64 if is64 else lib().rvcx_convert_batch
+            self._ck(fn(self._h, model_id, B, wp, ns, C.byref(params), npp, op, fp, out_n), "convert_batch")
         pcm = [o[:out_n[i]].copy() for i, o in enumerate(outs)]
         if want_f32:
             return pcm, [o[:out_n[i]].copy() for i, o in enumerate(f32s)]
@@ -512,6 +539,20 @@ class Context:
         self._ck(lib().rvcx_get_f0_x(self._h, _p(x), C.c_int64(x.shape[0]), C.byref(params), _p(coarse, C.c_int32),
                                      _p(f0)), "get_f0_x")
         return coarse, f0
+
+    def get_f0_x_ex(self, x, p_len, params: "Params", inp_f0=None):
+        """VC.get_f0 in full (F0 model by params.f0_method, pitch shift, optional f0-file table, coarse) on the padded
+        signal: (coarse, f0) of 1 + n/160 frames (rmvpe+) or p_len frames (fcpe)."""
+        x = f32(x)
+        cap = max(int(p_len), 1 + x.shape[0] // 160)
+        coarse = np.empty(cap, np.int32)
+        f0 = np.empty(cap, np.float32)
+        tab = None if inp_f0 is None else np.ascontiguousarray(inp_f0, dtype=np.float32).reshape(-1, 2)
+        got = C.c_int64(0)
+        self._ck(lib().rvcx_get_f0_x_ex(self._h, _p(x), C.c_int64(x.shape[0]), C.c_int64(int(p_len)), C.byref(params),
+                                        _p(tab), 0 if tab is None else tab.shape[0], _p(coarse, C.c_int32), _p(f0),
+                                        C.byref(got)), "get_f0_x_ex")
+        return coarse[:got.value].copy(), f0[:got.value].copy()
 
     def vc_frames(self, n: int) -> int:
         return int(lib().rvcx_vc_frames(self._h, C.c_int64(n)))
@@ -597,6 +638,16 @@ class Context:
     def fp32_reruns(self) -> int:
         """calls repeated on the exact-fp32 kernels after an fp16-split overflow"""
         return int(lib().rvcx_fp32_reruns(self._h))
+
+    def fp32_layers(self) -> int:
+        """layers pinned to the exact-fp32 kernels after an activation left fp16 range (sticky per model)"""
+        return int(lib().rvcx_fp32_layers(self._h))
+
+    def gru_fallbacks(self) -> int:
+        return int(lib().rvcx_gru_fallbacks(self._h))
+
+    def debug_inject(self, what: int):
+        self._ck(lib().rvcx_debug_inject(self._h, int(what)), "debug_inject")
 
     def flop_counter(self, reset=False) -> float:
         return float(lib().rvcx_flop_counter(self._h, 1 if reset else 0))

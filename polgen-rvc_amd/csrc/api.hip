@@ -17,42 +17,99 @@ struct rvcx_ctx {
 
 static thread_local std::string g_last_error;
 
-// Every entry point's body runs inside a two-attempt loop: if a split-fp16 kernel reported an activation it could
-// not represent (Ctx::take_overflow), the whole call is repeated on the exact-fp32 kernels (thread-local
-// g_force_fp32) and counted (rvcx_fp32_reruns).  Bodies are written to be repeatable (they reset the arena first).
+// Every entry point's body runs inside api_call():
+//  * fp16-split range guard.  If a split-fp16 kernel reported an activation it could not represent
+//    (Ctx::take_overflow), the FIRST offending layer of the call (launch order; every layer stamps its own device
+//    word) is pinned to the exact-fp32 kernels for the life of its model and the call is repeated -- a one-off per
+//    model and layer (rvcx_fp32_reruns counts the repeats, rvcx_fp32_layers the pinned layers).  If no layer can be
+//    named (kernel-level test entry points pack their weights per call) or after kMaxAttempts - 1 repeats, the last
+//    attempt runs everything on the exact-fp32 kernels (thread-local g_force_fp32).
+//  * BiGRU cluster time-out.  The cluster kernel needs its workgroups co-resident; if a partner never showed up
+//    (Ctx::check_dev_err -> GruTimeout) the call is repeated once with the single-workgroup GRU kernel.
+// Bodies are written to be repeatable (they reset the arena first); load / unload entry points run once (repeat = false).
 struct Fp32Scope {
   bool saved;
   explicit Fp32Scope(bool on) : saved(g_force_fp32) { g_force_fp32 = saved || on; }
   ~Fp32Scope() { g_force_fp32 = saved; }
 };
+struct GruScope {
+  bool saved;
+  explicit GruScope(bool on) : saved(g_gru_no_cluster) { g_gru_no_cluster = saved || on; }
+  ~GruScope() { g_gru_no_cluster = saved; }
+};
+constexpr int kMaxAttempts = 6;
 
-#define API_BEGIN(ctxp)                       \
-  Ctx* C = (ctxp) ? &(ctxp)->c : nullptr;     \
-  try {                                       \
-    if (!C) fail("null context");             \
-    RVCX_HIP(hipSetDevice(C->device));        \
-    for (int attempt_ = 0; attempt_ < 2; ++attempt_) { \
-      Fp32Scope fp32_scope_(attempt_ == 1);
+static std::vector<WeightRegion*> all_regions(Ctx& c, uint64_t* hash);
 
-#define API_END                               \
-      if (attempt_ == 0 && C->take_overflow()) { \
-        C->fp32_reruns++;                     \
-        continue;                             \
-      }                                       \
-      break;                                  \
-    }                                         \
-    return 0;                                 \
-  } catch (const std::exception& e) {         \
-    g_last_error = e.what();                  \
-    if (C) {                                  \
-      C->last_error = e.what();               \
-      (void)hipDeviceSynchronize(); /* side streams may still use arena memory */ \
-      C->arena.reset();                       \
-      C->arena_f0.reset();                    \
-    }                                         \
-    (void)hipGetLastError();                  \
-    return -1;                                \
+// pins the first layer (in launch order) whose activations left fp16 range; false: none of the resident models named one
+static bool localize_overflow(Ctx& c) {
+  WeightRegion* best_r = nullptr;
+  int best = 0, best_i = -1;
+  for (WeightRegion* r : all_regions(c, nullptr)) {
+    int i = -1;
+    const int v = r->first_overflow(&i);       // also clears the region's words
+    if (v > best) {
+      best = v;
+      best_i = i;
+      best_r = r;
+    }
   }
+  if (!best_r) return false;
+  best_r->drop_flag(best_i);
+  return true;
+}
+
+static void reset_after_failure(Ctx& c) {
+  (void)hipDeviceSynchronize();    // side streams may still use arena memory
+  c.arena.reset();
+  c.arena_f0.reset();
+  c.arena_hub.reset();
+}
+
+template <typename F>
+static int api_call(rvcx_ctx* ctxp, bool repeat, F&& body) {
+  Ctx* C = ctxp ? &ctxp->c : nullptr;
+  try {
+    if (!C) fail("null context");
+    RVCX_HIP(hipSetDevice(C->device));
+    const int last = repeat ? kMaxAttempts - 1 : 0;
+    bool gru_plain = false;
+    for (int attempt = 0; attempt <= last; ++attempt) {
+      Fp32Scope fp32_scope(attempt > 0 && attempt == last);
+      GruScope gru_scope(gru_plain);
+      C->launch_seq = 0;
+      try {
+        body(C);
+      } catch (const GruTimeout&) {
+        if (!repeat || gru_plain) throw;
+        gru_plain = true;
+        C->gru_fallbacks++;
+        reset_after_failure(*C);
+        --attempt;
+        continue;
+      }
+      if (attempt < last && C->take_overflow()) {
+        C->fp32_reruns++;
+        if (!localize_overflow(*C)) attempt = last - 1;     // nobody to pin: everything on fp32 next
+        continue;
+      }
+      break;
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    if (C) {
+      C->last_error = e.what();
+      reset_after_failure(*C);
+    }
+    (void)hipGetLastError();
+    return -1;
+  }
+}
+
+#define API_BEGIN(ctxp) return api_call((ctxp), true, [&](Ctx* C) {
+#define API_BEGIN_ONCE(ctxp) return api_call((ctxp), false, [&](Ctx* C) {
+#define API_END });
 
 // copy n elements from host-or-device memory into the arena
 template <typename T>
@@ -112,6 +169,7 @@ int rvcx_create(int device, rvcx_ctx** out) {
       }
     }
     conv_init();
+    resblock_pair_init();
     h->c.resblock_streams = !getenv("RVCX_RESBLOCK_STREAMS") || atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
     // RVCX_SERIAL=1: every launch on the one main stream (rocprofv3 kernel durations are then each launch's own)
     h->c.serial_env = getenv("RVCX_SERIAL") && atoi(getenv("RVCX_SERIAL")) != 0;
@@ -119,6 +177,17 @@ int rvcx_create(int device, rvcx_ctx** out) {
     RVCX_HIP(hipMalloc(&h->c.dev_err, sizeof(int)));
     RVCX_HIP(hipMemset(h->c.dev_err, 0, sizeof(int)));
     h->c.arena.reserve((size_t)256 << 20);
+    {
+      // One-time work a serving process should not pay inside its first request (round 2: 88 ms in the first call's
+      // high-pass stage): the code object is loaded on the first launch, and every stream / hardware queue is
+      // created on its first use.  One trivial launch per stream, then wait.
+      float* w = h->c.arena.alloc<float>(256);
+      hipStream_t ss[] = {h->c.stream, h->c.stream2, h->c.aux[0], h->c.aux[1], h->c.stream_h};
+      for (hipStream_t s : ss)
+        if (s) launch_randn(w, 64, 1, 0, s);
+      RVCX_HIP(hipDeviceSynchronize());
+      h->c.arena.reset();
+    }
     *out = h;
     return 0;
   } catch (const std::exception& e) {
@@ -141,7 +210,7 @@ const char* rvcx_last_error(rvcx_ctx* ctx) {
 void* rvcx_stream(rvcx_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
 
 int rvcx_mem_info(rvcx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   size_t f = 0, t = 0;
   RVCX_HIP(hipMemGetInfo(&f, &t));
   if (free_bytes) *free_bytes = (int64_t)f;
@@ -150,6 +219,21 @@ int rvcx_mem_info(rvcx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
 }
 
 int64_t rvcx_fp32_reruns(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.fp32_reruns : -1; }
+
+int64_t rvcx_fp32_layers(rvcx_ctx* ctx) {
+  if (!ctx) return -1;
+  int64_t n = 0;
+  for (WeightRegion* r : all_regions(ctx->c, nullptr)) n += r->dropped();
+  return n;
+}
+
+int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
+
+int rvcx_debug_inject(rvcx_ctx* ctx, int what) {
+  if (!ctx || what != 1) return -1;
+  ctx->c.inject_gru_timeout = true;
+  return 0;
+}
 
 double rvcx_flop_counter(rvcx_ctx* ctx, int reset) {
   if (!ctx) return 0.0;
@@ -526,7 +610,7 @@ static TensorTable make_table(const rvcx_tensor* tbl, int n) {
 }
 
 int rvcx_load_synth(rvcx_ctx* ctx, const rvcx_synth_cfg* cfg, const rvcx_tensor* tbl, int n, int* model_id) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   TensorTable t = make_table(tbl, n);
   auto m = synth_load(*C, *cfg, t);
   int id = -1;
@@ -542,7 +626,7 @@ int rvcx_load_synth(rvcx_ctx* ctx, const rvcx_synth_cfg* cfg, const rvcx_tensor*
 }
 
 int rvcx_unload_synth(rvcx_ctx* ctx, int model_id) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   if (model_id < 0 || model_id >= (int)C->synths.size()) fail("bad model id");
   RVCX_HIP(hipDeviceSynchronize());
   C->synths[model_id].reset();   // frees the model's weight region
@@ -598,7 +682,7 @@ int rvcx_weights_regions(rvcx_ctx* ctx, int cap, void** dev_ptrs, int64_t* nbyte
 }
 
 int rvcx_weights_clone(rvcx_ctx* ctx, rvcx_ctx* src) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   if (!src) fail("weights_clone: null source context");
   if (src->c.device != C->device) fail("weights_clone: contexts live on different devices (use the RCCL broadcast)");
   uint64_t ha = 0, hb = 0;
@@ -617,7 +701,7 @@ int rvcx_weights_clone(rvcx_ctx* ctx, rvcx_ctx* src) {
 }
 
 int rvcx_weights_adopt(rvcx_ctx* ctx) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   RVCX_HIP(hipDeviceSynchronize());
   for (WeightRegion* r : all_regions(*C, nullptr)) r->adopt();
   API_END
@@ -721,14 +805,14 @@ int rvcx_op_layernorm_c(rvcx_ctx* ctx, const float* x, const float* gamma, const
 }
 
 int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor* tbl, int n) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   TensorTable t = make_table(tbl, n);
   C->rmvpe = rmvpe_load(*C, *cfg, t);
   API_END
 }
 
 int rvcx_load_fcpe(rvcx_ctx* ctx, const rvcx_fcpe_cfg* cfg, const rvcx_tensor* tbl, int n) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   TensorTable t = make_table(tbl, n);
   C->fcpe = fcpe_load(*C, *cfg, t);
   API_END
@@ -796,7 +880,7 @@ int rvcx_get_f0_fcpe_x(rvcx_ctx* ctx, const float* x, int64_t n, int64_t p_len, 
 }
 
 int rvcx_load_hubert(rvcx_ctx* ctx, const rvcx_hubert_cfg* cfg, const rvcx_tensor* tbl, int n) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   TensorTable t = make_table(tbl, n);
   C->hubert = hubert_load(*C, *cfg, t);
   API_END
@@ -908,7 +992,7 @@ int rvcx_op_bigru(rvcx_ctx* ctx, const float* x, const float* w_ih, const float*
 }
 
 int rvcx_load_index(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   if (!big_npy || n == 0) {
     C->index.reset();
   } else {
@@ -919,7 +1003,7 @@ int rvcx_load_index(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim) {
 
 int rvcx_load_index_ivf(rvcx_ctx* ctx, const float* big_npy, int64_t n, int dim, const float* centroids, int nlist,
                         const int32_t* assign, int nprobe) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   if (!big_npy || n <= 0 || !centroids || nlist <= 0 || !assign) fail("load_index_ivf: null argument");
   if (nprobe != 1) fail("load_index_ivf: only nprobe = 1 (what RVC index files carry) is implemented");
   C->index = index_load(*C, big_npy, n, dim, centroids, nlist, assign);
@@ -959,7 +1043,7 @@ int64_t rvcx_noise_len(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params
 
 static int convert_impl(rvcx_ctx* ctx, int model_id, int B, const float* const* wav32, const double* const* wav64,
                         const int64_t* n, const rvcx_params* p, const float* const* noise, int16_t* const* out,
-                        float* const* out_f32, int64_t* out_n) {
+                        float* const* out_f32, int64_t* out_n, const rvcx_utt_extra* extra = nullptr) {
   API_BEGIN(ctx)
   (void)get_synth(*C, model_id);
   if (B < 0 || (B > 0 && (!n || !p || !out || (!wav32 && !wav64)))) fail("convert_batch: null argument");
@@ -973,6 +1057,10 @@ static int convert_impl(rvcx_ctx* ctx, int model_id, int B, const float* const* 
     u.out = out[i];
     u.out_f32 = out_f32 ? out_f32[i] : nullptr;
     u.seed_offset = i;
+    if (extra) {
+      u.inp_f0 = extra[i].inp_f0;
+      u.inp_f0_rows = extra[i].inp_f0 ? extra[i].inp_f0_rows : 0;
+    }
     if (!(u.wav || u.wav64) || !u.out) fail("convert_batch: null buffer for utterance " + std::to_string(i));
   }
   static const bool timing = !getenv("RVCX_STAGE_TIMING") || atoi(getenv("RVCX_STAGE_TIMING")) != 0;
@@ -996,6 +1084,14 @@ int rvcx_convert_batch_f64(rvcx_ctx* ctx, int model_id, int B, const double* con
                            const rvcx_params* p, const float* const* noise, int16_t* const* out,
                            float* const* out_f32, int64_t* out_n) {
   return convert_impl(ctx, model_id, B, nullptr, wav16k, n, p, noise, out, out_f32, out_n);
+}
+
+int rvcx_convert_batch_ex(rvcx_ctx* ctx, int model_id, int B, const void* const* wav16k, int wav_is_f64,
+                          const int64_t* n, const rvcx_params* p, const float* const* noise,
+                          const rvcx_utt_extra* extra, int16_t* const* out, float* const* out_f32, int64_t* out_n) {
+  return convert_impl(ctx, model_id, B, wav_is_f64 ? nullptr : reinterpret_cast<const float* const*>(wav16k),
+                      wav_is_f64 ? reinterpret_cast<const double* const*>(wav16k) : nullptr, n, p, noise, out, out_f32,
+                      out_n, extra);
 }
 
 int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
@@ -1053,6 +1149,55 @@ int rvcx_get_f0_x(rvcx_ctx* ctx, const float* x, int64_t n, const rvcx_params* p
   C->check_dev_err();
   C->arena.reset();
   API_END
+}
+
+int rvcx_get_f0_x_ex(rvcx_ctx* ctx, const float* x, int64_t n, int64_t p_len, const rvcx_params* p, const float* inp_f0,
+                     int inp_f0_rows, int32_t* coarse, float* f0, int64_t* frames) {
+  API_BEGIN(ctx)
+  if (!p || !x) fail("get_f0: null argument");
+  check_f0_backend(*C, *p);
+  const bool fcpe = p->f0_method == RVCX_F0_FCPE;
+  const long F = fcpe ? (long)p_len : 1 + n / 160;        // rmvpe+: un-truncated; fcpe: compute_f0 resizes to p_len
+  if (F <= 0) fail("get_f0: p_len must be positive");
+  const std::vector<double> track = f0_file_track(inp_f0, inp_f0 ? inp_f0_rows : 0);
+  C->arena.reserve(f0_arena_bytes(*C, *p, 1, n) + (size_t)n * 8 + (size_t)(F + n / 160 + 8) * 48 + track.size() * 8 +
+                   (64 << 20));
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  float* dx = any_to_dev(*C, x, (size_t)n);
+  float* fraw = C->arena.alloc<float>((size_t)(1 + n / 160));
+  int* dc = C->arena.alloc<int>((size_t)F);
+  float* df = C->arena.alloc<float>((size_t)F);
+  if (fcpe) {
+    fcpe_forward(*C, *C->fcpe, 1, dx, n, 0.03f, fraw, nullptr, nullptr, s);
+    fcpe_post_coarse(*C, fraw, 1, (int)(1 + n / 160), (int)F, df, dc, F, p->pitch, p->f0_min, p->f0_max, s);
+  } else {
+    rmvpe_forward(*C, *C->rmvpe, 1, dx, n, 0.03f, p->f0_min, p->f0_max, fraw, nullptr, s);
+    launch_f0_coarse(fraw, df, dc, (int)F, p->pitch, p->f0_min, p->f0_max, s);
+  }
+  if (!track.empty()) {
+    double* rep = C->arena.alloc<double>(track.size());
+    RVCX_HIP(hipMemcpyAsync(rep, track.data(), track.size() * 8, hipMemcpyHostToDevice, s));
+    launch_f0_override(rep, (int)track.size(), 100 * p->x_pad, df, dc, (int)F, p->f0_min, p->f0_max, s);
+  }
+  RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)F * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)F * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  C->check_dev_err();
+  if (frames) *frames = F;
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_f0_file_track(const float* inp_f0, int rows, double* track, int cap) {
+  try {
+    const std::vector<double> t = f0_file_track(inp_f0, rows);
+    for (size_t i = 0; i < t.size() && (int)i < cap; ++i) track[i] = t[i];
+    return (int)t.size();
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return -1;
+  }
 }
 
 int rvcx_vc_frames(rvcx_ctx* ctx, int64_t n) {
@@ -1132,7 +1277,7 @@ int rvcx_vc(rvcx_ctx* ctx, int model_id, const float* audio0, int64_t n, const i
 
 int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
                       int32_t* bn, int32_t* kind, int cap) {
-  API_BEGIN(ctx)
+  API_BEGIN_ONCE(ctx)
   C->serial = begin != 0 || C->serial_env;
   if (begin) {
     conv_profile_begin();

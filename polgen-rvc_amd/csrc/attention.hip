@@ -10,11 +10,10 @@
 #include <cstdlib>
 
 #include "conv.h"
+#include "conv_device.h"
 #include "ops.h"
 
 namespace rvcx {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KT = 32;     // keys per tile
 constexpr int VROW = 33;   // odd pitch: conflict-free strided A-fragment reads of V
@@ -214,7 +213,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
                                                       float* __restrict__ m_out, float* __restrict__ l_out,
                                                       const float* __restrict__ relq, int H, int D, int T,
                                                       int ld, long in_bs, long out_bs, float scale, int window,
-                                                      const int* lens, int nsplit, float* opart, int* ovf_word) {
+                                                      const int* lens, int nsplit, float* opart, int* ovf_word,
+                                                      int* ovf_layer, int seq) {
   constexpr int NS = 2 * DT;                       // k16-steps over the head dimension
   __shared__ uint4 Ks[NS * 2 * 2 * 32];            // [s][op {S kh, S kl}][h][key]   (kh = (S kh)/S in registers)
   __shared__ uint4 Vs[DT * 2 * 2 * 2 * 32];        // [dt][s2][op {S vh, S vl}][h][d]
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
         acc_o[dt] = att_mfma(a2, ph[s2], acc_o[dt]);
       }
   }
-  if (ovf && ovf_word) atomicOr(ovf_word, kErrH3Overflow);
+  if (ovf) report_h3_overflow(ovf_word, ovf_layer, seq);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -584,7 +584,8 @@ __global__ __launch_bounds__(256) void rel_values_kernel(const float* __restrict
 
 void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
                       int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
-                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream, int* ovf) {
+                      const int* lens, float* scratch, float* split_scratch, hipStream_t stream, int* ovf, int* ovf_layer,
+                      int seq, bool allow_h3) {
   RVCX_CHECK(D % 2 == 0 && D <= 96, "attention: head dim must be even and <= 96");
   const int nrel = 2 * window + 1;
   float *relq = nullptr, *mb = nullptr, *lb = nullptr;
@@ -618,16 +619,16 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
   float* lo = nsplit > 1 ? nullptr : lb;
   dim3 grid(cdiv(T, 128) * nsplit, H, B);
   static const int h3_env = getenv("RVCX_ATT_H3") ? atoi(getenv("RVCX_ATT_H3")) : 1;   // 0: exact-fp32 MFMA attention
-  const int h3 = h3_env && !g_force_fp32;
+  const int h3 = h3_env && !g_force_fp32 && allow_h3;
   if (h3 && DT == 1)
     hipLaunchKernelGGL(attn_h3_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart, ovf);
+                       out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
   else if (h3 && DT == 2)
     hipLaunchKernelGGL(attn_h3_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart, ovf);
+                       out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
   else if (h3)
     hipLaunchKernelGGL(attn_h3_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart, ovf);
+                       out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
   else if (DT == 1)
     hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
                        out_bs, scale, window, lens, nsplit, opart);

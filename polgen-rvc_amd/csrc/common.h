@@ -15,6 +15,11 @@ struct Error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+// the BiGRU cluster kernel gave up waiting for a partner workgroup (gru.hip): api_call repeats with the plain kernel
+struct GruTimeout : Error {
+  using Error::Error;
+};
+
 [[noreturn]] inline void fail(const std::string& msg) { throw Error(msg); }
 
 #define RVCX_HIP(expr)                                                                   \

@@ -62,6 +62,8 @@ struct ConvArgs {
   int stagger = 0;               // start delay per resident-workgroup slot in 100 MHz ticks (first round only)
   int stagger_blocks = 0;        // workgroups of the first round (linear id below this get the delay)
   int* ovf = nullptr;            // device error word: bit 1 is set when an activation does not fit the fp16 hi/lo split
+  int* ovf_layer = nullptr;      // the LAYER's own device word (ConvW::ovf_word): receives 0x7fffffff - seq, so the host finds the
+  int seq = 0;                   // first offender of a call in launch order and pins that layer to the exact-fp32 kernels
   int dbg = 0;                   // timing ablations only (RVCX_CONV_DBG): 1 skip weight staging, 2 skip input staging, 4 skip MFMAs
 };
 
@@ -88,16 +90,22 @@ struct PairArgs {
   int acc2_mode = ACC2_NONE;
   float acc2_div = 1.f;
   int* ovf = nullptr;            // as ConvArgs::ovf
+  int* ovf_layer = nullptr;      // as ConvArgs::ovf_layer (the pair reports as its first conv)
+  int seq = 0;
 };
 // fp16 hi/lo split kernels hold activations as fp16 halves: |x| >= 65504 (attention K / V: >= 255) would become
-// inf.  Every split kernel checks what it converts and raises bit 1 of the context's device error word; the API
-// entry point then repeats the call on the exact-fp32 kernels (g_force_fp32, thread-local) and counts it.
+// inf.  Every split kernel checks what it converts, raises bit 1 of the context's device error word and stamps its
+// layer's own word with the launch sequence number.  The API entry point then pins the FIRST offending layer of the
+// call to the exact-fp32 kernels for the life of its model (a region flag: sticky) and repeats the call -- once per
+// model and layer, not once per request.  g_force_fp32 (thread-local: everything on fp32) is the last resort.
 constexpr float kH3ActLimit = 6.0e4f;
 constexpr int kErrGruTimeout = 1, kErrH3Overflow = 2;
 extern thread_local bool g_force_fp32;
+extern thread_local bool g_gru_no_cluster;   // this attempt of the API call runs the single-workgroup BiGRU kernel (gru.hip)
 bool resblock_pair_enabled();                                // RVCX_FUSE (default on) and the h3 kernels enabled
 bool resblock_pair_ok(const PairArgs& a);
 void launch_resblock_pair(const PairArgs& a, hipStream_t stream);              // raw launch (resblock.hip)
+void resblock_pair_init();                                                     // kernel attributes, once per process
 void conv_launch_pair(const PairArgs& a, double flops, hipStream_t stream);    // + profile record (conv.hip)
 int resblock_pair_slot(int C);
 struct ConvProfile;

@@ -6,6 +6,12 @@ namespace rvcx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// an activation did not fit the fp16 hi/lo split (conv.h: kH3ActLimit): tell the context and the layer
+__device__ __forceinline__ void report_h3_overflow(int* ovf, int* layer, int seq) {
+  if (ovf) atomicOr(ovf, kErrH3Overflow);
+  if (layer) atomicMax(layer, 0x7fffffff - seq);     // larger = earlier launch of this call
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
     case ACT_LRELU: return v > 0.f ? v : v * slope;

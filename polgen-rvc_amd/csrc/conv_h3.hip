@@ -54,7 +54,7 @@ __device__ __forceinline__ void store_tile_split(const ConvArgs& a, int b, int c
         float v = t[4 * g + q] + (a.bias ? a.bias[cg + 4 * hl + q] : 0.f);
         v = apply_act(v, a.act, a.act_slope);
         v = live ? v : 0.f;
-        if (!(fabsf(v) < kH3ActLimit) && a.ovf) atomicOr(a.ovf, kErrH3Overflow);   // never taken on sane data
+        if (!(fabsf(v) < kH3ActLimit)) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);   // never taken on sane data
         const _Float16 vh = (_Float16)v;
         hi[q] = vh;
         lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
     chunk = chunk1;
   }
 
-  if (ovf && a.ovf) atomicOr(a.ovf, kErrH3Overflow);
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
   constexpr float inv = 1.f / kH3Scale;
 #pragma unroll
   for (int m = 0; m < WM; ++m)
@@ -369,6 +369,7 @@ constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 }  // namespace
 
 thread_local bool g_force_fp32 = false;
+thread_local bool g_gru_no_cluster = false;
 
 bool conv_h3_enabled() {
   static const int mode = getenv("RVCX_H3") ? atoi(getenv("RVCX_H3")) : 1;   // initialised once, thread-safe

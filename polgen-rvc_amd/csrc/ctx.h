@@ -31,6 +31,7 @@ class WeightRegion {
   }
   ~WeightRegion() {
     for (auto& c : chunks_) (void)hipFree(c.base);
+    if (ovf_words_) (void)hipFree(ovf_words_);
   }
   WeightRegion(const WeightRegion&) = delete;
   WeightRegion& operator=(const WeightRegion&) = delete;
@@ -58,11 +59,44 @@ class WeightRegion {
   }
   // a value-dependent yes/no that must agree on every rank after a broadcast; the returned pointer stays valid
   // for the life of the region and is what kernels' launchers consult
-  const uint8_t* new_flag(bool v) {
+  uint8_t* new_flag(bool v) {
     if (nflags_ >= kMaxFlags) fail("weight region: flag table full");
     flags_[nflags_] = v ? 1 : 0;
     return &flags_[nflags_++];
   }
+  // Device word of a flag: split-fp16 kernels stamp it (conv.h: ovf_layer) when an activation of that layer leaves
+  // fp16 range.  Not part of the broadcast layout (a plain per-region scratch array, zero when idle).
+  int* ovf_word(const uint8_t* flag) {
+    if (!ovf_words_) {
+      RVCX_HIP(hipMalloc(&ovf_words_, kMaxFlags * sizeof(int)));
+      RVCX_HIP(hipMemset(ovf_words_, 0, kMaxFlags * sizeof(int)));
+    }
+    return ovf_words_ + (flag - flags_.get());
+  }
+  // After a call that reported an overflow: the largest stamp of this region (0: none) and its flag index.
+  int first_overflow(int* index) {
+    if (!ovf_words_) return 0;
+    std::vector<int> w(kMaxFlags);
+    RVCX_HIP(hipMemcpy(w.data(), ovf_words_, kMaxFlags * sizeof(int), hipMemcpyDeviceToHost));
+    int best = 0;
+    for (int i = 0; i < nflags_; ++i)
+      if (w[i] > best) {
+        best = w[i];
+        *index = i;
+      }
+    if (best) RVCX_HIP(hipMemset(ovf_words_, 0, kMaxFlags * sizeof(int)));
+    return best;
+  }
+  void clear_overflow() {
+    if (ovf_words_) RVCX_HIP(hipMemset(ovf_words_, 0, kMaxFlags * sizeof(int)));
+  }
+  // pin a layer to the exact-fp32 kernels for the life of the region (sticky); the device header follows
+  void drop_flag(int index) {
+    flags_[index] = 0;
+    ++dropped_;
+    if (!chunks_.empty()) RVCX_HIP(hipMemcpy(chunks_[0].base, flags_.get(), kMaxFlags, hipMemcpyHostToDevice));
+  }
+  int dropped() const { return dropped_; }
   void seal() {     // publish the host flags into the device header (end of a load)
     if (chunks_.empty()) reserve(256);
     RVCX_HIP(hipMemcpy(chunks_[0].base, flags_.get(), kMaxFlags, hipMemcpyHostToDevice));
@@ -99,7 +133,8 @@ class WeightRegion {
   }
   std::vector<Chunk> chunks_;
   std::unique_ptr<uint8_t[]> flags_;
-  int nflags_ = 0;
+  int* ovf_words_ = nullptr;
+  int nflags_ = 0, dropped_ = 0;
   uint64_t hash_ = 1469598103934665603ull;
 };
 
@@ -108,7 +143,7 @@ class WeightSlab {
  public:
   float* upload(const std::vector<float>& h) { return cur().upload(h); }
   float* upload(const float* h, size_t n) { return cur().upload(h, n); }
-  const uint8_t* new_flag(bool v) { return cur().new_flag(v); }
+  uint8_t* new_flag(bool v) { return cur().new_flag(v); }
   WeightRegion& cur() {
     if (!cur_) fail("internal: weight upload outside a RegionScope");
     return *cur_;
@@ -156,7 +191,10 @@ struct Ctx {
   int* dev_err = nullptr;         // device error word (conv.h: kErrGruTimeout, kErrH3Overflow), read after each API call
   void check_dev_err();           // throws on a GRU timeout; an fp16-split overflow is left for take_overflow()
   bool take_overflow();           // true (and the bit cleared) when a split kernel met an activation beyond fp16
-  long fp32_reruns = 0;           // calls repeated on the exact-fp32 kernels because of that
+  long fp32_reruns = 0;           // calls repeated because of that (each repeat pins one layer to fp32, or, last resort, all)
+  long gru_fallbacks = 0;         // calls repeated with the single-workgroup BiGRU kernel after a cluster time-out
+  bool inject_gru_timeout = false;
+  int launch_seq = 0;             // launches of split-fp16 kernels since the call began (orders the layers' overflow stamps)
   float timing[9] = {0};
   StageTimer timer;
   std::unique_ptr<HubertModel> hubert;
@@ -187,6 +225,7 @@ struct Ctx {
     flops += f;
     PairArgs b = a;
     b.ovf = dev_err;
+    b.seq = ++launch_seq;
     conv_launch_pair(b, f, s);
   }
   void conv(const ConvArgs& a) { conv_on(a, stream); }
@@ -198,6 +237,7 @@ struct Ctx {
     a.part_cap = kSplitKFloats * splitk_items;
     a.part_cap_item = kSplitKFloats;
     a.ovf = dev_err;
+    a.seq = ++launch_seq;
     launch_conv(a, s);
   }
 };
@@ -214,11 +254,26 @@ struct RegionScope {
 struct ConvW {
   const float* w = nullptr;
   const void* w_h3 = nullptr;     // fp16 hi/lo split image (space is reserved whenever the SHAPE allows it)
-  const uint8_t* h3_ok = nullptr; // region flag: the image is usable (no weight overflowed fp16 at scale S)
+  const uint8_t* h3_ok = nullptr; // region flag: the image is usable (no weight overflowed fp16 at scale S, and no activation
+                                  // of this layer has left fp16 range since the model was loaded)
+  int* ovf_word = nullptr;        // the layer's device overflow word (WeightRegion::ovf_word)
   const float* bias = nullptr;
   int cin = 0, cout = 0, k = 1, groups = 1;
   int cin_gp = 0, cout_gp = 0;
 };
+
+// an attention call has no weights of its own: its "layer" is a flag + overflow word in the model's region
+struct AttFlag {
+  const uint8_t* ok = nullptr;
+  int* word = nullptr;
+  bool h3() const { return !ok || *ok; }
+};
+inline AttFlag make_att_flag(Ctx& c) {
+  AttFlag f;
+  f.ok = c.slab.new_flag(true);
+  f.word = c.slab.cur().ovf_word(f.ok);
+  return f;
+}
 
 ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups = 1,
                bool h3 = true);
@@ -227,6 +282,7 @@ ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, 
 inline void conv_set_weights(ConvArgs& a, const ConvW& w) {
   a.w = w.w;
   a.w_h3 = (w.w_h3 && w.h3_ok && *w.h3_ok) ? w.w_h3 : nullptr;
+  a.ovf_layer = w.ovf_word;
   a.bias = w.bias;
   a.groups = w.groups;
   a.Cin_g = w.cin / w.groups;

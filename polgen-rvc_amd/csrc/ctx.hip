@@ -60,9 +60,14 @@ void Ctx::check_dev_err() {
   if (!dev_err) return;
   int v = 0;
   RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (inject_gru_timeout) {       // test hook (rvcx_debug_inject): behave as if the cluster kernel had timed out
+    inject_gru_timeout = false;
+    v |= kErrGruTimeout;
+  }
   if (v & kErrGruTimeout) {
-    RVCX_HIP(hipMemset(dev_err, 0, sizeof(int)));
-    fail("device-side timeout: a GRU cluster workgroup lost its partner");
+    v &= ~kErrGruTimeout;
+    RVCX_HIP(hipMemcpy(dev_err, &v, sizeof(int), hipMemcpyHostToDevice));
+    throw GruTimeout("device-side timeout: a GRU cluster workgroup lost its partner");
   }
 }
 
@@ -163,6 +168,7 @@ static void upload_h3(Ctx& c, ConvW& L, const std::vector<float>& wp, int k) {
   const size_t n = (size_t)k * (L.cin_gp / 16) * 4 * L.cout_gp * 4;
   L.w_h3 = hp.empty() ? c.slab.cur().reserve(n * sizeof(float)) : c.slab.upload(hp);
   L.h3_ok = c.slab.new_flag(!hp.empty());
+  L.ovf_word = c.slab.cur().ovf_word(L.h3_ok);
 }
 
 ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups, bool h3) {

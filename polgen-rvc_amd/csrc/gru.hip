@@ -13,6 +13,7 @@
 //    L2 (~7 us).
 //  * bigru_kernel: one workgroup per (direction, item), W_hh streamed from L2 every step.  Used when
 //    the cluster grid would not be co-resident (large batches) -- the cluster kernel spins.
+#include "conv.h"
 #include "ops.h"
 
 namespace rvcx {
@@ -236,7 +237,7 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
   RVCX_CHECK(H == GRU_H, "bigru: hidden size must be 256 (RMVPE)");
   // the cluster kernel needs all 2*B*NC workgroups co-resident (they spin on each other)
   static const int nc = getenv("RVCX_GRU_NC") ? atoi(getenv("RVCX_GRU_NC")) : GRU_NC;
-  if (scratch && err && 2 * B * nc <= 128) {
+  if (scratch && err && 2 * B * nc <= 128 && !g_gru_no_cluster) {
     unsigned long long* xbuf = static_cast<unsigned long long*>(scratch);
     RVCX_HIP(hipMemsetAsync(scratch, 0, bigru_scratch_bytes(B), stream));
     static int colocate = -1;

@@ -55,6 +55,7 @@ std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, con
       auto bi = t.f32(p + n + ".bias");
       return make_conv(c, wi.data(), bi.data(), co, ci, 1, 1);
     };
+    L.att = make_att_flag(c);
     L.o = lin(".self_attn.out_proj", E, E);
     L.fc1 = lin(".fc1", cfg.ffn_dim, E);
     L.fc2 = lin(".fc2", E, cfg.ffn_dim);
@@ -140,7 +141,8 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     ConvArgs a = conv1d_args(L.qkv, h, qkv, B, T, T);
     c.conv_on(a, s);
     launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T,
-                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s, c.dev_err);
+                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s, c.dev_err, L.att.word,
+                     ++c.launch_seq, L.att.h3());
     c.flops += attention_flops(B, cf.heads, hd, T);
     a = conv1d_args(L.o, att, h2, B, T, T);
     conv_set_res(a, h, E, T);

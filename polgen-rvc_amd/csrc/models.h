@@ -18,6 +18,7 @@ struct SynthModel {
   const float* emb_pitch = nullptr;  // (256, hidden)
   struct EncLayer {
     ConvW qkv, o, ffn1, ffn2;
+    AttFlag att;                                         // this layer's attention call (fp16-split range guard)
     const float *rel_k = nullptr, *rel_v = nullptr;      // (21, hidden/heads)
     const float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   };
@@ -139,6 +140,7 @@ struct HubertModel {
   const float *eln_g = nullptr, *eln_b = nullptr;
   struct Layer {
     ConvW qkv, o, fc1, fc2;
+    AttFlag att;                                         // this layer's attention call (fp16-split range guard)
     const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   };
   std::vector<Layer> layers;

@@ -8,7 +8,9 @@ namespace rvcx {
 void launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int D, int T,
                       int ld, long in_bs, long out_bs, float scale, const float* emb_rel_k, const float* emb_rel_v, int window,
                       const int* lens, float* scratch, float* split_scratch, hipStream_t stream,
-                      int* ovf = nullptr /* device error word (fp16-split overflow bit), see conv.h */);
+                      int* ovf = nullptr /* device error word (fp16-split overflow bit), see conv.h */,
+                      int* ovf_layer = nullptr, int seq = 0 /* this call's own word + launch number (conv.h) */,
+                      bool allow_h3 = true /* false: the exact-fp32 kernel (a call pinned after an overflow) */);
 size_t attention_scratch_floats(int B, int H, int T, int window);
 size_t attention_split_floats(int B, int H, int T);
 double attention_flops(int B, int H, int D, int T);
@@ -80,6 +82,11 @@ void launch_decode_f0(const float* sal, float* f0, int B, int T, int ld, float t
 // f0 (n) -> f0 * 2^(pitch/12), coarse 1..255      [pipeline.py:183,193-201] (float64 arithmetic)
 void launch_f0_coarse(const float* f0_in, float* f0_out, int* coarse, int n, double pitch, double f0_min,
                       double f0_max, hipStream_t s);
+
+// f0 file override (pipeline.py:185-191): frames [start, start+count) of f0 / coarse (n frames) take rep (device, float64)
+void launch_f0_override(const double* rep, int count, int start, float* f0, int* coarse, int n, double f0_min,
+                        double f0_max, hipStream_t s);
+std::vector<double> f0_file_track(const float* tbl, int rows);   // host: np.interp restated (see ops.hip)
 
 // ---- pipeline glue
 // feats (C,T) -> x2 nearest upsample, protect mix; writes phone (C, 2T') cropped to p_len  [pipeline.py:252-270]

@@ -1,5 +1,9 @@
 // Non-GEMM kernels.  All memory-bound: coalesced along the contiguous (time) axis, one pass
 // where the math allows, wavefront/LDS reductions for the normalisations.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "ops.h"
 
 namespace rvcx {
@@ -568,6 +572,74 @@ void launch_f0_coarse(const float* f0_in, float* f0_out, int* coarse, int n, dou
   const double mel_min = 1127.0 * std::log(1.0 + f0_min / 700.0), mel_max = 1127.0 * std::log(1.0 + f0_max / 700.0);
   hipLaunchKernelGGL(f0_coarse_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, f0_in, f0_out, coarse, n,
                      std::pow(2.0, pitch / 12.0), mel_min, mel_max);
+}
+
+// f0 file (pipeline.py:185-191): frames [start, start + count) take the track read from the file -- after the pitch
+// shift, like the reference -- and are quantised with the same float64 formula
+__global__ void f0_override_kernel(const double* rep, int count, int start, float* f0, int* coarse, int n, double mel_min,
+                                   double mel_max) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < count; idx += gridDim.x * 256) {
+    const int t = start + idx;
+    if (t >= n) return;
+    const double f = rep[idx];
+    double m = 1127.0 * log(1.0 + f / 700.0);
+    if (m > 0.0) m = (m - mel_min) * 254.0 / (mel_max - mel_min) + 1.0;
+    if (m <= 1.0) m = 1.0;
+    if (m > 255.0) m = 255.0;
+    coarse[t] = (int)rint(m);
+    f0[t] = (float)f;
+  }
+}
+void launch_f0_override(const double* rep, int count, int start, float* f0, int* coarse, int n, double f0_min,
+                        double f0_max, hipStream_t s) {
+  if (count <= 0 || start >= n) return;
+  const double mel_min = 1127.0 * std::log(1.0 + f0_min / 700.0), mel_max = 1127.0 * std::log(1.0 + f0_max / 700.0);
+  hipLaunchKernelGGL(f0_override_kernel, dim3(cdiv(count, 256)), dim3(256), 0, s, rep, count, start, f0, coarse, n, mel_min,
+                     mel_max);
+}
+
+// The track VC.get_f0 builds from an f0 file's (time [s], f0 [Hz]) rows (pipeline.py:186-189), float32 table in, float64
+// out: delta_t = int16(round((t.max() - t.min()) * 100 + 1)) in float32 arithmetic, then np.interp(range(delta_t),
+// t * 100 [float32], f0) with numpy's own rules (flat extrapolation, exact hits return the sample, last of equal xp).
+std::vector<double> f0_file_track(const float* tbl, int rows) {
+  if (!tbl || rows <= 0) return {};
+  float tmin = tbl[0], tmax = tbl[0];
+  for (int i = 1; i < rows; ++i) {
+    tmin = std::fmin(tmin, tbl[2 * i]);
+    tmax = std::fmax(tmax, tbl[2 * i]);
+  }
+  const float span = (tmax - tmin) * 100.0f + 1.0f;
+  const int delta_t = (int)(short)std::nearbyint(span);      // np.round (half to even) -> astype("int16")
+  if (delta_t <= 0) return {};
+  std::vector<double> xp((size_t)rows), fp((size_t)rows);
+  for (int i = 0; i < rows; ++i) {
+    xp[i] = (double)(tbl[2 * i] * 100.0f);
+    fp[i] = (double)tbl[2 * i + 1];
+  }
+  std::vector<double> out((size_t)delta_t);
+  for (int q = 0; q < delta_t; ++q) {
+    const double x = (double)q;
+    double r;
+    if (x < xp[0]) {
+      r = fp[0];
+    } else if (x > xp[rows - 1]) {
+      r = fp[rows - 1];
+    } else {
+      const int j = (int)(std::upper_bound(xp.begin(), xp.end(), x) - xp.begin()) - 1;
+      if (j >= rows - 1 || xp[j] == x) {
+        r = fp[std::min(j, rows - 1)];
+      } else {
+        const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+        r = slope * (x - xp[j]) + fp[j];
+        if (std::isnan(r)) {
+          r = slope * (x - xp[j + 1]) + fp[j + 1];
+          if (std::isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+        }
+      }
+    }
+    out[q] = r;
+  }
+  return out;
 }
 
 __global__ void upsample_protect_kernel(const float* feats, const float* feats0, const float* pitchf, float* out,

@@ -33,6 +33,8 @@ struct UttIO {
   float* out_f32 = nullptr;        // optional, same capacity
   long out_n = 0;                  // produced samples (result)
   int seed_offset = 0;             // Philox stream of this utterance = params.seed + seed_offset
+  const float* inp_f0 = nullptr;   // f0 file table, rows of (time [s], f0 [Hz]) float32 in HOST memory (pipeline.py:349-360)
+  int inp_f0_rows = 0;
 };
 // VC.pipeline for a list of utterances: equal-length utterances run as micro-batches (B > 1 through every network).
 void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& utts, const rvcx_params& p, float* stage_ms /*9 or null*/);

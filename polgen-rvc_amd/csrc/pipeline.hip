@@ -356,6 +356,8 @@ struct Utt {
   long n = 0, n_pad = 0, p_len = 0, cap = 0;
   const float* noise = nullptr;   // packed parity noise on the device (or null)
   long noise_cap = 0;
+  double* rep = nullptr;          // f0-file track on the device (pipeline.py:185-191) or null
+  int rep_n = 0;
   short* pcm = nullptr;
   float* outf = nullptr;
   long out_n = 0;
@@ -493,6 +495,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     any_noise |= u.noise != nullptr;
     n_max = std::max(n_max, u.n);
     call_bytes += convert_call_bytes(c, model_id, u.n, p, u.wav64 != nullptr, u.noise != nullptr);
+    if (u.inp_f0) call_bytes += (size_t)65536 * sizeof(double) + 256;      // delta_t is an int16
   }
   for (const auto& mb : mbs) {
     const long n = ios[order[mb.first]].n;
@@ -517,6 +520,8 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   c.arena_hub.reserve(hub_bytes + ((size_t)64 << 20));
 
   // ---- call-long buffers
+  std::vector<std::vector<double>> f0_tracks;      // host copies stay alive until the call's last synchronisation
+  f0_tracks.reserve(NB);
   std::vector<Utt> utts(NB);
   for (int i = 0; i < NB; ++i) {
     Utt& u = utts[i];
@@ -530,6 +535,15 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     if (ios[i].noise) {
       u.noise_cap = noise_len_for(c, M, u.n, p);
       u.noise = A.alloc<float>((size_t)u.noise_cap);
+    }
+    if (ios[i].inp_f0 && ios[i].inp_f0_rows > 0) {       // f0 file: the replacement track, built like the reference does
+      f0_tracks.push_back(f0_file_track(ios[i].inp_f0, ios[i].inp_f0_rows));
+      const std::vector<double>& tr = f0_tracks.back();
+      if (!tr.empty()) {
+        u.rep_n = (int)tr.size();
+        u.rep = A.alloc<double>(tr.size());
+        RVCX_HIP(hipMemcpyAsync(u.rep, tr.data(), tr.size() * sizeof(double), hipMemcpyHostToDevice, sf));
+      }
     }
   }
   // two front sets (micro-batch k+1's front end runs while k is in the synthesizer)
@@ -654,6 +668,13 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       throw;
     }
     c.arena.swap(c.arena_f0);
+    for (int b = 0; b < mb.count; ++b) {                 // f0 file override (pipeline.py:185-191): x_pad * 100 frames in
+      const Utt& u = utts[order[mb.first + b]];
+      const long stride = n_pad / 160 + 8;
+      if (u.rep)
+        launch_f0_override(u.rep, u.rep_n, (int)(g.t_pad / 160), f.f0 + (size_t)b * stride, f.coarse + (size_t)b * stride,
+                           (int)(n_pad / 160), p.f0_min, p.f0_max, sf);
+    }
     f0_ev1[k] = clk.mark(sf);
     if (sf != s) RVCX_HIP(hipEventRecord(c.ev_join, sf));
   };

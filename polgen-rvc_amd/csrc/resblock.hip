@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
       }
     }
 
-  if (ovf && a.ovf) atomicOr(a.ovf, kErrH3Overflow);
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
 
   // ================================================================ phase 2: y = c2(Y1) + b2 + x
   zero_acc();
@@ -375,9 +375,7 @@ void resblock_pair_describe(ConvProfile* p) {
   }
 }
 
-void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
-  RVCX_CHECK(resblock_pair_ok(a), "resblock pair: unsupported shape");
-  RVCX_CHECK(a.y != a.x && a.y2 != a.x, "resblock pair: in-place operation is a race (halo reads vs neighbours' stores)");
+void resblock_pair_init() {
   static const bool init = [] {       // once per process, also when several contexts start on different threads
     for (const auto& c : kPair)
       RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -385,6 +383,12 @@ void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
     return true;
   }();
   (void)init;
+}
+
+void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
+  RVCX_CHECK(resblock_pair_ok(a), "resblock pair: unsupported shape");
+  RVCX_CHECK(a.y != a.x && a.y2 != a.x, "resblock pair: in-place operation is a race (halo reads vs neighbours' stores)");
+  resblock_pair_init();
   const PairCfg& c = *find_cfg(a.C, a.k);
   const int bn_out = c.n1 - (a.k - 1);
   dim3 grid(cdiv(a.T, bn_out), 1, a.B);

@@ -78,6 +78,7 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
       b.insert(b.end(), bi.begin(), bi.end());
     }
     L.qkv = make_conv(c, w.data(), b.data(), 3 * hid, hid, 1, 1);
+    L.att = make_att_flag(c);
     L.o = load_conv(c, t, a + ".conv_o");
     L.rel_k = c.slab.upload(t.f32(a + ".emb_rel_k"));
     L.rel_v = c.slab.upload(t.f32(a + ".emb_rel_v"));
@@ -251,7 +252,8 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     ConvArgs a = conv1d_args(L.qkv, x, qkv, B, T, T);
     c.conv(a);
     launch_attention(qkv, qkv + (size_t)hid * T, qkv + (size_t)2 * hid * T, att, B, heads, kc, T, T,
-                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, asplit, s, c.dev_err);
+                     (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, asplit, s, c.dev_err, L.att.word,
+                     ++c.launch_seq, L.att.h3());
     c.flops += attention_flops(B, heads, kc, T);
     a = conv1d_args(L.o, att, tmp, B, T, T);
     conv_set_res(a, x, hid, T);
@@ -400,6 +402,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
             pa.w2 = (S.c2[j][mi].w_h3 && S.c2[j][mi].h3_ok && *S.c2[j][mi].h3_ok) ? S.c2[j][mi].w_h3 : nullptr;
             pa.b1 = S.c1[j][mi].bias;
             pa.b2 = S.c2[j][mi].bias;
+            pa.ovf_layer = S.c1[j][mi].ovf_word;
             pa.lens = lout;
             pa.B = db;
             pa.C = S.ch;

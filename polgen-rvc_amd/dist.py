@@ -73,6 +73,11 @@ def broadcast_weights(ctx, device_index: int = 0, src: int = 0, force: bool = Fa
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return nbytes
     on_gpu = dist.get_backend() == "nccl"
+    if not on_gpu and getattr(ctx, "regions_on_device", False):
+        # weights_regions() of a real context hands out hipMalloc'd addresses: wrapping them as host memory for a CPU
+        # backend would read and write HBM addresses from the CPU
+        raise RuntimeError(f"broadcast_weights: backend {dist.get_backend()!r} cannot move device-resident weight "
+                           "regions; use backend 'nccl' (RCCL) for rvcx contexts")
     dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")
     sizes_hash = 1469598103934665603
     for _, n in regions:

@@ -16,6 +16,11 @@ import struct
 import numpy as np
 
 
+class UnsupportedIndex(ValueError):
+    """A well-formed FAISS file of a kind (or with an option) rvcx does not implement.  faiss would read and search
+    it, so the caller must hear about it -- unlike a corrupt file, which the reference swallows too."""
+
+
 class _R:
     def __init__(self, b):
         self.b, self.o = b, 0
@@ -73,10 +78,10 @@ def _read_index(r):
         dm_type = r.take("B")                # direct map
         r.vec(np.int64)
         if dm_type == 2:
-            raise ValueError("hashtable direct map not supported")
+            raise UnsupportedIndex("hashtable direct map not supported")
         il = r.fourcc()
         if il != "ilar":
-            raise ValueError(f"unsupported inverted lists {il!r}")
+            raise UnsupportedIndex(f"unsupported inverted lists {il!r}")
         nl, code_size = r.take("Q"), r.take("Q")
         lt = r.fourcc()
         if lt == "full":
@@ -86,9 +91,9 @@ def _read_index(r):
             sizes = np.zeros(nl, np.uint64)
             sizes[sp[0::2].astype(np.int64)] = sp[1::2]
         else:
-            raise ValueError(f"unsupported list type {lt!r}")
+            raise UnsupportedIndex(f"unsupported list type {lt!r}")
         if code_size != 4 * d or nl != nlist:
-            raise ValueError("IVF inverted lists are not flat float32 codes")
+            raise UnsupportedIndex("IVF inverted lists are not flat float32 codes")
         out = np.zeros((ntotal, d), np.float32)
         assign = np.full(ntotal, -1, np.int32)
         for li, sz in enumerate(sizes):
@@ -103,7 +108,9 @@ def _read_index(r):
         if (assign < 0).any():
             raise ValueError("IVF index: stored ids are not 0..ntotal-1 (reconstruct_n would fail in the reference too)")
         return out, dict(centroids=centroids, assign=assign, nprobe=int(nprobe))
-    raise ValueError(f"unsupported FAISS index type {cc!r}")
+    if cc[:1] == "I" and cc.isprintable():          # some other faiss index class ("IwPQ", "IxPq", "IHNf", ...)
+        raise UnsupportedIndex(f"unsupported FAISS index type {cc!r} (rvcx reads IndexFlat and IndexIVFFlat files)")
+    raise ValueError(f"not a FAISS index file (starts with {cc!r})")
 
 
 def read_index(path: str) -> IndexFile:

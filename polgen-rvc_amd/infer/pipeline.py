@@ -3,6 +3,7 @@ signatures, backed by librvcx.so (HIP, gfx950).  Everything between the float64 
 the int16 output array runs on the GPU through the C ABI; there is no CPU fallback.
 
 Differences that are deliberate and documented:
+  * ``f0_file``: read like the reference (an object with ``.name``; rows "time,f0"), applied on the device.
   * ``f0_method``: "rmvpe+" (with its BASELINE alias "rmvpe") and "fcpe" are implemented; "mangio-crepe" raises
     ValueError, as does anything else (the reference hits an accidental UnboundLocalError, pipeline.py:152-183).
   * ``filter_radius`` / ``hop_length`` are accepted and unused, as in the reference for rmvpe+ and fcpe.
@@ -14,6 +15,7 @@ Differences that are deliberate and documented:
 from __future__ import annotations
 
 import os
+import zlib
 
 import numpy as np
 
@@ -122,31 +124,11 @@ class VC:
         self._check_method(f0_method)
         ctx = self._ensure_f0_model(f0_method)
         x = _np(x, np.float32)
-        if inp_f0 is None:
-            p = self._params(pitch, 0, 1, 0.5, f0_min, f0_max, f0_method=f0_method)
-            coarse, f0 = ctx.get_f0_fcpe_x(x, p_len, p) if f0_method == "fcpe" else ctx.get_f0_x(x, p)
-            return coarse.astype(np.int64), f0.astype(np.float64)
-        # f0 file (pipeline.py:185-191): the estimate is patched on the host, then quantised exactly as the
-        # reference does (numpy float64).  rvc_infer never takes this branch (f0_file=None, infer.py:149).
-        if f0_method == "fcpe":
-            f0 = ctx.get_f0_fcpe_x(x, p_len, self._params(0, 0, 1, 0.5, f0_min, f0_max, f0_method="fcpe"))[1].astype(np.float64)
-        else:
-            f0 = self.get_f0_rmvpe(x, f0_min=f0_min, f0_max=f0_max)
-        f0 *= pow(2, pitch / 12)
-        tf0 = self.sample_rate // self.window
-        inp_f0 = np.asarray(inp_f0, dtype=np.float64)
-        delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
-        replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
-        shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
-        f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
-        f0_mel_min = 1127 * np.log(1 + f0_min / 700)
-        f0_mel_max = 1127 * np.log(1 + f0_max / 700)
-        f0bak = f0.copy()
-        f0_mel = 1127 * np.log(1 + f0 / 700)
-        f0_mel[f0_mel > 0] = (f0_mel[f0_mel > 0] - f0_mel_min) * 254 / (f0_mel_max - f0_mel_min) + 1
-        f0_mel[f0_mel <= 1] = 1
-        f0_mel[f0_mel > 255] = 255
-        return np.rint(f0_mel).astype(int), f0bak
+        # the whole of get_f0 -- F0 model, pitch shift, the optional f0-file table (pipeline.py:185-191), coarse
+        # quantisation -- runs behind the C ABI (rvcx_get_f0_x_ex); rvc_infer never passes inp_f0 (f0_file=None, infer.py:149)
+        p = self._params(pitch, 0, 1, 0.5, f0_min, f0_max, f0_method=f0_method)
+        coarse, f0 = ctx.get_f0_x_ex(x, p_len, p, None if inp_f0 is None else _np(inp_f0, np.float32))
+        return coarse.astype(np.int64), f0.astype(np.float64)
 
     def vc(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect, *,
            z_noise=None, src_noise=None):
@@ -174,8 +156,14 @@ class VC:
     @staticmethod
     def _make_resident(ctx, index, big_npy):
         """vc() was handed an index the context may not hold (callers other than pipeline())."""
-        key = index.key if isinstance(index, IndexHandle) else ("array", id(big_npy))
-        if _INDEX_RESIDENT.get(id(ctx)) == key:
+        if isinstance(index, IndexHandle):
+            key = index.key
+        elif isinstance(big_npy, np.ndarray):
+            # an array is identified by what it holds, never by id(): a new array at a recycled id is a new index
+            key = ("array", big_npy.shape, str(big_npy.dtype), zlib.crc32(np.ascontiguousarray(big_npy).view(np.uint8)))
+        else:
+            key = None
+        if key is not None and _INDEX_RESIDENT.get(id(ctx)) == key:
             return
         if isinstance(big_npy, np.ndarray):
             ctx.load_index(big_npy)
@@ -192,13 +180,16 @@ class VC:
                 ctx.load_index(None)
                 _INDEX_RESIDENT[id(ctx)] = None
             return None, None
+        from ..index_io import UnsupportedIndex, read_index
         try:
             key = _state.file_key(file_index)
             if _INDEX_RESIDENT.get(id(ctx)) != key:
-                from ..index_io import read_index
                 ix = read_index(file_index)
                 big_npy = ix.vectors
                 if ix.is_ivf:       # RVC's "IVF{n},Flat" files: searched like faiss does, nprobe from the file
+                    if ix.nprobe != 1:
+                        raise UnsupportedIndex(f"IVF index with nprobe = {ix.nprobe}: rvcx searches nprobe = 1 only "
+                                               "(what RVC training writes)")
                     ctx.load_index_ivf(big_npy, ix.centroids, ix.assign, ix.nprobe)
                 else:
                     ctx.load_index(big_npy)
@@ -206,7 +197,12 @@ class VC:
                 ctx._index_shape = big_npy.shape
             n, d = getattr(ctx, "_index_shape", (0, 0))
             return IndexHandle(ctx, key, n, d), True
-        except Exception as e:  # noqa: BLE001 -- same degrade-to-None behaviour as the reference
+        except UnsupportedIndex:
+            # a file faiss would have read and searched: converting WITHOUT the index would silently change the result
+            ctx.load_index(None)
+            _INDEX_RESIDENT[id(ctx)] = None
+            raise
+        except Exception as e:  # noqa: BLE001 -- unreadable file: same degrade-to-None behaviour as the reference
             print(f"Error reading the FAISS index: {e}")
             ctx.load_index(None)
             _INDEX_RESIDENT[id(ctx)] = None
@@ -233,9 +229,14 @@ class VC:
             raise ValueError("non-f0 models cannot run in the reference either (generators.py:57-77)")
         if version != "v2":
             raise ValueError("only RVC v2 voice models are supported")
-        if f0_file is not None:
-            raise ValueError("f0 files are not supported by pipeline() (rvc_infer always passes None, infer.py:149); "
-                             "use get_f0(inp_f0=...) + vc()")
+        inp_f0 = None
+        if f0_file and hasattr(f0_file, "name"):              # pipeline.py:349-360 (failures are printed and ignored)
+            try:
+                with open(f0_file.name, "r") as f:
+                    lines = f.read().strip("\n").split("\n")
+                inp_f0 = np.array([[float(i) for i in line.split(",")] for line in lines], dtype="float32")
+            except Exception as e:  # noqa: BLE001
+                print(f"Error reading the F0 file: {e}")
         if resample_sr >= self.sample_rate and tgt_sr != resample_sr:
             raise ValueError("resample_sr is hard-wired to 0 by rvc_infer (infer.py:144)")
         ctx = net_g.ctx
@@ -249,7 +250,8 @@ class VC:
         clips = [a if _np(a).dtype == np.float64 else _np(a, np.float32) for a in map(_np, audios)]
         if not all(c.dtype == clips[0].dtype for c in clips):
             clips = [c.astype(np.float64) for c in clips]
-        res = ctx.convert_batch(net_g.model_id, clips, p, noise, want_f32=return_f32)
+        res = ctx.convert_batch(net_g.model_id, clips, p, noise, want_f32=return_f32,
+                                inp_f0=None if inp_f0 is None else [inp_f0] * len(clips))
         if _single:
             return (res[0][0], res[1][0]) if return_f32 else res[0]
         return res

@@ -274,18 +274,19 @@ def test_load_audio_resamples_other_rates(tmp_path):
 
 
 def test_bench_refuses_more_gpus_than_visible():
-    """bench.py --gpus N must stop before touching anything when the node does not have N GPUs (this container: 0)
-    or when it was not started one process per GPU."""
+    """bench.py --gpus N must stop before touching anything when the node does not have N GPUs (this container: 0),
+    as a torch.distributed.run worker and as its own launcher (tests/test_dist_gloo.py drives the launcher itself)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    # invoked plainly (no WORLD_SIZE) it launches its own ranks -- but never past the visible GPU count
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
 
 
 def test_fcpe_cfg_is_read_off_the_checkpoint():
@@ -316,3 +317,85 @@ def _fcpe_shapes(cfg):
         s[p + ".attn.fast_attention.projection_matrix"] = (266, 64)
         s[p + ".conformer.net.4.conv.weight"] = (2 * C, 1, 31)
     return s
+
+
+def test_f0_file_track_equals_numpy_interp():
+    """VC.get_f0's f0-file branch (pipeline.py:186-189) behind the C ABI: delta_t in float32 arithmetic, np.interp in
+    float64 -- bit for bit what numpy gives on the same table (host code of librvcx.so, no GPU call)."""
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import _lib
+    g = np.random.Generator(np.random.PCG64(17))
+    for rows in (1, 2, 7, 300):
+        t = np.sort(g.uniform(0.0, 4.0, rows)).astype(np.float32)
+        if rows > 3:
+            t[3] = t[2]                                            # a repeated time stamp
+        tab = np.stack([t, g.uniform(80.0, 400.0, rows).astype(np.float32)], 1)
+        delta_t = np.round((tab[:, 0].max() - tab[:, 0].min()) * 100 + 1).astype("int16")
+        want = np.interp(list(range(delta_t)), tab[:, 0] * 100, tab[:, 1])
+        got = _lib.f0_file_track(tab)
+        assert got.shape == want.shape and np.array_equal(got, want), rows
+    # and the oracle's get_f0 tail uses exactly that track
+    f0 = np.full(500, 100.0)
+    tab = np.array([[0.0, 200.0], [1.0, 300.0]], np.float32)
+    coarse, bak = OP.f0_to_coarse(f0, 0.0, 50, 1100, tab, 1)
+    assert bak[99] == 100.0 and bak[100] == 200.0 and bak[200] == 300.0 and bak[201] == 100.0
+    assert coarse[150] == OP.f0_to_coarse(np.array([250.0]), 0.0)[0][0]
+
+
+def test_unsupported_index_files_raise_instead_of_converting_without_index(tmp_path):
+    """an index faiss would read and search but rvcx does not implement (other index classes, IVF with
+    nprobe != 1) must not degrade silently to "no index"; a corrupt file does, like the reference (pipeline.py:321-326)."""
+    import struct
+    import faiss_writer as FW
+    from polgen_rvc_amd.infer.pipeline import VC
+
+    class FakeCtx:
+        def __init__(self):
+            self.loaded = []
+
+        def load_index(self, a):
+            self.loaded.append(None if a is None else "flat")
+
+        def load_index_ivf(self, *a):
+            self.loaded.append("ivf")
+    vc = VC(48000, I.Config())
+    big = S.make_index(64, 8, 0)
+    cent = big[:4].copy()
+    assign = (np.arange(64) % 4).astype(np.int32)
+    p2 = os.path.join(tmp_path, "nprobe2.index")
+    open(p2, "wb").write(FW.ivf_flat_bytes(big, cent, assign, nprobe=2))
+    with pytest.raises(index_io.UnsupportedIndex):
+        vc._load_index(FakeCtx(), p2, 0.5)
+    pq = os.path.join(tmp_path, "pq.index")
+    open(pq, "wb").write(b"IwPQ" + struct.pack("<iqqqBi", 8, 64, 1 << 20, 1 << 20, 1, 1))
+    with pytest.raises(index_io.UnsupportedIndex):
+        vc._load_index(FakeCtx(), pq, 0.5)
+    bad = os.path.join(tmp_path, "garbage.index")
+    open(bad, "wb").write(b"\x00\x01\x02")
+    c = FakeCtx()
+    assert vc._load_index(c, bad, 0.5) == (None, None) and c.loaded[-1] is None
+    ok = os.path.join(tmp_path, "ok.index")
+    open(ok, "wb").write(FW.ivf_flat_bytes(big, cent, assign, nprobe=1))
+    c = FakeCtx()
+    h, flag = vc._load_index(c, ok, 0.5)
+    assert h is not None and flag is True and c.loaded == ["ivf"]
+
+
+def test_broadcast_refuses_device_regions_on_a_cpu_backend():
+    """dist._view must never wrap hipMalloc'd addresses as host memory."""
+    import torch.distributed as dist
+
+    class Ctx:
+        regions_on_device = True
+
+        def weights_regions(self):
+            return [(0x7F0000000000, 4096)], 1
+    if dist.is_initialized():
+        pytest.skip("a process group is already up")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(RuntimeError, match="device-resident"):
+            D.broadcast_weights(Ctx(), 0, 0, force=True)
+    finally:
+        dist.destroy_process_group()
