@@ -77,7 +77,8 @@ typedef struct {
   int32_t x_pad, x_query, x_center, x_max; /* seconds */
   uint64_t seed;          /* Philox seed for the two Gaussian draws when noise == NULL */
   int32_t f0_method;      /* RVCX_F0_RMVPE ("rmvpe" / "rmvpe+", pipeline.py:142-167) or RVCX_F0_FCPE ("fcpe", :169-181) */
-  int32_t reserved;
+  int32_t resample_sr;    /* VC.pipeline's resample_sr (pipeline.py:453-454): >= 16000 and != tgt_sr resamples the output
+                             before the peak normalisation; 0 (what rvc_infer passes, infer.py:144) = off */
 } rvcx_params;
 enum { RVCX_F0_RMVPE = 0, RVCX_F0_FCPE = 1 };
 
@@ -226,6 +227,12 @@ int rvcx_get_f0_x_ex(rvcx_ctx*, const float* x_hd, int64_t n, int64_t p_len, con
 /* host only (no GPU needed): the 100 Hz track VC.get_f0 builds from an f0 file's rows (pipeline.py:186-189: delta_t in
  * float32, np.interp in float64).  Writes min(count, cap) values, returns count. */
 int rvcx_f0_file_track(const float* inp_f0, int rows, double* track, int cap);
+/* librosa.resample(librosa.to_mono(audio.T), orig_sr=sr_in, target_sr=sr_out) of load_audio (rvc/lib/my_utils.py:9-13):
+ * x = (frames, channels) interleaved float64 (host or device), y = rvcx_resample_len(frames, ...) mono float64 samples.
+ * Band-limited sinc interpolation with resampy's published "kaiser_best" filter (csrc/audio.hip; soxr, librosa's
+ * current default, is not published as a formula: parity unpinned). */
+int64_t rvcx_resample_len(int64_t n, int sr_in, int sr_out);
+int rvcx_resample_f64(rvcx_ctx*, const double* x_hd, int64_t frames, int channels, int sr_in, int sr_out, double* y_hd);
 /* VC.vc(model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version="v2", protect) --
  * rvc/infer/pipeline.py:203-287: HuBERT -> (retrieval blend with the resident index when index_rate != 0) ->
  * x2 upsample / protect mix -> Synthesizer.infer.  audio0 (n samples of audio_pad); pitch / pitchf (n_pitch
@@ -308,6 +315,15 @@ int rvcx_op_convtranspose2d(rvcx_ctx*, const float* x, const float* w, const flo
 int rvcx_op_attention(rvcx_ctx*, const float* q, const float* k, const float* v, float* out, int B,
                       int H, int D, int T, float scale, const float* emb_rel_k,
                       const float* emb_rel_v, int window, const int32_t* lens);
+/* The time-major Linear kernel of the transformer sections (csrc/gemm.hip): x_cf (B, Cin, T) is turned into rows
+ * r = b T + t (split form, or fp32 when exact_fp32), y = act(x W^T + bias) + res.  w (Cout, Cin); res_tm (B T, Cout) or
+ * NULL; act as in rvcx_op_conv1d (0 none, 2 relu, 3 gelu).  Outputs, each (B T, Cout) unless noted: y_tm; y_cf
+ * (B, Cout, T) or NULL; y_split = the split-form output decoded to fp32 (hi + lo) or NULL. */
+int rvcx_op_gemm_tm(rvcx_ctx*, const float* x_cf, const float* w, const float* bias, const float* res_tm, int B, int T,
+                    int Cin, int Cout, int act, int exact_fp32, float* y_tm, float* y_cf, float* y_split);
+/* LayerNorm of time-major rows (rows, C): fp32 result and the decoded split-form result (NULL to skip) */
+int rvcx_op_layernorm_tm(rvcx_ctx*, const float* x, const float* gamma, const float* beta, float* y, float* y_split,
+                         int64_t rows, int C, float eps);
 /* LayerNorm over channels of (B,C,T) */
 int rvcx_op_layernorm_c(rvcx_ctx*, const float* x, const float* gamma, const float* beta, float* y,
                         int B, int C, int T, float eps);

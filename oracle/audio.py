@@ -1,0 +1,98 @@
+"""TEST INFRASTRUCTURE (CPU oracle) -- audio I/O edges of the path: ``load_audio`` (rvc/lib/my_utils.py:5-16), the
+``librosa.resample`` calls at my_utils.py:12-13 and rvc/infer/pipeline.py:453-454, and ``convert_to_stereo``
+(rvc/scripts/voice_conversion.py:45-51).
+
+PARITY UNPINNED: ``librosa`` / ``soxr`` / ``resampy`` / ``soundfile`` are third-party packages that are neither vendored
+in /root/reference nor installed here (the reference does not even pin a librosa version: requirements.txt lists none).
+``librosa.resample``'s default ``res_type`` is "soxr_hq" since librosa 0.10 and was "kaiser_best" before; soxr's filter
+design is not published as a formula, resampy's is.  This file restates **resampy's "kaiser_best"** band-limited sinc
+interpolation (Smith's algorithm as published with resampy: a Kaiser-windowed sinc with num_zeros = 64, 2**9 table
+samples per zero crossing, roll-off 0.9475937167399596, beta 14.769656459379492, linear interpolation between table
+samples, output length int(n * ratio)) from its published description.  The product's resampler (csrc/audio.hip) is
+tested against this restatement; neither is checked against soxr.
+
+Only tests/ (and tools/) may import this module."""
+from __future__ import annotations
+
+import numpy as np
+
+KAISER_BEST = dict(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=14.769656459379492)
+
+
+def sinc_window(num_zeros: int, precision: int, rolloff: float, beta: float):
+    """Right half of the Kaiser-windowed sinc interpolation filter: num_zeros * 2**precision + 1 samples."""
+    num_bits = 2 ** precision
+    n = num_bits * num_zeros
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    taper = np.kaiser(2 * n + 1, beta)[n:]
+    return taper * sinc_win, num_bits
+
+
+def resample_kaiser_best(x: np.ndarray, sr_orig: int, sr_new: int) -> np.ndarray:
+    """1-D band-limited sinc interpolation (the published resampy algorithm), float64 arithmetic."""
+    x = np.asarray(x, dtype=np.float64)
+    ratio = float(sr_new) / float(sr_orig)
+    n_out = int(x.shape[0] * ratio)
+    interp_win, num_table = sinc_window(**KAISER_BEST)
+    if ratio < 1:
+        interp_win = interp_win * ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    scale = min(1.0, ratio)
+    time_increment = 1.0 / ratio
+    index_step = int(scale * num_table)
+    nwin = interp_win.shape[0]
+    n_orig = x.shape[0]
+    y = np.zeros(n_out, dtype=np.float64)
+    t = np.arange(n_out, dtype=np.float64) * time_increment
+    n = t.astype(np.int64)
+    # left wing: samples x[n - i], i = 0 .. i_max - 1
+    frac = scale * (t - n)
+    index_frac = frac * num_table
+    offset = index_frac.astype(np.int64)
+    eta = index_frac - offset
+    i_max = np.minimum(n + 1, (nwin - offset) // index_step)
+    for i in range(int(i_max.max()) if n_out else 0):
+        live = i < i_max
+        idx = np.where(live, offset + i * index_step, 0)
+        w = interp_win[idx] + eta * interp_delta[idx]
+        y += np.where(live, w * x[np.where(live, n - i, 0)], 0.0)
+    # right wing: samples x[n + k + 1], k = 0 .. k_max - 1
+    frac = scale - frac
+    index_frac = frac * num_table
+    offset = index_frac.astype(np.int64)
+    eta = index_frac - offset
+    k_max = np.minimum(n_orig - n - 1, (nwin - offset) // index_step)
+    for k in range(int(k_max.max()) if n_out else 0):
+        live = k < k_max
+        idx = np.where(live, offset + k * index_step, 0)
+        w = interp_win[idx] + eta * interp_delta[idx]
+        y += np.where(live, w * x[np.where(live, n + k + 1, 0)], 0.0)
+    return y
+
+
+def to_mono(audio: np.ndarray) -> np.ndarray:
+    """librosa.to_mono(audio.T) of a (frames, channels) array as soundfile returns it (my_utils.py:10-11)."""
+    a = np.asarray(audio, dtype=np.float64)
+    return a if a.ndim == 1 else a.mean(axis=1)
+
+
+def load_audio_from_array(audio: np.ndarray, sr: int, sample_rate: int) -> np.ndarray:
+    """my_utils.py:9-16 after ``sf.read``: mono mean -> resample (when the rates differ) -> flatten."""
+    a = to_mono(audio)
+    if sr != sample_rate:
+        a = resample_kaiser_best(a, sr, sample_rate)
+    return a.flatten()
+
+
+def convert_to_stereo_array(y: np.ndarray) -> np.ndarray:
+    """voice_conversion.py:45-51 on the array librosa.load(sr=None, mono=False) returns ((frames,) for mono files,
+    (channels, frames) otherwise): mono is doubled; the reference's second branch tests ``y.ndim > 2``, which a
+    (channels, frames) array never satisfies, so files with more than two channels keep all of them.  Returns
+    (frames, channels) as handed to sf.write."""
+    y = np.asarray(y)
+    if y.ndim == 1:
+        y = np.vstack([y, y])
+    elif y.ndim > 2:
+        y = y[:2, :]
+    return y.T

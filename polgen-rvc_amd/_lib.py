@@ -58,7 +58,7 @@ class Params(C.Structure):
                 ("index_rate", C.c_float), ("protect", C.c_float), ("volume_envelope", C.c_float),
                 ("sid", C.c_int32), ("x_pad", C.c_int32), ("x_query", C.c_int32),
                 ("x_center", C.c_int32), ("x_max", C.c_int32), ("seed", C.c_uint64),
-                ("f0_method", C.c_int32), ("reserved", C.c_int32)]
+                ("f0_method", C.c_int32), ("resample_sr", C.c_int32)]
 
 
 class UttExtra(C.Structure):
@@ -81,7 +81,8 @@ SYMBOLS = [
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
-    "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track",
+    "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
+    "rvcx_resample_len", "rvcx_resample_f64",
 ]
 
 
@@ -101,6 +102,7 @@ def lib() -> C.CDLL:
         _lib.rvcx_fp32_reruns.restype = C.c_int64
         _lib.rvcx_fp32_layers.restype = C.c_int64
         _lib.rvcx_gru_fallbacks.restype = C.c_int64
+        _lib.rvcx_resample_len.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
     return _lib
 
@@ -281,6 +283,29 @@ class Context:
         self._ck(lib().rvcx_op_attention(self._h, _p(q), _p(k), _p(v), _p(out), B, heads, D, T, C.c_float(scale),
                                          _p(ek), _p(ev), window, _p(li, C.c_int32)), "op_attention")
         return out
+
+    def gemm_tm(self, x_cf, w, bias=None, res_tm=None, act=0, exact_fp32=False):
+        """the time-major Linear kernel: x_cf (B, Cin, T) -> (y_tm (B*T, Cout), y_cf (B, Cout, T), y_split decoded)"""
+        x_cf, w = f32(x_cf), f32(w)
+        B, Cin, T = x_cf.shape
+        Cout = w.shape[0]
+        bias = None if bias is None else f32(bias)
+        res = None if res_tm is None else f32(res_tm)
+        y = np.empty((B * T, Cout), np.float32)
+        ycf = np.empty((B, Cout, T), np.float32)
+        ysp = np.empty((B * T, Cout), np.float32) if Cout % 16 == 0 else None
+        self._ck(lib().rvcx_op_gemm_tm(self._h, _p(x_cf), _p(w), _p(bias), _p(res), B, T, Cin, Cout, int(act),
+                                       1 if exact_fp32 else 0, _p(y), _p(ycf), _p(ysp)), "op_gemm_tm")
+        return y, ycf, ysp
+
+    def layernorm_tm(self, x, gamma, beta, eps=1e-5):
+        x = f32(x)
+        rows, Cc = x.shape
+        y = np.empty_like(x)
+        ysp = np.empty_like(x) if Cc % 16 == 0 else None
+        self._ck(lib().rvcx_op_layernorm_tm(self._h, _p(x), _p(f32(gamma)), _p(f32(beta)), _p(y), _p(ysp),
+                                            C.c_int64(rows), Cc, C.c_float(eps)), "op_layernorm_tm")
+        return y, ysp
 
     def layernorm_c(self, x, gamma, beta, eps=1e-5):
         x = f32(x)
@@ -554,6 +579,16 @@ class Context:
                                         C.byref(got)), "get_f0_x_ex")
         return coarse[:got.value].copy(), f0[:got.value].copy()
 
+    def resample(self, audio, sr_in: int, sr_out: int) -> np.ndarray:
+        """librosa.resample(librosa.to_mono(audio.T), sr_in -> sr_out): audio (frames,) or (frames, channels) -> float64 mono"""
+        a = np.ascontiguousarray(audio, dtype=np.float64)
+        frames, ch = a.shape[0], (1 if a.ndim == 1 else a.shape[1])
+        n_out = int(lib().rvcx_resample_len(C.c_int64(frames), int(sr_in), int(sr_out)))
+        y = np.empty(max(n_out, 0), np.float64)
+        self._ck(lib().rvcx_resample_f64(self._h, _p(a, C.c_double), C.c_int64(frames), ch, int(sr_in), int(sr_out),
+                                         _p(y, C.c_double)), "resample_f64")
+        return y
+
     def vc_frames(self, n: int) -> int:
         return int(lib().rvcx_vc_frames(self._h, C.c_int64(n)))
 
@@ -594,11 +629,11 @@ class Context:
         self._ck(lib().rvcx_weights_adopt(self._h), "weights_adopt")
 
     def conv_profile_begin(self):
-        z = (C.c_int64 * 56)()
+        z = (C.c_int64 * 64)()
         self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, None, 0), "conv_profile")
 
     def conv_profile_end(self):
-        N = 56
+        N = 64
         la, fl, ms = (C.c_int64 * N)(), (C.c_double * N)(), (C.c_double * N)()
         bm, bn, kd = (C.c_int32 * N)(), (C.c_int32 * N)(), (C.c_int32 * N)()
         self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, kd, N), "conv_profile")
@@ -606,6 +641,10 @@ class Context:
         def name(i):
             if kd[i] < 0:
                 return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
+            if kd[i] == 600001:
+                return "gemm_f32<64,64> (time-major Linear, exact fp32)"
+            if kd[i] >= 600000:
+                return f"gemm_h3<{bm[i]},{bn[i]}> (time-major Linear)"
             if kd[i] >= 500000:
                 return f"resblock_pair<C={kd[i] - 500000},N1={bn[i]}> (c1 -> c2 -> +x fused)"
             if kd[i] >= 400000:

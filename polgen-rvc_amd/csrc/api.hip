@@ -93,6 +93,7 @@ static int api_call(rvcx_ctx* ctxp, bool repeat, F&& body) {
         if (!localize_overflow(*C)) attempt = last - 1;     // nobody to pin: everything on fp32 next
         continue;
       }
+      if (attempt > 0 && attempt == last) (void)C->take_overflow();   // producers of split tensors may have re-raised the bit
       break;
     }
     return 0;
@@ -790,6 +791,76 @@ int rvcx_op_attention(rvcx_ctx* ctx, const float* q, const float* k, const float
   API_END
 }
 
+// host view of split rows: hi + (S lo) / S
+static void decode_xs(const std::vector<uint16_t>& raw, long rows, int Cc, float* out) {
+  for (long r = 0; r < rows; ++r)
+    for (int c = 0; c < Cc; ++c) {
+      const size_t e = ((size_t)r * Cc * 2) + (size_t)(c >> 4) * 32 + ((c >> 3) & 1) * 8 + (c & 7);
+      out[(size_t)r * Cc + c] = half_to_float(raw[e]) + half_to_float(raw[e + 16]) / 256.f;
+    }
+}
+
+int rvcx_op_gemm_tm(rvcx_ctx* ctx, const float* x_cf, const float* w, const float* bias, const float* res_tm, int B,
+                    int T, int Cin, int Cout, int act, int exact_fp32, float* y_tm, float* y_cf, float* y_split) {
+  API_BEGIN(ctx)
+  TEMP_REGION(C);
+  const long R = (long)B * T;
+  C->arena.reserve(((size_t)R * (3 * (size_t)Cin + 4 * (size_t)Cout)) * 4 + (64 << 20));
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  ConvW L = make_conv(*C, w, bias, Cout, Cin, 1, 1, true);
+  float* dx = to_dev(*C, x_cf, (size_t)R * Cin);
+  float* xf = C->arena.alloc<float>((size_t)R * Cin);
+  float* xs = C->arena.alloc<float>((size_t)R * L.cin_gp);
+  RVCX_HIP(hipMemsetAsync(xs, 0, (size_t)R * L.cin_gp * 4, s));
+  const bool h3 = !exact_fp32 && conv_h3_ok(L) && gemm_h3_enabled() && Cin % 4 == 0;
+  launch_cf_to_tm(dx, (long)Cin * T, xf, Cin, h3 ? xs : nullptr, (long)L.cin_gp * 4, B, Cin, T, C->dev_err, nullptr, 0, s);
+  GemmArgs g = gemm_args(L, R, T);
+  if (h3) g.xs = xs, g.ld_xs = (long)L.cin_gp * 4;
+  else g.w_h3 = nullptr, g.x = xf, g.ld_x = Cin;
+  g.act = act;
+  if (res_tm) g.res = to_dev(*C, res_tm, (size_t)R * Cout), g.ld_res = Cout;
+  float* dy = C->arena.alloc<float>((size_t)R * Cout);
+  float* dc = C->arena.alloc<float>((size_t)R * Cout);
+  float* ds = C->arena.alloc<float>((size_t)R * Cout);
+  RVCX_HIP(hipMemsetAsync(dy, 0xff, (size_t)R * Cout * 4, s));
+  RVCX_HIP(hipMemsetAsync(dc, 0xff, (size_t)R * Cout * 4, s));
+  g.y = dy, g.ld_y = Cout;
+  if (y_cf) g.y_cf = dc, g.cf_bs = (long)Cout * T;
+  if (y_split && Cout % 16 == 0) g.ys = ds, g.ld_ys = (long)Cout * 4;
+  C->gemm_on(g, s);
+  to_host(*C, y_tm, dy, (size_t)R * Cout);
+  if (y_cf) to_host(*C, y_cf, dc, (size_t)R * Cout);
+  if (g.ys) {
+    std::vector<uint16_t> raw((size_t)R * Cout * 2);
+    RVCX_HIP(hipMemcpy(raw.data(), ds, raw.size() * 2, hipMemcpyDeviceToHost));
+    decode_xs(raw, R, Cout, y_split);
+  }
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_op_layernorm_tm(rvcx_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* y_split,
+                         int64_t rows, int Cc, float eps) {
+  API_BEGIN(ctx)
+  const size_t n = (size_t)rows * Cc;
+  C->arena.reserve(n * 16 + (64 << 20));
+  C->arena.reset();
+  float* dx = to_dev(*C, x, n);
+  float* dy = C->arena.alloc<float>(n);
+  float* ds = C->arena.alloc<float>(n);
+  launch_layernorm_tm(dx, Cc, to_dev(*C, gamma, Cc), to_dev(*C, beta, Cc), dy, Cc, (y_split && Cc % 16 == 0) ? ds : nullptr,
+                      (long)Cc * 4, rows, Cc, eps, C->dev_err, nullptr, 0, C->stream);
+  to_host(*C, y, dy, n);
+  if (y_split && Cc % 16 == 0) {
+    std::vector<uint16_t> raw(n * 2);
+    RVCX_HIP(hipMemcpy(raw.data(), ds, raw.size() * 2, hipMemcpyDeviceToHost));
+    decode_xs(raw, rows, Cc, y_split);
+  }
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_op_layernorm_c(rvcx_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int B,
                         int Cc, int T, float eps) {
   API_BEGIN(ctx)
@@ -1198,6 +1269,27 @@ int rvcx_f0_file_track(const float* inp_f0, int rows, double* track, int cap) {
     g_last_error = e.what();
     return -1;
   }
+}
+
+int64_t rvcx_resample_len(int64_t n, int sr_in, int sr_out) {
+  return (sr_in > 0 && sr_out > 0 && n >= 0) ? (int64_t)resample_out_len((long)n, sr_in, sr_out) : -1;
+}
+
+int rvcx_resample_f64(rvcx_ctx* ctx, const double* x, int64_t frames, int channels, int sr_in, int sr_out, double* y) {
+  API_BEGIN(ctx)
+  if (!x || !y || frames <= 0 || channels < 1 || sr_in <= 0 || sr_out <= 0) fail("resample: bad argument");
+  const long n_out = resample_out_len((long)frames, sr_in, sr_out);
+  C->arena.reserve(((size_t)frames * channels + (size_t)n_out) * 8 + ((size_t)2 << 20));
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  double* dx = any_to_dev(*C, x, (size_t)frames * channels);
+  double* dy = C->arena.alloc<double>((size_t)std::max<long>(n_out, 1));
+  const ResampleFilter f = make_resample_filter(C->arena, sr_in, sr_out, s);
+  launch_resample_f64(f, dx, (long)frames, channels, dy, n_out, s);
+  RVCX_HIP(hipMemcpyAsync(y, dy, (size_t)n_out * 8, hipMemcpyDefault, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  C->arena.reset();
+  API_END
 }
 
 int rvcx_vc_frames(rvcx_ctx* ctx, int64_t n) {

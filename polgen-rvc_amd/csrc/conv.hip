@@ -1,6 +1,7 @@
 // Implicit-GEMM conv on v_mfma_f32_32x32x2_f32 -- see conv.h for the design.
 #include "conv.h"
 #include "conv_device.h"
+#include "gemm.h"
 
 #include <algorithm>
 #include <cmath>
@@ -195,6 +196,7 @@ void conv_profile_end(ConvProfile* out) {
   conv_fast_describe(out);
   conv_h3_describe(out);
   resblock_pair_describe(out);
+  gemm_describe(out);
   for (auto& r : g_prof) {
     RVCX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -225,6 +227,22 @@ void conv_launch_pair(const PairArgs& a, double flops, hipStream_t stream) {
   rec.cin = a.C; rec.cout = a.C; rec.k = a.k; rec.nout = a.T; rec.stride = a.dil; rec.B = a.B;
   RVCX_HIP(hipEventRecord(rec.a, stream));
   launch_resblock_pair(a, stream);
+  RVCX_HIP(hipEventRecord(rec.b, stream));
+  g_prof.push_back(rec);
+}
+
+void conv_launch_gemm(const GemmArgs& a, double flops, hipStream_t stream) {
+  if (!g_prof_on) {
+    launch_gemm(a, stream);
+    return;
+  }
+  ProfRec rec;
+  RVCX_HIP(hipEventCreate(&rec.a));
+  RVCX_HIP(hipEventCreate(&rec.b));
+  rec.flops = flops;
+  rec.cin = a.cin; rec.cout = a.cout; rec.k = 1; rec.nout = (int)a.rows; rec.stride = 1; rec.B = (int)(a.rows / a.T);
+  RVCX_HIP(hipEventRecord(rec.a, stream));
+  rec.tile = launch_gemm(a, stream);
   RVCX_HIP(hipEventRecord(rec.b, stream));
   g_prof.push_back(rec);
 }

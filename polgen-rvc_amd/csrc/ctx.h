@@ -5,6 +5,7 @@
 
 #include "common.h"
 #include "conv.h"
+#include "gemm.h"
 
 namespace rvcx {
 
@@ -228,6 +229,13 @@ struct Ctx {
     b.seq = ++launch_seq;
     conv_launch_pair(b, f, s);
   }
+  void gemm_on(GemmArgs a, hipStream_t s) {
+    const double f = 2.0 * (double)a.rows * a.cout * a.cin;
+    flops += f;
+    a.ovf = dev_err;
+    a.seq = ++launch_seq;
+    conv_launch_gemm(a, f, s);
+  }
   void conv(const ConvArgs& a) { conv_on(a, stream); }
   void conv_on(ConvArgs a, hipStream_t s) {
     flops += conv_flops(a);
@@ -277,6 +285,24 @@ inline AttFlag make_att_flag(Ctx& c) {
 
 ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups = 1,
                bool h3 = true);
+
+// may this layer run on the split-fp16 kernels right now?
+inline bool conv_h3_ok(const ConvW& w) { return w.w_h3 && w.h3_ok && *w.h3_ok && conv_h3_enabled(); }
+
+// a Linear (k = 1) layer as the time-major GEMM sees it (gemm.h); the caller adds the operands
+inline GemmArgs gemm_args(const ConvW& w, long rows, int T) {
+  GemmArgs a;
+  a.w_h3 = conv_h3_ok(w) ? w.w_h3 : nullptr;
+  a.w = w.w;
+  a.bias = w.bias;
+  a.cin = w.cin;
+  a.cin_p = w.cin_gp;
+  a.cout = w.cout;
+  a.cout_p = w.cout_gp;
+  a.rows = rows;
+  a.T = T;
+  return a;
+}
 
 // fill the channel/pad fields of ConvArgs from a packed layer
 inline void conv_set_weights(ConvArgs& a, const ConvW& w) {

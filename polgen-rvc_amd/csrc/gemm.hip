@@ -1,0 +1,314 @@
+// GEMM-shaped kernels for the Linear layers of the transformer sections (HuBERT q/k/v, out-proj, fc1, fc2 -- call site
+// rvc/infer/pipeline.py:228-236; the north star's "HuBERT transformer QKV/FFN MFMA GEMMs").
+//
+//     Y[r][co] = act( sum_k W[co][k] X[r][k] + bias[co] ) + R[r][co]         r = b T + t : batch folded into the rows
+//
+// Activations are TIME-MAJOR here: a row is one frame, its channels are contiguous -- LayerNorm becomes one wavefront
+// per row (ops.hip: layernorm_tm), and the B operand of the matrix cores (8 consecutive k per lane) is ONE 16-byte
+// load.  Between layers the activations travel already in the fp16 hi/lo split form the MFMAs consume
+// ("XS": row r = [chunk of 16 channels][op {hi, S lo}][h][8 halves], 64 bytes per chunk, the same bytes as fp32): the
+// producer's epilogue splits (and range-checks, conv.h: kH3ActLimit), the consumer stages with plain 16-byte copies.
+//
+// gemm_h3_kernel: fp32-grade products from three fp16 MFMAs (conv_h3.hip has the arithmetic), M = Cout from the layer's
+// existing fp16 hi/lo weight image, N = rows.  Tile BM x BN, 4 waves as 2 x 2, a stage = 2 chunks (32 channels) of both
+// operands, LDS double-buffered, ONE barrier per stage: while the MFMAs of stage s run, the registers fetched for stage
+// s + 1 are committed to the other buffer and the loads of stage s + 2 are issued.  No split-K: the k-order is
+// fixed, so every tile gives the same bits and a batched call equals its single runs.
+// gemm_f32_kernel: the exact-fp32 form (v_mfma_f32_32x32x2_f32) for layers pinned after an fp16-range overflow.
+#include <algorithm>
+#include <cstdlib>
+
+#include "conv.h"
+#include "conv_device.h"
+#include "gemm.h"
+#include "h3_device.h"
+
+namespace rvcx {
+
+namespace {
+
+constexpr int kKC = 2;                 // chunks of 16 channels per stage
+constexpr int kBnMax = 128;
+
+// One 32 x 32 accumulator tile -> the requested outputs.  Lane (j = lane & 31, hl = lane >> 5) owns row r0 + j and the
+// channels c0 + 8 g + 4 hl + q (g, q = 0..3): four runs of 4 consecutive channels = one 16-byte store per run (fp32
+// time-major) or one 8-byte hi + one 8-byte lo store (split form).
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int c0, long row, int hl, const f32x16& t, bool& ovf) {
+  if (row >= a.rows) return;
+  const bool live = !a.lens || (int)(row % a.T) < a.lens[row / a.T];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = c0 + 8 * g + 4 * hl;
+    if (c >= a.cout) continue;                       // cout is a multiple of 4 (checked by the launcher)
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = t[4 * g + q] + (a.bias ? a.bias[c + q] : 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act, 0.f);
+    if (a.res) {
+      const float4 r = *reinterpret_cast<const float4*>(a.res + row * a.ld_res + c);
+      v[0] += r.x;
+      v[1] += r.y;
+      v[2] += r.z;
+      v[3] += r.w;
+    }
+    if (!live) v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (a.y) *reinterpret_cast<float4*>(a.y + row * a.ld_y + c) = make_float4(v[0], v[1], v[2], v[3]);
+    if (a.y_cf) {                                    // channel-first (B, cout, T): what the attention kernels read
+      float* yc = a.y_cf + (row / a.T) * a.cf_bs + (long)c * a.T + row % a.T;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) yc[(long)q * a.T] = v[q];
+    }
+    if (a.ys) {
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      half4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ovf |= !(fabsf(v[q]) < kH3ActLimit);
+        const _Float16 vh = (_Float16)v[q];
+        hi[q] = vh;
+        lo[q] = (_Float16)((v[q] - (float)vh) * kH3Scale);
+      }
+      char* e = static_cast<char*>(a.ys) + row * a.ld_ys + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+      *reinterpret_cast<half4*>(e) = hi;
+      *reinterpret_cast<half4*>(e + 32) = lo;
+    }
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
+  constexpr int WM = BM / 64, WN = BN / 64;            // 4 waves as 2 x 2
+  constexpr int BNP = BN + 1;                           // odd pitch (in 16-byte elements): conflict-free commits
+  constexpr int A_ST = kKC * 4 * BM, B_ST = kKC * 4 * BNP;
+  constexpr int NA = kKC * 4 * BM / 256, NB = kKC * 4 * BN / 256;
+  static_assert(WM >= 1 && WN >= 1 && NA * 256 == kKC * 4 * BM && NB * 256 == kKC * 4 * BN, "bad tile");
+  extern __shared__ uint4 gemm_lds[];
+  uint4(*As)[A_ST] = reinterpret_cast<uint4(*)[A_ST]>(gemm_lds);                 // [buf][cl][op*2 + h][co]
+  uint4(*Bs)[B_ST] = reinterpret_cast<uint4(*)[B_ST]>(gemm_lds + 2 * A_ST);      // [buf][cl][op*2 + h][p]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.y * BM;
+  const long n0 = (long)blockIdx.x * BN;
+  const int nchunk = a.cin_p / 16;
+  const int nst = (nchunk + kKC - 1) / kKC;
+  const H3Rsrc wres = h3_rsrc(a.w_h3, nchunk * 4 * a.cout_p * 16);
+  // rows of this tile as one buffer: an offset past the last valid byte reads zeros (rows beyond `rows`, chunks
+  // beyond cin_p)
+  const long rows_here = a.rows - n0 < BN ? a.rows - n0 : BN;
+  const H3Rsrc xres = h3_rsrc(static_cast<const char*>(a.xs) + n0 * a.ld_xs, (int)(rows_here * a.ld_xs));
+  const int slab = 4 * a.cout_p * 16;
+
+  int a_off[NA], a_cl[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int e = tid + 256 * j;                        // (cl, oph, co)
+    const int co = e % BM, rest = e / BM;
+    a_cl[j] = rest >> 2;
+    a_off[j] = co0 + co < a.cout_p ? ((rest & 3) * a.cout_p + co0 + co) * 16 : kH3Oob;
+  }
+  int b_off[NB], b_dst[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = tid + 256 * j;                        // (p, cl, oph): 8 consecutive lanes = 128 contiguous bytes of a row
+    const int l8 = e & (4 * kKC - 1), p = e / (4 * kKC);
+    b_off[j] = p < rows_here ? p * a.ld_xs + l8 * 16 : kH3Oob;
+    b_dst[j] = l8 * BNP + p;
+  }
+  const int row_bytes = a.cin_p * 4;                    // bytes of a row that hold data
+
+  uint4 ra[NA], rb[NB];
+  auto fetch = [&](int st) {
+    const int c0 = st * kKC;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int ch = c0 + a_cl[j];
+      ra[j] = h3_load4(wres, (a_off[j] != kH3Oob && ch < nchunk) ? ch * slab + a_off[j] : kH3Oob);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = c0 * 64 + ((tid + 256 * j) & (4 * kKC - 1)) * 16;
+      rb[j] = h3_load4(xres, (b_off[j] != kH3Oob && col < row_bytes) ? b_off[j] + c0 * 64 : kH3Oob);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) As[buf][tid + 256 * j] = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) Bs[buf][b_dst[j]] = rb[j];
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  fetch(0);
+  commit(0);
+  if (nst > 1) fetch(1);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+#pragma unroll
+    for (int cl = 0; cl < kKC; ++cl) {
+      half8 af[3][WM], bf[2][WN];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        af[0][m] = __builtin_bit_cast(half8, As[buf][(cl * 4 + 0 + h) * BM + wr * (WM * 32) + m * 32 + i]);
+        af[2][m] = __builtin_bit_cast(half8, As[buf][(cl * 4 + 2 + h) * BM + wr * (WM * 32) + m * 32 + i]);
+        af[1][m] = af[0][m] * (_Float16)(1.f / kH3Scale);
+      }
+#pragma unroll
+      for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          bf[op][n] = __builtin_bit_cast(half8, Bs[buf][(cl * 4 + op * 2 + h) * BNP + wc * (WN * 32) + n * 32 + i]);
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          acc[m][n] = h3_mfma(af[0][m], bf[0][n], acc[m][n]);   // (S wh) xh
+          acc[m][n] = h3_mfma(af[1][m], bf[1][n], acc[m][n]);   // wh (S xl)
+          acc[m][n] = h3_mfma(af[2][m], bf[0][n], acc[m][n]);   // (S wl) xh
+        }
+    }
+    if (st + 1 < nst) {
+      commit(buf ^ 1);                    // stage st + 1 was fetched an iteration ago; nobody reads buffer buf ^ 1 now
+      if (st + 2 < nst) fetch(st + 2);
+      __syncthreads();
+    }
+  }
+
+  constexpr float inv = 1.f / kH3Scale;
+  bool ovf = false;
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] *= inv;
+      gemm_store_tile(a, co0 + wr * (WM * 32) + m * 32, n0 + wc * (WN * 32) + n * 32 + i, h, acc[m][n], ovf);
+    }
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
+}
+
+// Exact fp32 (v_mfma_f32_32x32x2_f32): 64 x 64 tile, 4 waves of 32 x 32, 32 channels per stage.  x is fp32 time-major.
+// Only layers pinned to fp32 after an fp16-range overflow run here.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
+  constexpr int KT = 32, P = 65;
+  __shared__ float As[KT][64];                          // [k][co]
+  __shared__ float Bs[KT][P];                           // [k][p]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.y * 64;
+  const long n0 = (long)blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < a.cin; k0 += KT) {
+    __syncthreads();
+    for (int e = tid; e < KT * 64; e += 256) {
+      const int k = e >> 6, c = e & 63;
+      As[k][c] = (k0 + k < a.cin && co0 + c < a.cout_p) ? a.w[(long)(k0 + k) * a.cout_p + co0 + c] : 0.f;
+    }
+    for (int e = tid; e < KT * 64; e += 256) {
+      const int p = e >> 5, k = e & 31;                 // 32 consecutive lanes = 128 contiguous bytes of a row
+      Bs[k][p] = (n0 + p < a.rows && k0 + k < a.cin) ? a.x[(n0 + p) * a.ld_x + k0 + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KT / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * s + h][wr * 32 + i], Bs[2 * s + h][wc * 32 + i], acc, 0, 0, 0);
+  }
+  bool ovf = false;
+  gemm_store_tile(a, co0 + wr * 32, n0 + wc * 32 + i, h, acc, ovf);
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
+}
+
+struct GemmCfg {
+  int bm, bn;
+  size_t lds;
+  void (*kern)(const GemmArgs);
+};
+template <int BM, int BN>
+constexpr GemmCfg gemm_cfg() {
+  return {BM, BN, (size_t)2 * kKC * 4 * (BM + BN + 1) * 16, gemm_h3_kernel<BM, BN>};
+}
+const GemmCfg kGemm[] = {gemm_cfg<128, 128>(), gemm_cfg<64, 128>(), gemm_cfg<128, 64>(), gemm_cfg<64, 64>()};
+constexpr int kNumGemm = sizeof(kGemm) / sizeof(kGemm[0]);
+
+}  // namespace
+
+bool gemm_h3_enabled() {
+  static const int mode = getenv("RVCX_GEMM") ? atoi(getenv("RVCX_GEMM")) : 1;
+  return mode != 0 && conv_h3_enabled();
+}
+
+constexpr int kGemmSlot0 = 53, kGemmF32Slot = 57;
+
+void gemm_describe(ConvProfile* p) {
+  for (int t = 0; t < kNumGemm; ++t) {
+    p->bm[kGemmSlot0 + t] = kGemm[t].bm;
+    p->bn[kGemmSlot0 + t] = kGemm[t].bn;
+    p->halo[kGemmSlot0 + t] = 600000;
+  }
+  p->bm[kGemmF32Slot] = 64;
+  p->bn[kGemmF32Slot] = 64;
+  p->halo[kGemmF32Slot] = 600001;
+}
+
+void gemm_init() {
+  static const bool init = [] {
+    for (const auto& c : kGemm)
+      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)c.lds));
+    return true;
+  }();
+  (void)init;
+}
+
+// returns the profile slot of the kernel that ran
+int launch_gemm(GemmArgs a, hipStream_t stream) {
+  RVCX_CHECK(a.rows > 0 && a.cout % 4 == 0 && a.T > 0, "gemm: bad shape");
+  RVCX_CHECK(a.y || a.ys || a.y_cf, "gemm: no output");
+  if (a.xs && a.w_h3 && gemm_h3_enabled()) {
+    RVCX_CHECK(a.cin_p % 16 == 0 && (long)kBnMax * a.ld_xs < kH3Oob && (long)a.cin_p * a.cout_p * 4 < kH3Oob, "gemm: operand too large");
+    // Tile choice (the k-order does not depend on it: every tile gives the same bits).  Two workgroups fit a CU; a
+    // workgroup's time ~ its MFMA work + a fixed prologue / epilogue.
+    const int forced = g_conv_override.tile >= 200 ? g_conv_override.tile - 200 : -1;   // tuning / tests (rvcx_conv_override)
+    int best = 0;
+    double best_t = 1e300;
+    const double ksteps = a.cin_p / 16.0;
+    for (int t = 0; t < kNumGemm; ++t) {
+      if (forced >= 0 && forced != t) continue;
+      const long blocks = (long)cdiv(a.cout_p, kGemm[t].bm) * cdiv64(a.rows, kGemm[t].bn);
+      const double work = (kGemm[t].bm / 32) * (kGemm[t].bn / 32) / 4.0 * ksteps * 96.0 + 6000.0;   // cycles per workgroup
+      const double per_cu = std::ceil(blocks / 256.0);
+      // two co-resident workgroups share the matrix pipes but hide each other's prologue / epilogue
+      const double t_est = per_cu * work * (per_cu >= 2 ? 0.9 : 1.0);
+      if (t_est < best_t) {
+        best_t = t_est;
+        best = t;
+      }
+    }
+    const GemmCfg& F = kGemm[best];
+    dim3 grid((unsigned)cdiv64(a.rows, F.bn), cdiv(a.cout_p, F.bm), 1);
+    gemm_init();
+    hipLaunchKernelGGL(F.kern, grid, dim3(256), F.lds, stream, a);
+    RVCX_HIP(hipGetLastError());
+    return kGemmSlot0 + best;
+  }
+  RVCX_CHECK(a.x && a.w, "gemm: the exact-fp32 kernel needs fp32 activations and weights");
+  dim3 grid((unsigned)cdiv64(a.rows, 64), cdiv(a.cout_p, 64), 1);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, a);
+  RVCX_HIP(hipGetLastError());
+  return kGemmF32Slot;
+}
+
+}  // namespace rvcx

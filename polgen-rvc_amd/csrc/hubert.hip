@@ -79,7 +79,7 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
   const int64_t t0 = (n - m.cfg.conv_kernels[0]) / m.cfg.conv_strides[0] + 1;
   const int T = hubert_frames(m, n);
   size_t conv = 2 * (size_t)m.cfg.conv_dim * t0;
-  size_t enc = (size_t)T * (size_t)(6 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + 8 * 98 * m.cfg.heads);
+  size_t enc = (size_t)T * (size_t)(11 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + 8 * 98 * m.cfg.heads);
   return (size_t)B * (conv + enc) * sizeof(float) + ((size_t)64 << 20);
 }
 
@@ -126,16 +126,90 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     a.act = ACT_GELU;
     conv_set_res(a, h, E, T);
     c.conv_on(a, s);
-    launch_layernorm_c(h2, m.eln_g, m.eln_b, h, B, E, T, 1e-5f, nullptr, s);
   }
-  // ---- post-LN transformer layers
+  const int nl = std::min(output_layer, cf.layers);
+  const int hd = E / cf.heads;
+  const float scale = 1.f / std::sqrt((float)hd);
+  if (gemm_h3_enabled() && E % 16 == 0 && cf.ffn_dim % 16 == 0 && E <= 1024 && nl > 0) {
+    // ---- post-LN transformer layers, TIME-MAJOR (gemm.hip): rows r = b T + t.  Between layers the activations
+    // travel as fp32 rows (residuals, LayerNorm input) and in the split form the next GEMM stages.  A layer pinned to
+    // fp32 (sticky range guard, conv.h) takes fp32 rows instead and runs gemm_f32_kernel.
+    const long R = (long)B * T;
+    const int F = cf.ffn_dim;
+    float* hf = A.alloc<float>((size_t)R * E);
+    float* hs = A.alloc<float>((size_t)R * E);          // split rows: same bytes as fp32
+    float* tmp = A.alloc<float>((size_t)R * E);
+    float* qkv = A.alloc<float>((size_t)R * 3 * E);     // channel-first (B, 3E, T): the attention kernels' layout
+    float* att = A.alloc<float>((size_t)R * E);         // channel-first (B, E, T)
+    float* attr = A.alloc<float>((size_t)R * E);        // attention output as rows (split or fp32)
+    float* ff = A.alloc<float>((size_t)R * F);          // FFN intermediate rows (split or fp32)
+    float* asplit = A.alloc<float>(attention_split_floats(B, cf.heads, T));
+    const long ldE = E, ldEb = (long)E * 4, ldFb = (long)F * 4;
+    auto first_use = [&](const ConvW& w) { return conv_h3_ok(w); };
+    launch_cf_to_tm(h2, (long)E * T, tmp, ldE, nullptr, 0, B, E, T, nullptr, nullptr, 0, s);
+    {
+      const bool q3 = first_use(m.layers[0].qkv);
+      launch_layernorm_tm(tmp, ldE, m.eln_g, m.eln_b, hf, ldE, q3 ? hs : nullptr, ldEb, R, E, 1e-5f, c.dev_err,
+                          m.layers[0].qkv.ovf_word, ++c.launch_seq, s);
+    }
+    for (int l = 0; l < nl; ++l) {
+      const auto& L = m.layers[l];
+      const bool q3 = conv_h3_ok(L.qkv), o3 = conv_h3_ok(L.o), f13 = conv_h3_ok(L.fc1), f23 = conv_h3_ok(L.fc2);
+      GemmArgs g = gemm_args(L.qkv, R, T);
+      if (q3) g.xs = hs, g.ld_xs = ldEb;
+      else g.x = hf, g.ld_x = ldE;
+      g.y_cf = qkv;
+      g.cf_bs = (long)3 * E * T;
+      c.gemm_on(g, s);
+      launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T, (long)3 * E * T,
+                       (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s, c.dev_err, L.att.word,
+                       ++c.launch_seq, L.att.h3());
+      c.flops += attention_flops(B, cf.heads, hd, T);
+      launch_cf_to_tm(att, (long)E * T, o3 ? nullptr : attr, ldE, o3 ? attr : nullptr, ldEb, B, E, T, c.dev_err,
+                      L.o.ovf_word, ++c.launch_seq, s);
+      g = gemm_args(L.o, R, T);
+      if (o3) g.xs = attr, g.ld_xs = ldEb;
+      else g.x = attr, g.ld_x = ldE;
+      g.res = hf;
+      g.ld_res = ldE;
+      g.y = tmp;
+      g.ld_y = ldE;
+      c.gemm_on(g, s);
+      launch_layernorm_tm(tmp, ldE, L.ln1_g, L.ln1_b, hf, ldE, f13 ? hs : nullptr, ldEb, R, E, 1e-5f, c.dev_err,
+                          L.fc1.ovf_word, ++c.launch_seq, s);
+      g = gemm_args(L.fc1, R, T);
+      if (f13) g.xs = hs, g.ld_xs = ldEb;
+      else g.x = hf, g.ld_x = ldE;
+      g.act = ACT_GELU;
+      if (f23) g.ys = ff, g.ld_ys = ldFb, g.ovf_next = L.fc2.ovf_word;
+      else g.y = ff, g.ld_y = F;
+      c.gemm_on(g, s);
+      g = gemm_args(L.fc2, R, T);
+      if (f23) g.xs = ff, g.ld_xs = ldFb;
+      else g.x = ff, g.ld_x = F;
+      g.res = hf;
+      g.ld_res = ldE;
+      g.y = tmp;
+      g.ld_y = ldE;
+      c.gemm_on(g, s);
+      if (l == nl - 1) {
+        launch_layernorm_tm(tmp, ldE, L.ln2_g, L.ln2_b, hf, ldE, nullptr, 0, R, E, 1e-5f, nullptr, nullptr, 0, s);
+        launch_transpose(hf, feats_ct, B, T, E, s);      // rows (B, T, E) -> channel-first (B, E, T)
+      } else {
+        const ConvW& nq = m.layers[l + 1].qkv;
+        launch_layernorm_tm(tmp, ldE, L.ln2_g, L.ln2_b, hf, ldE, conv_h3_ok(nq) ? hs : nullptr, ldEb, R, E, 1e-5f,
+                            c.dev_err, nq.ovf_word, ++c.launch_seq, s);
+      }
+    }
+    RVCX_HIP(hipGetLastError());
+    return;
+  }
+  // ---- post-LN transformer layers, channel-first (RVCX_GEMM=0, the exact-fp32 mode, odd geometries)
+  launch_layernorm_c(h2, m.eln_g, m.eln_b, h, B, E, T, 1e-5f, nullptr, s);
   float* qkv = A.alloc<float>((size_t)B * 3 * E * T);
   float* att = A.alloc<float>((size_t)B * E * T);
   float* ff = A.alloc<float>((size_t)B * cf.ffn_dim * T);
   float* asplit = A.alloc<float>(attention_split_floats(B, cf.heads, T));
-  const int hd = E / cf.heads;
-  const float scale = 1.f / std::sqrt((float)hd);
-  const int nl = std::min(output_layer, cf.layers);
   for (int l = 0; l < nl; ++l) {
     const auto& L = m.layers[l];
     ConvArgs a = conv1d_args(L.qkv, h, qkv, B, T, T);

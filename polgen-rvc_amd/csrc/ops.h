@@ -28,6 +28,14 @@ void launch_bigru(const float* gi, const float* whh, const float* bhh, float* y,
 // LayerNorm over channels of (B,C,T): y = (x-mean)/sqrt(var+eps)*gamma+beta  [normalization.py:13-16]
 void launch_layernorm_c(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                         float eps, const int* lens, hipStream_t s);
+// ---- time-major transformer section (gemm.hip): rows r = b T + t, channels contiguous
+// LayerNorm of fp32 rows (ld_x floats apart) -> fp32 rows y (or null) and / or the fp16 hi/lo split rows ys the next GEMM
+// stages (or null).  ovf / ovf_next / seq: range guard of the split form (conv.h), stamped for the consuming layer.
+void launch_layernorm_tm(const float* x, long ld_x, const float* gamma, const float* beta, float* y, long ld_y, void* ys,
+                         long ld_ys, long rows, int C, float eps, int* ovf, int* ovf_next, int seq, hipStream_t s);
+// channel-first (B, C, T) fp32 (batch stride x_bs) -> time-major fp32 rows and / or split rows
+void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, long ld_ys, int B, int C, int T, int* ovf,
+                     int* ovf_next, int seq, hipStream_t s);
 // per-(b,c) normalisation over time + GELU (GroupNorm(C,C) of the HuBERT extractor)
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                            float eps, hipStream_t s);
@@ -87,6 +95,20 @@ void launch_f0_coarse(const float* f0_in, float* f0_out, int* coarse, int n, dou
 void launch_f0_override(const double* rep, int count, int start, float* f0, int* coarse, int n, double f0_min,
                         double f0_max, hipStream_t s);
 std::vector<double> f0_file_track(const float* tbl, int rows);   // host: np.interp restated (see ops.hip)
+
+// ---- audio.hip: librosa.resample stand-in (resampy "kaiser_best", see the file header)
+struct ResampleFilter {
+  const double* win = nullptr;     // device: interp_win, kWin doubles
+  const double* delta = nullptr;   // device: forward differences
+  double scale = 1.0, time_increment = 1.0;
+  int index_step = 512;
+};
+long resample_out_len(long n, int sr_in, int sr_out);                // int(n * sr_out / sr_in)
+ResampleFilter make_resample_filter(Arena& A, int sr_in, int sr_out, hipStream_t s);
+// x: (n frames, channels) interleaved float64, averaged over the channels on the fly; y: n_out mono samples
+void launch_resample_f64(const ResampleFilter& f, const double* x, long n, int channels, double* y, long n_out,
+                         hipStream_t s);
+void launch_resample_f32(const ResampleFilter& f, const float* x, long n, float* y, long n_out, hipStream_t s);
 
 // ---- pipeline glue
 // feats (C,T) -> x2 nearest upsample, protect mix; writes phone (C, 2T') cropped to p_len  [pipeline.py:252-270]

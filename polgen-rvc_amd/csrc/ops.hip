@@ -4,6 +4,7 @@
 #include <cmath>
 #include <vector>
 
+#include "conv.h"
 #include "ops.h"
 
 namespace rvcx {
@@ -82,6 +83,118 @@ void launch_layernorm_c(const float* x, const float* gamma, const float* beta, f
                         float eps, const int* lens, hipStream_t s) {
   RVCX_CHECK(C <= LN_MAXC, "layernorm: too many channels");
   hipLaunchKernelGGL(layernorm_c_kernel, dim3(cdiv(T, LN_TX), B), dim3(256), 0, s, x, gamma, beta, y, C, T, eps, lens);
+}
+
+// ------------------------------------------------------------------ time-major section (gemm.hip)
+// 4 channels c .. c+3 of row `row` into the fp16 hi/lo split form the GEMM stages (gemm.h: 64 bytes per 16 channels)
+__device__ __forceinline__ bool store_xs4(void* ys, long ld_ys, long row, int c, const float (&v)[4]) {
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  half4 hi, lo;
+  bool ovf = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ovf |= !(fabsf(v[q]) < kH3ActLimit);
+    const _Float16 vh = (_Float16)v[q];
+    hi[q] = vh;
+    lo[q] = (_Float16)((v[q] - (float)vh) * 256.f);
+  }
+  char* e = static_cast<char*>(ys) + row * ld_ys + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+  *reinterpret_cast<half4*>(e) = hi;
+  *reinterpret_cast<half4*>(e + 32) = lo;
+  return ovf;
+}
+
+// LayerNorm over the channels of time-major rows: ONE WAVEFRONT PER ROW, the row lives in registers (float4 per lane
+// and pass), both reductions are wavefront shuffles.  Writes fp32 rows and / or the split form for the next GEMM.
+constexpr int LNT_MAXC = 1024;
+__global__ __launch_bounds__(256) void layernorm_tm_kernel(const float* __restrict__ x, long ld_x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y,
+                                                           long ld_y, void* __restrict__ ys, long ld_ys, long rows, int C,
+                                                           float eps, int* ovf, int* ovf_next, int seq) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int NP = LNT_MAXC / 256;
+  float4 v[NP];
+  const float4* xr = reinterpret_cast<const float4*>(x + row * ld_x);
+  const int n4 = C >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int f = lane + 64 * k;
+    v[k] = f < n4 ? xr[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (lane + 64 * k < n4) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int f = lane + 64 * k;
+    if (f < n4) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[f], bb = reinterpret_cast<const float4*>(beta)[f];
+      const float o[4] = {(v[k].x - mean) * rstd * g.x + bb.x, (v[k].y - mean) * rstd * g.y + bb.y,
+                          (v[k].z - mean) * rstd * g.z + bb.z, (v[k].w - mean) * rstd * g.w + bb.w};
+      if (y) reinterpret_cast<float4*>(y + row * ld_y)[f] = make_float4(o[0], o[1], o[2], o[3]);
+      if (ys) bad |= store_xs4(ys, ld_ys, row, 4 * f, o);
+    }
+  }
+  if (bad) {
+    if (ovf) atomicOr(ovf, kErrH3Overflow);
+    if (ovf_next) atomicMax(ovf_next, 0x7fffffff - seq);
+  }
+}
+
+void launch_layernorm_tm(const float* x, long ld_x, const float* gamma, const float* beta, float* y, long ld_y, void* ys,
+                         long ld_ys, long rows, int C, float eps, int* ovf, int* ovf_next, int seq, hipStream_t s) {
+  RVCX_CHECK(C % 4 == 0 && C <= LNT_MAXC, "layernorm_tm: channels must be a multiple of 4 and <= 1024");
+  hipLaunchKernelGGL(layernorm_tm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, x, ld_x, gamma, beta, y, ld_y,
+                     ys, ld_ys, rows, C, eps, ovf, ovf_next, seq);
+}
+
+// channel-first (B, C, T) fp32 -> time-major rows (r = b T + t): fp32 and / or split form.  64 x 64 tiles through LDS:
+// reads coalesced along t, writes 16 bytes (4 channels) per lane along c.
+__global__ __launch_bounds__(256) void cf_to_tm_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ y,
+                                                       long ld_y, void* __restrict__ ys, long ld_ys, int C, int T,
+                                                       int* ovf, int* ovf_next, int seq) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const float* xb = x + (long)b * x_bs;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e >> 6, t = e & 63;
+    tile[c][t] = (c0 + c < C && t0 + t < T) ? xb[(long)(c0 + c) * T + t0 + t] : 0.f;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+    const int t = e >> 4, c4 = (e & 15) * 4;
+    if (t0 + t < T && c0 + c4 < C) {
+      const float o[4] = {tile[c4][t], tile[c4 + 1][t], tile[c4 + 2][t], tile[c4 + 3][t]};
+      const long row = (long)b * T + t0 + t;
+      if (y) *reinterpret_cast<float4*>(y + row * ld_y + c0 + c4) = make_float4(o[0], o[1], o[2], o[3]);
+      if (ys) bad |= store_xs4(ys, ld_ys, row, c0 + c4, o);
+    }
+  }
+  if (bad) {
+    if (ovf) atomicOr(ovf, kErrH3Overflow);
+    if (ovf_next) atomicMax(ovf_next, 0x7fffffff - seq);
+  }
+}
+
+void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, long ld_ys, int B, int C, int T, int* ovf,
+                     int* ovf_next, int seq, hipStream_t s) {
+  RVCX_CHECK(C % 4 == 0, "cf_to_tm: channels must be a multiple of 4");
+  hipLaunchKernelGGL(cf_to_tm_kernel, dim3(cdiv(T, 64), cdiv(C, 64), B), dim3(256), 0, s, x, x_bs, y, ld_y, ys, ld_ys, C, T,
+                     ovf, ovf_next, seq);
 }
 
 // ------------------------------------------------------------------ GroupNorm(C,C) + GELU

@@ -312,7 +312,10 @@ long out_capacity(const SynthModel& m, long n, const rvcx_params& p) {
   // samples VC.pipeline can return at most: every chunk yields <= (its frames)*upp - 2*t_pad_tgt and
   // consecutive chunks overlap by 2*t_pad + one window (pipeline.py:385-397)
   const Geometry g = make_geometry(p, m.cfg.sr);
-  return (n / 160 + cut_count(n, g) + 4) * m.upp;
+  const long cap = (n / 160 + cut_count(n, g) + 4) * m.upp;
+  // resample_sr (pipeline.py:453-454): the output leaves at another rate
+  if (p.resample_sr >= 16000 && p.resample_sr != m.cfg.sr) return std::max(cap, resample_out_len(cap, m.cfg.sr, p.resample_sr) + 8);
+  return cap;
 }
 
 long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params& p) {
@@ -495,6 +498,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     any_noise |= u.noise != nullptr;
     n_max = std::max(n_max, u.n);
     call_bytes += convert_call_bytes(c, model_id, u.n, p, u.wav64 != nullptr, u.noise != nullptr);
+    if (p.resample_sr >= 16000) call_bytes += (size_t)out_capacity(M, u.n, p) * 4 + ((size_t)1 << 20);
     if (u.inp_f0) call_bytes += (size_t)65536 * sizeof(double) + 256;      // delta_t is an int16
   }
   for (const auto& mb : mbs) {
@@ -585,6 +589,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       f.feats_cap = hmax;
     }
   }
+  // resample_sr (pipeline.py:453-454): librosa.resample(audio_opt, orig_sr=tgt_sr, target_sr=resample_sr) ahead of the peak
+  // normalisation -- hard-wired off by rvc_infer (infer.py:144), reachable through VC.pipeline
+  const bool resamp = p.resample_sr >= 16000 && p.resample_sr != M.cfg.sr;
+  ResampleFilter rs_filter;
+  if (resamp) rs_filter = make_resample_filter(A, M.cfg.sr, p.resample_sr, s);
   const size_t work_mark = A.mark();
 
   float t_hp = 0, t_f0 = 0, t_hub = 0, t_idx = 0, t_syn[3] = {0, 0, 0}, t_post = 0, t_wait_hub = 0, t_wait_f0 = 0;
@@ -916,6 +925,14 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         hipLaunchKernelGGL(frame_rms_kernel<float>, dim3(n2), dim3(256), 0, s, u.outf, r2, u.out_n, f2, h2, n2);
         hipLaunchKernelGGL(envelope_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 65535)), dim3(256), 0, s,
                            u.outf, r1, n1, r2, n2, u.out_n, p.volume_envelope);
+      }
+      if (resamp) {
+        const long nr = resample_out_len(u.out_n, M.cfg.sr, p.resample_sr);
+        RVCX_CHECK(nr <= u.cap, "convert: resampled output exceeds the capacity");
+        float* r = A.alloc<float>((size_t)std::max<long>(nr, 1));
+        launch_resample_f32(rs_filter, u.outf, u.out_n, r, nr, s);
+        RVCX_HIP(hipMemcpyAsync(u.outf, r, (size_t)nr * sizeof(float), hipMemcpyDeviceToDevice, s));
+        u.out_n = nr;
       }
       unsigned int* amax = A.alloc<unsigned int>(1);
       RVCX_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned int), s));
