@@ -321,6 +321,8 @@ int rvcx_op_attention(rvcx_ctx*, const float* q, const float* k, const float* v,
  * (B, Cout, T) or NULL; y_split = the split-form output decoded to fp32 (hi + lo) or NULL. */
 int rvcx_op_gemm_tm(rvcx_ctx*, const float* x_cf, const float* w, const float* bias, const float* res_tm, int B, int T,
                     int Cin, int Cout, int act, int exact_fp32, float* y_tm, float* y_cf, float* y_split);
+/* micro-benchmark of the time-major Linear kernel on device-resident random rows (split form in, fp32 rows out) */
+int rvcx_bench_gemm(rvcx_ctx*, int64_t rows, int Cin, int Cout, int iters, float* ms_per_launch);
 /* LayerNorm of time-major rows (rows, C): fp32 result and the decoded split-form result (NULL to skip) */
 int rvcx_op_layernorm_tm(rvcx_ctx*, const float* x, const float* gamma, const float* beta, float* y, float* y_split,
                          int64_t rows, int C, float eps);

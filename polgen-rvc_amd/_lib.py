@@ -82,7 +82,7 @@ SYMBOLS = [
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
     "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
-    "rvcx_resample_len", "rvcx_resample_f64",
+    "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm",
 ]
 
 
@@ -297,6 +297,11 @@ class Context:
         self._ck(lib().rvcx_op_gemm_tm(self._h, _p(x_cf), _p(w), _p(bias), _p(res), B, T, Cin, Cout, int(act),
                                        1 if exact_fp32 else 0, _p(y), _p(ycf), _p(ysp)), "op_gemm_tm")
         return y, ycf, ysp
+
+    def bench_gemm(self, rows, cin, cout, iters=20):
+        ms = C.c_float(0)
+        self._ck(lib().rvcx_bench_gemm(self._h, C.c_int64(rows), cin, cout, iters, C.byref(ms)), "bench_gemm")
+        return ms.value, 2.0 * rows * cin * cout / (ms.value * 1e-3) / 1e12
 
     def layernorm_tm(self, x, gamma, beta, eps=1e-5):
         x = f32(x)

@@ -119,25 +119,33 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
   }
   const int row_bytes = a.cin_p * 4;                    // bytes of a row that hold data
 
-  uint4 ra[NA], rb[NB];
-  auto fetch = [&](int st) {
+  // Two register sets: stage s travels in set s & 1.  Loads stay in flight across the barriers (a raw s_barrier that
+  // waits for this wave's LDS traffic only -- __syncthreads() would also drain vmcnt and serialise every stage behind
+  // its own load latency): a stage is fetched two iterations before it is committed to LDS.
+  uint4 ra[2][NA], rb[2][NB];
+  auto fetch = [&](int st, uint4 (&qa)[NA], uint4 (&qb)[NB]) {
     const int c0 = st * kKC;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int ch = c0 + a_cl[j];
-      ra[j] = h3_load4(wres, (a_off[j] != kH3Oob && ch < nchunk) ? ch * slab + a_off[j] : kH3Oob);
+      qa[j] = h3_load4(wres, (a_off[j] != kH3Oob && ch < nchunk) ? ch * slab + a_off[j] : kH3Oob);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int col = c0 * 64 + ((tid + 256 * j) & (4 * kKC - 1)) * 16;
-      rb[j] = h3_load4(xres, (b_off[j] != kH3Oob && col < row_bytes) ? b_off[j] + c0 * 64 : kH3Oob);
+      qb[j] = h3_load4(xres, (b_off[j] != kH3Oob && col < row_bytes) ? b_off[j] + c0 * 64 : kH3Oob);
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, const uint4 (&qa)[NA], const uint4 (&qb)[NB]) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) As[buf][tid + 256 * j] = ra[j];
+    for (int j = 0; j < NA; ++j) As[buf][tid + 256 * j] = qa[j];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) Bs[buf][b_dst[j]] = rb[j];
+    for (int j = 0; j < NB; ++j) Bs[buf][b_dst[j]] = qb[j];
+  };
+  auto lds_barrier = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
   };
 
   f32x16 acc[WM][WN];
@@ -148,12 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  fetch(0);
-  commit(0);
-  if (nst > 1) fetch(1);
-  __syncthreads();
-  for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int cl = 0; cl < kKC; ++cl) {
       half8 af[3][WM], bf[2][WN];
@@ -177,11 +180,24 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
           acc[m][n] = h3_mfma(af[2][m], bf[0][n], acc[m][n]);   // (S wl) xh
         }
     }
-    if (st + 1 < nst) {
-      commit(buf ^ 1);                    // stage st + 1 was fetched an iteration ago; nobody reads buffer buf ^ 1 now
-      if (st + 2 < nst) fetch(st + 2);
-      __syncthreads();
-    }
+  };
+  // iteration st: stage st + 1 (set q) goes to LDS buffer (st + 1) & 1 -- nobody reads it any more: every wave passed
+  // the barrier behind compute(st - 1) -- its registers are refilled with stage st + 3, then the MFMAs of stage st run
+  auto iter = [&](int st, uint4 (&qa)[NA], uint4 (&qb)[NB]) {
+    if (st + 1 < nst) commit((st + 1) & 1, qa, qb);
+    fetch(st + 3, qa, qb);             // unconditional: stages past the end read zeros (buffer bounds), and the number of
+    if (st < nst) compute(st & 1);     // loads in flight stays known to the compiler -> counted vmcnt waits, never vmcnt(0)
+    lds_barrier();
+  };
+
+  fetch(0, ra[0], rb[0]);
+  fetch(1, ra[1], rb[1]);
+  commit(0, ra[0], rb[0]);
+  fetch(2, ra[0], rb[0]);
+  lds_barrier();
+  for (int st = 0; st < nst; st += 2) {
+    iter(st, ra[1], rb[1]);
+    iter(st + 1, ra[0], rb[0]);        // st + 1 == nst on an odd stage count: nothing to multiply, see iter
   }
 
   constexpr float inv = 1.f / kH3Scale;
@@ -197,10 +213,11 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
   if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
 }
 
-// Exact fp32 (v_mfma_f32_32x32x2_f32): 64 x 64 tile, 4 waves of 32 x 32, 32 channels per stage.  x is fp32 time-major.
-// Only layers pinned to fp32 after an fp16-range overflow run here.
+// Exact fp32 (v_mfma_f32_32x32x2_f32): 64 x 64 tile, 4 waves of 32 x 32, 64 channels per stage, the next stage's
+// operands are fetched into registers while the current one is multiplied.  x is fp32 time-major.  Only layers pinned
+// to fp32 after an fp16-range overflow run here.
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
-  constexpr int KT = 32, P = 65;
+  constexpr int KT = 64, P = 65, NE = KT * 64 / 256;
   __shared__ float As[KT][64];                          // [k][co]
   __shared__ float Bs[KT][P];                           // [k][p]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,17 +228,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float qa[NE], qb[NE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      const int k = e >> 6, c = e & 63;                 // A: 64 consecutive lanes = 256 contiguous bytes of a weight row
+      qa[j] = (k0 + k < a.cin && co0 + c < a.cout_p) ? a.w[(long)(k0 + k) * a.cout_p + co0 + c] : 0.f;
+      const int p = e >> 6, kb = e & 63;                // B: 64 consecutive lanes = 256 contiguous bytes of an x row
+      qb[j] = (n0 + p < a.rows && k0 + kb < a.cin) ? a.x[(n0 + p) * a.ld_x + k0 + kb] : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < a.cin; k0 += KT) {
     __syncthreads();
-    for (int e = tid; e < KT * 64; e += 256) {
-      const int k = e >> 6, c = e & 63;
-      As[k][c] = (k0 + k < a.cin && co0 + c < a.cout_p) ? a.w[(long)(k0 + k) * a.cout_p + co0 + c] : 0.f;
-    }
-    for (int e = tid; e < KT * 64; e += 256) {
-      const int p = e >> 5, k = e & 31;                 // 32 consecutive lanes = 128 contiguous bytes of a row
-      Bs[k][p] = (n0 + p < a.rows && k0 + k < a.cin) ? a.x[(n0 + p) * a.ld_x + k0 + k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      As[e >> 6][e & 63] = qa[j];
+      Bs[e & 63][e >> 6] = qb[j];
     }
     __syncthreads();
+    if (k0 + KT < a.cin) fetch(k0 + KT);
 #pragma unroll
     for (int s = 0; s < KT / 2; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * s + h][wr * 32 + i], Bs[2 * s + h][wc * 32 + i], acc, 0, 0, 0);

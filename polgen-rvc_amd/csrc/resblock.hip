@@ -33,6 +33,13 @@ constexpr int kPairPadY = 16;    // c2 reads up to k - 1 <= 10 columns past N1 (
 #define RVCX_PAIR_SCHED_FENCE 0
 #endif
 constexpr bool kSchedFence = RVCX_PAIR_SCHED_FENCE != 0;
+// Timing ablations (tools/ablate_pair.sh builds one library per value; results are garbage, only the clock counts):
+//   1 c2: no weight commit, no barriers      2 c2 epilogue: no residual loads / stores      4 no fragment reads, no MFMAs
+//   8 c1: no input conversion at commit     16 c1: no weight commit, one barrier per chunk
+#ifndef RVCX_PAIR_ABL
+#define RVCX_PAIR_ABL 0
+#endif
+constexpr int kAbl = RVCX_PAIR_ABL;
 
 // K: taps (compile time: the k-loop is straight-line code, fragment reads of slot s+1 are issued ahead of the MFMAs
 // of slot s).  A stage = NCS chunks of 16 input channels x a group of <= KKT taps ("slots"); NCS > 1 only with
@@ -136,6 +143,11 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float v = rb[j][q];
+          if (kAbl & 8) {
+            hi[q] = (_Float16)0.f;
+            lo[q] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned, v) & 1));
+            continue;
+          }
           v = v > 0.f ? v : v * slope;                 // leaky_relu ahead of c1
           ovf |= !(fabsf(v) < kH3ActLimit);
           const _Float16 vh = (_Float16)v;
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   auto compute = [&](auto taps_tag, const uint4* Bt, int pitch, int cl_pitch, int kk0, int tap_step) {
     constexpr int TAPS = decltype(taps_tag)::value;
     constexpr int NS = NCS * TAPS;
+    if (kAbl & 4) return;
     half8 af[2][2][WM], bf[2][2][WN];
     auto load = [&](int buf, int s) {
       const int cl = s / TAPS, kkl = s % TAPS;
@@ -205,10 +218,10 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   {
     int chunk = 0, g = 0;
     for (int st = 0; st < nst; ++st) {
-      __syncthreads();
+      if (!(kAbl & 16) || g == 0) __syncthreads();
       if (g == 0) commit_b();
-      commit_a();
-      __syncthreads();
+      if (!(kAbl & 16)) commit_a();
+      if (!(kAbl & 16) || g == 0) __syncthreads();
       int g1 = g + 1, chunk1 = chunk;
       if (g1 == NG) {
         g1 = 0;
@@ -260,16 +273,19 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   zero_acc();
   {
     int chunk = 0, g = 0;
+    if (kAbl & 1) __syncthreads();
     for (int st = 0; st < nst; ++st) {
-      __syncthreads();
-      commit_a();
-      __syncthreads();
+      if (!(kAbl & 1)) {
+        __syncthreads();
+        commit_a();
+        __syncthreads();
+      }
       int g1 = g + 1, chunk1 = chunk;
       if (g1 == NG) {
         g1 = 0;
         chunk1 += NCS;
       }
-      if (st + 1 < nst) fetch_a(w2r, chunk1, g1 * KKT);
+      if (st + 1 < nst && !(kAbl & 1)) fetch_a(w2r, chunk1, g1 * KKT);
       if (NG > 1 && g == NG - 1) compute(Last{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
       else compute(Full{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
       g = g1;
@@ -284,6 +300,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
       const int col = wc * (WN * 32) + n * 32 + i;
       const int pos = n0 + col;
       if (col >= BN_OUT || pos >= a.T) continue;
+      if ((kAbl & 2) && acc[m][n][0] != 12345.678f) continue;
       const bool live = pos < len;
       const int co_base = wr * (WM * 32) + m * 32 + 4 * h;
       const float* xb = a.x + (long)b * a.bs + pos;

@@ -1,0 +1,71 @@
+"""Audio I/O edges of the path: what ``soundfile.read`` / ``librosa.load`` / ``librosa.resample`` /
+``soundfile.write`` do for ``load_audio`` (rvc/lib/my_utils.py:5-16) and ``convert_to_stereo``
+(rvc/scripts/voice_conversion.py:45-51).
+
+Decoding: when ``soundfile`` is importable (it is wherever the reference runs) it reads the file, so every container the
+reference accepts is accepted; otherwise RIFF/WAVE files (PCM 8/16/24/32, float 32/64) are read with scipy and anything
+else raises a clear error naming the missing decoder -- this image has neither soundfile nor ffmpeg.
+Resampling runs on the GPU (``rvcx_resample_f64``, csrc/audio.hip): resampy's published "kaiser_best" filter;
+``librosa.resample``'s current default (soxr_hq) is not published as a formula -- parity unpinned, see oracle/audio.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_MAGIC = {b"fLaC": "FLAC", b"OggS": "Ogg", b"ID3": "MP3", b"\xff\xfb": "MP3", b"\xff\xf3": "MP3", b"\xff\xf2": "MP3",
+          b"FORM": "AIFF", b"caff": "CAF"}
+
+
+def read_audio(path):
+    """``soundfile.read(path)`` -> (float64 array (frames,) or (frames, channels), sample rate)."""
+    try:
+        import soundfile as sf
+    except ImportError:
+        sf = None
+    if sf is not None:
+        return sf.read(path)
+    with open(path, "rb") as f:
+        head = f.read(12)
+    if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        kind = next((v for k, v in _MAGIC.items() if head.startswith(k)), "unknown")
+        raise ValueError(f"{path}: {kind} container -- this installation has no decoder for it (the 'soundfile' package "
+                         "is not installed); only RIFF/WAVE files can be read without it")
+    from scipy.io import wavfile
+    sr, a = wavfile.read(path)
+    if a.dtype == np.uint8:
+        a = (a.astype(np.float64) - 128.0) / 128.0
+    elif a.dtype == np.int16:
+        a = a.astype(np.float64) / 32768.0
+    elif a.dtype == np.int32:            # 24-bit files arrive left-justified in int32
+        a = a.astype(np.float64) / 2147483648.0
+    else:
+        a = a.astype(np.float64)
+    return a, int(sr)
+
+
+def write_wav_pcm16(path, data, sr):
+    """``soundfile.write(path, data, sr, format="WAV")``: WAV's default subtype is PCM_16 whatever the dtype."""
+    try:
+        import soundfile as sf
+        sf.write(path, data, sr, format="WAV")
+        return
+    except ImportError:
+        pass
+    from scipy.io import wavfile
+    a = np.asarray(data)
+    if a.dtype.kind == "f":              # libsndfile: lrint(x * 0x7FFF), here with saturation
+        a = np.clip(np.rint(a.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    wavfile.write(path, int(sr), a)
+
+
+def convert_to_stereo(input_path, output_path):
+    """rvc/scripts/voice_conversion.py:45-51, same signature: mono files are doubled to two channels, everything else is
+    written back unchanged (the reference's ``y.ndim > 2`` branch never fires on a (channels, frames) array), at the
+    ORIGINAL sample rate -- so the file ``rvc_infer`` loads next is rarely 16 kHz and load_audio really resamples."""
+    a, sr = read_audio(input_path)       # (frames,) or (frames, channels) == librosa.load(sr=None, mono=False).T
+    y = a.T if a.ndim > 1 else a
+    if y.ndim == 1:
+        y = np.vstack([y, y])
+    elif y.ndim > 2:
+        y = y[:2, :]
+    write_wav_pcm16(output_path, y.T, sr)

@@ -164,30 +164,21 @@ def get_vc(device, is_half, config, model_path, cpt=None):
 
 
 def load_audio(file, sample_rate):
-    """rvc/lib/my_utils.py:5-16: read -> mono mean -> resample -> flatten.  PCM/float WAV through scipy (soundfile
-    is absent here).  Other rates are converted with a Kaiser-windowed polyphase filter
-    (``scipy.signal.resample_poly``); the reference calls ``librosa.resample`` (soxr_hq), which is not vendored, so
-    this edge is "parity unpinned": same band-limiting intent, not the same filter taps."""
+    """rvc/lib/my_utils.py:5-16: read -> mono mean -> resample -> flatten (float64).  Decoding: infer/audio.py
+    (soundfile when installed, RIFF/WAVE otherwise).  The mono mix and the rate conversion run on the GPU in one pass
+    (``rvcx_resample_f64``): resampy's "kaiser_best" band-limited interpolation; librosa's current default, soxr_hq, is
+    not published as a formula, so this edge stays "parity unpinned" (oracle/audio.py restates what is computed)."""
     try:
         file = file.strip(" ").strip('"').strip("\n").strip('"').strip(" ")
-        from scipy.io import wavfile
-        sr, audio = wavfile.read(file)
-        if audio.dtype == np.int16:
-            audio = audio.astype(np.float64) / 32768.0
-        elif audio.dtype == np.int32:
-            audio = audio.astype(np.float64) / 2147483648.0
-        else:
-            audio = audio.astype(np.float64)
-        if audio.ndim > 1:
-            audio = audio.mean(axis=1)
+        from .audio import read_audio
+        audio, sr = read_audio(file)
         if sr != sample_rate:
-            from math import gcd
-            from scipy.signal import resample_poly
-            g = gcd(int(sr), int(sample_rate))
-            audio = resample_poly(audio, int(sample_rate) // g, int(sr) // g, window=("kaiser", 14.0))
+            audio = _context("cuda:0").resample(audio, sr, sample_rate)
+        elif len(audio.shape) > 1:
+            audio = np.asarray(audio, np.float64).mean(axis=1)        # librosa.to_mono(audio.T)
     except Exception as error:
         raise RuntimeError(f"An error occurred loading the audio: {error}")
-    return audio.flatten()
+    return np.asarray(audio, np.float64).flatten()
 
 
 def rvc_infer(index_path, index_rate, input_path, output_path, pitch, f0_method, cpt, version, net_g,
@@ -200,4 +191,5 @@ def rvc_infer(index_path, index_rate, input_path, output_path, pitch, f0_method,
     audio_opt = vc.pipeline(hubert_model, net_g, 0, audio, input_path, pitch, f0_method, index_path, index_rate,
                             pitch_guidance, filter_radius, tgt_sr, 0, volume_envelope, version, protect,
                             hop_length, f0_file=None, f0_min=f0_min, f0_max=f0_max)
+    # infer.py:153: sf.write(output_path, audio_opt, tgt_sr, format="WAV") -- a WAV whatever the extension says
     wavfile.write(output_path, tgt_sr, audio_opt)

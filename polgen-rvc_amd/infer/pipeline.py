@@ -237,8 +237,6 @@ class VC:
                 inp_f0 = np.array([[float(i) for i in line.split(",")] for line in lines], dtype="float32")
             except Exception as e:  # noqa: BLE001
                 print(f"Error reading the F0 file: {e}")
-        if resample_sr >= self.sample_rate and tgt_sr != resample_sr:
-            raise ValueError("resample_sr is hard-wired to 0 by rvc_infer (infer.py:144)")
         ctx = net_g.ctx
         if model.ctx is not ctx:
             raise ValueError("hubert and voice model live on different rvcx contexts")
@@ -246,6 +244,9 @@ class VC:
         index, _ = self._load_index(ctx, file_index, index_rate)
         p = self._params(pitch, index_rate if index is not None else 0.0, volume_envelope, protect, f0_min, f0_max,
                          int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid, f0_method=f0_method)
+        # pipeline.py:453-454: librosa.resample(audio_opt, orig_sr=tgt_sr, target_sr=resample_sr) ahead of the peak
+        # normalisation -- on the device (csrc/audio.hip); rvc_infer passes 0 (infer.py:144)
+        p.resample_sr = int(resample_sr) if (resample_sr >= self.sample_rate and tgt_sr != resample_sr) else 0
         # float64 stays float64 across the ABI (filtfilt then sees what the reference's sees); else float32
         clips = [a if _np(a).dtype == np.float64 else _np(a, np.float32) for a in map(_np, audios)]
         if not all(c.dtype == clips[0].dtype for c in clips):

@@ -256,21 +256,40 @@ def test_resident_asset_cache_is_keyed_by_path_and_mtime(tmp_path, monkeypatch):
     I.clear_cache()
 
 
-def test_load_audio_resamples_other_rates(tmp_path):
-    """my_utils.py:5-16: stereo 44.1 kHz int16 -> mono float64 at 16 kHz; a 440 Hz tone keeps its frequency and level."""
+def test_load_audio_and_convert_to_stereo_host_side(tmp_path):
+    """my_utils.py:5-16 / voice_conversion.py:45-51 without a rate change (the resampler itself is a GPU kernel:
+    tests/test_gpu_audio.py): PCM scaling, mono mean, mono -> stereo doubling at the ORIGINAL rate, PCM_16 output, and a
+    clear error for containers this image cannot decode."""
     from scipy.io import wavfile
-    from polgen_rvc_amd.infer import infer as I
-    sr = 44100
-    t = np.arange(sr) / sr
-    tone = 0.5 * np.sin(2 * np.pi * 440 * t)
-    pcm = np.stack([tone, tone], axis=1)
-    wavfile.write(tmp_path / "a.wav", sr, (pcm * 32767).astype(np.int16))
-    y = I.load_audio(str(tmp_path / "a.wav"), 16000)
-    assert y.ndim == 1 and abs(len(y) - 16000) <= 1
-    ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(y)) / 16000)
-    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3
-    wavfile.write(tmp_path / "b.wav", 16000, (ref * 32767).astype(np.int16))
-    assert np.abs(I.load_audio(str(tmp_path / "b.wav"), 16000) - ref).max() < 1e-4
+    from oracle import audio as OA
+    from polgen_rvc_amd.infer import audio as A, infer as I
+    g = np.random.Generator(np.random.PCG64(2))
+    left, right = g.uniform(-0.9, 0.9, 16000), g.uniform(-0.9, 0.9, 16000)
+    pcm = (np.stack([left, right], 1) * 32767).astype(np.int16)
+    wavfile.write(tmp_path / "st.wav", 16000, pcm)
+    y = I.load_audio(str(tmp_path / "st.wav"), 16000)
+    want = OA.load_audio_from_array(pcm.astype(np.float64) / 32768.0, 16000, 16000)
+    assert y.dtype == np.float64 and np.array_equal(y, want)
+    wavfile.write(tmp_path / "f32.wav", 16000, left.astype(np.float32))
+    assert np.array_equal(I.load_audio(' "' + str(tmp_path / "f32.wav") + '" ', 16000), left.astype(np.float32).astype(np.float64))
+    # convert_to_stereo: mono 44.1 kHz in -> two identical channels, still 44.1 kHz, 16-bit
+    mono = (left[:4410] * 32767).astype(np.int16)
+    wavfile.write(tmp_path / "mono.wav", 44100, mono)
+    A.convert_to_stereo(str(tmp_path / "mono.wav"), str(tmp_path / "stereo.wav"))
+    sr, out = wavfile.read(tmp_path / "stereo.wav")
+    ref = OA.convert_to_stereo_array(mono.astype(np.float64) / 32768.0)
+    assert sr == 44100 and out.dtype == np.int16 and out.shape == (4410, 2) == ref.shape
+    assert np.array_equal(out[:, 0], out[:, 1]) and np.abs(out[:, 0].astype(np.int32) - mono).max() <= 1
+    A.convert_to_stereo(str(tmp_path / "st.wav"), str(tmp_path / "st2.wav"))       # already stereo: unchanged
+    assert np.abs(wavfile.read(tmp_path / "st2.wav")[1].astype(np.int32) - pcm).max() <= 1
+    # compressed containers: no decoder in this image -> RuntimeError with the reason (my_utils.py:14 wraps it)
+    for name, magic in (("a.flac", b"fLaC\x00\x00\x00\x22"), ("a.mp3", b"ID3\x04\x00\x00\x00\x00\x00\x00")):
+        open(tmp_path / name, "wb").write(magic + bytes(64))
+        try:
+            import soundfile  # noqa: F401
+        except ImportError:
+            with pytest.raises(RuntimeError, match="no decoder"):
+                I.load_audio(str(tmp_path / name), 16000)
 
 
 def test_bench_refuses_more_gpus_than_visible():
