@@ -853,11 +853,8 @@ int rvcx_bench_gemm(rvcx_ctx* ctx, int64_t rows, int Cin, int Cout, int iters, f
   float* xs = C->arena.alloc<float>((size_t)rows * L.cin_gp);
   float* dy = C->arena.alloc<float>((size_t)rows * Cout);
   launch_randn(xf, (size_t)rows * Cin, 1, 0, s);
-  // rows of fp32 -> split rows (a (1, Cin, rows) channel-first view is not what we have: use the LayerNorm kernel's
-  // split store on normalised rows -- any well-scaled data will do for timing)
-  std::vector<float> ones((size_t)Cin, 1.f), zeros((size_t)Cin, 0.f);
-  launch_layernorm_tm(xf, Cin, to_dev(*C, ones.data(), Cin), to_dev(*C, zeros.data(), Cin), nullptr, 0, xs, (long)L.cin_gp * 4,
-                      rows, Cin, 1e-5f, nullptr, nullptr, 0, s);
+  // N(0,1) data read as a channel-first (1, Cin, rows) map -> split rows
+  launch_cf_to_tm(xf, (long)Cin * rows, nullptr, 0, xs, (long)L.cin_gp * 4, 1, Cin, (int)rows, nullptr, nullptr, 0, s);
   GemmArgs g = gemm_args(L, rows, (int)rows);
   g.xs = xs, g.ld_xs = (long)L.cin_gp * 4;
   g.y = dy, g.ld_y = Cout;

@@ -310,21 +310,14 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     // Tile choice (the k-order does not depend on it: every tile gives the same bits).  Two workgroups fit a CU; a
     // workgroup's time ~ its MFMA work + a fixed prologue / epilogue.
     const int forced = g_conv_override.tile >= 200 ? g_conv_override.tile - 200 : -1;   // tuning / tests (rvcx_conv_override)
-    int best = 0;
-    double best_t = 1e300;
-    const double ksteps = a.cin_p / 16.0;
-    for (int t = 0; t < kNumGemm; ++t) {
-      if (forced >= 0 && forced != t) continue;
-      const long blocks = (long)cdiv(a.cout_p, kGemm[t].bm) * cdiv64(a.rows, kGemm[t].bn);
-      const double work = (kGemm[t].bm / 32) * (kGemm[t].bn / 32) / 4.0 * ksteps * 96.0 + 6000.0;   // cycles per workgroup
-      const double per_cu = std::ceil(blocks / 256.0);
-      // two co-resident workgroups share the matrix pipes but hide each other's prologue / epilogue
-      const double t_est = per_cu * work * (per_cu >= 2 ? 0.9 : 1.0);
-      if (t_est < best_t) {
-        best_t = t_est;
-        best = t;
-      }
-    }
+    // Measured on the HuBERT-base shapes (tools/bench_gemm.py): the launches are small against the chip -- 1200 to 3600
+    // output tiles of 32 x 32 for 1024 SIMDs at B = 1 -- so what counts is how many workgroups share a CU (they hide
+    // each other's load latency), not operand reuse; the large tile only pays once every CU holds two of them.
+    auto blocks = [&](int t) { return (long)cdiv(a.cout_p, kGemm[t].bm) * cdiv64(a.rows, kGemm[t].bn); };
+    int best = 3;                                          // 64 x 64
+    if (blocks(0) >= 512) best = 0;                        // 128 x 128
+    else if (blocks(1) >= 384) best = 1;                   // 64 x 128
+    if (forced >= 0) best = forced;
     const GemmCfg& F = kGemm[best];
     dim3 grid((unsigned)cdiv64(a.rows, F.bn), cdiv(a.cout_p, F.bm), 1);
     gemm_init();

@@ -352,15 +352,20 @@ const PairCfg kPair[] = {
     // C = 128: k = 3 and k = 11 run 768 threads on N1 = 192 (three waves per SIMD: +12 % / +6 % in tools/bench_pair.py),
     // k = 7 keeps 512 threads with all 7 taps resident (the 768-thread form would spill)
     make_cfg<128, 6, 4, 3, 3, 3, 1>(),  make_cfg<128, 4, 4, 2, 7, 7, 1>(),  make_cfg<128, 6, 4, 3, 11, 4, 1>(),
+    // C = 256 (NSF stage 0): the c1 tile of all 256 channels is 1 KB per position, N1 = 96 fills the LDS (154 KB with two
+    // weight taps resident); 12 waves of 64 x 32.  RVCX_PAIR_C256=0: the two conv_h3 launches instead
+    make_cfg<256, 3, 4, 3, 3, 2, 1>(),  make_cfg<256, 3, 4, 3, 7, 2, 1>(),  make_cfg<256, 3, 4, 3, 11, 2, 1>(),
     // RVCX_PAIR_VARIANT=1: the alternatives, for A/B runs
     make_cfg<128, 4, 4, 2, 3, 3, 2, 1>(),  make_cfg<128, 6, 4, 3, 7, 4, 1, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1, 1>(),
 };
-constexpr int kPairBase = 9;
+constexpr int kPairBase = 12;
 const PairCfg* find_cfg(int C, int K) {
   static const int variant = getenv("RVCX_PAIR_VARIANT") ? atoi(getenv("RVCX_PAIR_VARIANT")) : 0;
   if (variant != 0)
     for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
       if (kPair[i].variant == variant && kPair[i].C == C && kPair[i].K == K) return &kPair[i];
+  static const bool c256 = !getenv("RVCX_PAIR_C256") || atoi(getenv("RVCX_PAIR_C256")) != 0;
+  if (C == 256 && !c256) return nullptr;
   for (int i = 0; i < kPairBase; ++i)
     if (kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   return nullptr;
@@ -380,7 +385,7 @@ bool resblock_pair_ok(const PairArgs& a) {
   return find_cfg(a.C, a.k) != nullptr;
 }
 
-int resblock_pair_slot(int C) { return C == 32 ? 50 : (C == 64 ? 51 : 52); }
+int resblock_pair_slot(int C) { return C == 32 ? 50 : (C == 64 ? 51 : (C == 128 ? 52 : 58)); }
 
 void resblock_pair_describe(ConvProfile* p) {
   for (int i = 0; i < kPairBase; ++i) {
