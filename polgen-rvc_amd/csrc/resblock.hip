@@ -44,10 +44,15 @@ constexpr int kAbl = RVCX_PAIR_ABL;
 // K: taps (compile time: the k-loop is straight-line code, fragment reads of slot s+1 are issued ahead of the MFMAs
 // of slot s).  A stage = NCS chunks of 16 input channels x a group of <= KKT taps ("slots"); NCS > 1 only with
 // KKT == K (small kernels: more MFMA work between two barriers).
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS>
+// TRIM: halo and pad sized for THIS kernel size (dilation <= 5) instead of the common 64 / 16 columns: the small-tile
+// variants that put two workgroups on a CU need every kilobyte.
+constexpr int pair_halo(int K, bool trim) { return trim ? (((K - 1) * 5 + 1) & ~1) : kPairHalo; }
+constexpr int pair_pady(int K, bool trim) { return trim ? K - 1 : kPairPadY; }
+
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool TRIM = false>
 __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairArgs a) {
   constexpr int THREADS = 64 * WR * WC;
-  constexpr int N1 = 32 * NT, N1P = N1 + kPairPadY, WROW = N1 + kPairHalo;
+  constexpr int N1 = 32 * NT, N1P = N1 + pair_pady(K, TRIM), WROW = N1 + pair_halo(K, TRIM);
   constexpr int WM = (C / 32) / WR, WN = NT / WC;
   constexpr int NCHUNK = C / 16;
   constexpr int NG = (K + KKT - 1) / KKT;                 // tap groups per chunk set
@@ -339,11 +344,12 @@ struct PairCfg {
   size_t lds;
   void (*kern)(const PairArgs);
 };
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0>
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false>
 constexpr PairCfg make_cfg() {
   return {C, K, 32 * NT, 64 * WR * WC, V,
-          (size_t)((C / 16) * 4 * (32 * NT + kPairPadY) + NCS * KKT * 4 * C + NCS * 4 * (32 * NT + kPairHalo)) * 16,
-          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS>};
+          (size_t)((C / 16) * 4 * (32 * NT + pair_pady(K, TRIM)) + NCS * KKT * 4 * C +
+                   NCS * 4 * (32 * NT + pair_halo(K, TRIM))) * 16,
+          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM>};
 }
 // (C, K) instantiations of the RVC v2 decoders (resblock kernels 3 / 7 / 11): 512 threads, one workgroup per CU
 const PairCfg kPair[] = {
@@ -357,6 +363,13 @@ const PairCfg kPair[] = {
     make_cfg<256, 3, 4, 3, 3, 2, 1>(),  make_cfg<256, 3, 4, 3, 7, 2, 1>(),  make_cfg<256, 3, 4, 3, 11, 2, 1>(),
     // RVCX_PAIR_VARIANT=1: the alternatives, for A/B runs
     make_cfg<128, 4, 4, 2, 3, 3, 2, 1>(),  make_cfg<128, 6, 4, 3, 7, 4, 1, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1, 1>(),
+    // RVCX_PAIR_VARIANT=2: small tiles, TWO workgroups per CU (<= 80 KB of LDS, <= 168 registers): one computes while the
+    // other is in its prologue / epilogue.  The timing ablations of round 3 (tools/ablate_pair.sh) showed the single
+    // resident workgroup serialises its phases: MFMA time + everything else = the whole launch, and the residual loads /
+    // output stores of the c2 epilogue alone are 80 us of every launch.
+    make_cfg<32, 8, 1, 4, 3, 3, 2, 2, true>(),   make_cfg<32, 8, 1, 4, 7, 7, 1, 2, true>(),   make_cfg<32, 8, 1, 4, 11, 11, 1, 2, true>(),
+    make_cfg<64, 4, 2, 2, 3, 3, 2, 2, true>(),   make_cfg<64, 4, 2, 2, 7, 7, 1, 2, true>(),   make_cfg<64, 4, 2, 2, 11, 4, 1, 2, true>(),
+    make_cfg<128, 3, 2, 3, 3, 2, 1, 2, true>(),  make_cfg<128, 3, 2, 3, 7, 2, 1, 2, true>(),  make_cfg<128, 3, 2, 3, 11, 2, 1, 2, true>(),
 };
 constexpr int kPairBase = 12;
 const PairCfg* find_cfg(int C, int K) {
@@ -365,7 +378,7 @@ const PairCfg* find_cfg(int C, int K) {
     for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
       if (kPair[i].variant == variant && kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   static const bool c256 = !getenv("RVCX_PAIR_C256") || atoi(getenv("RVCX_PAIR_C256")) != 0;
-  if (C == 256 && !c256) return nullptr;
+  if (C == 256 && (!c256 || K != 3)) return nullptr;     // k = 7 / 11 at C = 256: the two launches are faster (bench_pair)
   for (int i = 0; i < kPairBase; ++i)
     if (kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   return nullptr;
@@ -380,7 +393,7 @@ bool resblock_pair_enabled() {
 
 bool resblock_pair_ok(const PairArgs& a) {
   if (!resblock_pair_enabled() || !a.w1 || !a.w2) return false;
-  if (a.dil < 1 || (a.k - 1) * a.dil > kPairHalo - 14) return false;
+  if (a.dil < 1 || a.dil > 5 || (a.k - 1) * a.dil > kPairHalo - 14) return false;
   if ((long)a.C * a.cs * 4 >= kH3Oob || (long)a.k * a.C * a.C * 4 >= kH3Oob) return false;
   return find_cfg(a.C, a.k) != nullptr;
 }

@@ -21,15 +21,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SELECT = "tiny_chunked or tiny_ciargs or c2_30s_48k or float_waveform_vs_oracle"
 
 
-def _run_mode(env_extra):
+def _run_mode(env_extra, file="test_gpu_pipeline.py", select=SELECT, passed="4 passed"):
     env = dict(os.environ, **env_extra)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-           os.path.join(HERE, "test_gpu_pipeline.py"), "-k", SELECT, "-s"]
+           os.path.join(HERE, file), "-k", select, "-s"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(HERE))
     tail = (r.stdout[-3000:] + "\n" + r.stderr[-2000:])
     print(tail)
     assert r.returncode == 0, tail
-    assert "4 passed" in r.stdout, tail
+    assert passed in r.stdout, tail
     return r.stdout
 
 
@@ -44,3 +44,10 @@ def test_unfused_resblock_mode_passes_the_reference_goldens():
 
 def test_channel_first_linear_mode_passes_the_reference_goldens():
     _run_mode({"RVCX_GEMM": "0"})
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_alternative_fused_resblock_tiles_are_bit_identical_too(variant):
+    """RVCX_PAIR_VARIANT selects other tilings of the fused ResBlock step (2: small tiles, two workgroups per CU): the
+    k-order is the same, so each must equal the two conv launches bit for bit and torch within fp32 rounding."""
+    _run_mode({"RVCX_PAIR_VARIANT": variant}, "test_gpu_conv.py", "fused_resblock", "11 passed")
