@@ -49,7 +49,11 @@ constexpr int kAbl = RVCX_PAIR_ABL;
 constexpr int pair_halo(int K, bool trim) { return trim ? (((K - 1) * 5 + 1) & ~1) : kPairHalo; }
 constexpr int pair_pady(int K, bool trim) { return trim ? K - 1 : kPairPadY; }
 
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool TRIM = false>
+// RESPF: when the residual x of the output tile is fetched.  0: in the epilogue, eight values at a time (four dependent
+// load -> store round trips per wave: ~5 us of every workgroup, 3 ms of a 30 s clip -- round-3 ablation); 1: all of a
+// wave's values in one go right behind the c2 loop; 2: ahead of the c2 loop, so that the loads fly under its MFMAs
+// (where 16 WM WN more registers fit).
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool TRIM = false, int RESPF = 0>
 __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairArgs a) {
   constexpr int THREADS = 64 * WR * WC;
   constexpr int N1 = 32 * NT, N1P = N1 + pair_pady(K, TRIM), WROW = N1 + pair_halo(K, TRIM);
@@ -275,6 +279,38 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
 
   // ================================================================ phase 2: y = c2(Y1) + b2 + x
+  float resv[RESPF ? WM : 1][RESPF ? WN : 1][16];
+  auto load_res = [&]() {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int col = wc * (WN * 32) + n * 32 + i;
+        const int pos = n0 + col;
+        const bool ok = col < BN_OUT && pos < a.T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = wr * (WM * 32) + m * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+          if (RESPF == 2) {
+            // Issued HERE, not where the compiler would like them (it sinks a plain load across the whole c2 loop to its
+            // first use): inline asm stays put.  The compiler does not count these loads; they are older than every
+            // load of the c2 loop, loads return in order, so its counted waits stay correct (they only wait longer),
+            // and the epilogue waits vmcnt(0) by hand before the first use.
+            const float* p = a.x + (long)b * a.bs + (ok ? (long)co * a.cs + pos : 0);
+            float v;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+#else
+            v = *p;
+#endif
+            resv[RESPF ? m : 0][RESPF ? n : 0][r] = v;
+          } else {
+            resv[RESPF ? m : 0][RESPF ? n : 0][r] = h3_load1(xr, ok ? (co * a.cs + pos) * 4 : kH3Oob);
+          }
+        }
+      }
+  };
+  if (RESPF == 2 && !(kAbl & 2)) load_res();
   zero_acc();
   {
     int chunk = 0, g = 0;
@@ -298,6 +334,10 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
     }
   }
   // c2 epilogue: bias, residual (x itself: L2-hot, this workgroup staged it a moment ago), length mask, store
+  if (RESPF == 1 && !(kAbl & 2)) load_res();
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (RESPF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
   for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -318,7 +358,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
         for (int q = 0; q < 8; ++q) {
           const int co = co_base + ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
           bv[q] = a.b2 ? a.b2[co] : 0.f;
-          rv[q] = xb[(long)co * a.cs];
+          rv[q] = RESPF ? resv[RESPF ? m : 0][RESPF ? n : 0][r0 + q] : xb[(long)co * a.cs];
           pv[q] = (y2b && a.acc2_mode != ACC2_SET) ? y2b[(long)co * a.cs] : 0.f;
         }
 #pragma unroll
@@ -344,23 +384,23 @@ struct PairCfg {
   size_t lds;
   void (*kern)(const PairArgs);
 };
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false>
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false, int RESPF = 0>
 constexpr PairCfg make_cfg() {
   return {C, K, 32 * NT, 64 * WR * WC, V,
           (size_t)((C / 16) * 4 * (32 * NT + pair_pady(K, TRIM)) + NCS * KKT * 4 * C +
                    NCS * 4 * (32 * NT + pair_halo(K, TRIM))) * 16,
-          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM>};
+          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM, RESPF>};
 }
 // (C, K) instantiations of the RVC v2 decoders (resblock kernels 3 / 7 / 11): 512 threads, one workgroup per CU
 const PairCfg kPair[] = {
-    make_cfg<32, 16, 1, 8, 3, 3, 2>(),  make_cfg<32, 16, 1, 8, 7, 7, 1>(),  make_cfg<32, 16, 1, 8, 11, 11, 1>(),
-    make_cfg<64, 8, 2, 4, 3, 3, 2>(),   make_cfg<64, 8, 2, 4, 7, 7, 1>(),   make_cfg<64, 8, 2, 4, 11, 11, 1>(),
+    make_cfg<32, 16, 1, 8, 3, 3, 2, 0, false, 2>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 0, false, 2>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 0, false, 2>(),
+    make_cfg<64, 8, 2, 4, 3, 3, 2, 0, false, 2>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 0, false, 2>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 0, false, 2>(),
     // C = 128: k = 3 and k = 11 run 768 threads on N1 = 192 (three waves per SIMD: +12 % / +6 % in tools/bench_pair.py),
     // k = 7 keeps 512 threads with all 7 taps resident (the 768-thread form would spill)
-    make_cfg<128, 6, 4, 3, 3, 3, 1>(),  make_cfg<128, 4, 4, 2, 7, 7, 1>(),  make_cfg<128, 6, 4, 3, 11, 4, 1>(),
+    make_cfg<128, 6, 4, 3, 3, 3, 1, 0, false, 2>(),  make_cfg<128, 4, 4, 2, 7, 7, 1, 0, false, 2>(),  make_cfg<128, 6, 4, 3, 11, 4, 1, 0, false, 1>(),
     // C = 256 (NSF stage 0): the c1 tile of all 256 channels is 1 KB per position, N1 = 96 fills the LDS (154 KB with two
     // weight taps resident); 12 waves of 64 x 32.  RVCX_PAIR_C256=0: the two conv_h3 launches instead
-    make_cfg<256, 3, 4, 3, 3, 2, 1>(),  make_cfg<256, 3, 4, 3, 7, 2, 1>(),  make_cfg<256, 3, 4, 3, 11, 2, 1>(),
+    make_cfg<256, 3, 4, 3, 3, 2, 1, 0, false, 1>(),  make_cfg<256, 3, 4, 3, 7, 2, 1, 0, false, 1>(),  make_cfg<256, 3, 4, 3, 11, 2, 1, 0, false, 1>(),
     // RVCX_PAIR_VARIANT=1: the alternatives, for A/B runs
     make_cfg<128, 4, 4, 2, 3, 3, 2, 1>(),  make_cfg<128, 6, 4, 3, 7, 4, 1, 1>(),  make_cfg<128, 4, 4, 2, 11, 6, 1, 1>(),
     // RVCX_PAIR_VARIANT=2: small tiles, TWO workgroups per CU (<= 80 KB of LDS, <= 168 registers): one computes while the
@@ -370,6 +410,10 @@ const PairCfg kPair[] = {
     make_cfg<32, 8, 1, 4, 3, 3, 2, 2, true>(),   make_cfg<32, 8, 1, 4, 7, 7, 1, 2, true>(),   make_cfg<32, 8, 1, 4, 11, 11, 1, 2, true>(),
     make_cfg<64, 4, 2, 2, 3, 3, 2, 2, true>(),   make_cfg<64, 4, 2, 2, 7, 7, 1, 2, true>(),   make_cfg<64, 4, 2, 2, 11, 4, 1, 2, true>(),
     make_cfg<128, 3, 2, 3, 3, 2, 1, 2, true>(),  make_cfg<128, 3, 2, 3, 7, 2, 1, 2, true>(),  make_cfg<128, 3, 2, 3, 11, 2, 1, 2, true>(),
+    // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
+    make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
+    make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),
+    make_cfg<128, 6, 4, 3, 3, 3, 1, 3>(),  make_cfg<128, 4, 4, 2, 7, 7, 1, 3>(),  make_cfg<128, 6, 4, 3, 11, 4, 1, 3>(),
 };
 constexpr int kPairBase = 12;
 const PairCfg* find_cfg(int C, int K) {

@@ -184,7 +184,7 @@ def test_every_3x3_tile_stores_every_subtile(ctx, tile):
 
 @pytest.mark.parametrize("C,K,d,T", [(32, 3, 1, 5000), (32, 11, 5, 777), (64, 7, 3, 4099), (64, 11, 5, 300),
                                      (128, 3, 1, 1000), (128, 7, 1, 2500), (128, 11, 5, 1531), (128, 11, 3, 100),
-                                     (256, 3, 1, 700), (256, 7, 3, 1201), (256, 11, 5, 433)])
+                                     (256, 3, 1, 700), (256, 3, 1, 1201)])
 def test_fused_resblock_pair_equals_two_launches(ctx, C, K, d, T):
     """One ResBlock1 step (residuals.py:45-53) as one kernel (resblock.hip): against torch fp32 within fp32
     rounding, and bit-identical to the two conv_h3 launches it replaces -- ragged batch (per-item lengths,

@@ -50,4 +50,4 @@ def test_channel_first_linear_mode_passes_the_reference_goldens():
 def test_alternative_fused_resblock_tiles_are_bit_identical_too(variant):
     """RVCX_PAIR_VARIANT selects other tilings of the fused ResBlock step (2: small tiles, two workgroups per CU): the
     k-order is the same, so each must equal the two conv launches bit for bit and torch within fp32 rounding."""
-    _run_mode({"RVCX_PAIR_VARIANT": variant}, "test_gpu_conv.py", "fused_resblock", "11 passed")
+    _run_mode({"RVCX_PAIR_VARIANT": variant}, "test_gpu_conv.py", "fused_resblock", "10 passed")

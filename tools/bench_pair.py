@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 
-SHAPES = [(256, 38376, 3, 1), (256, 38376, 7, 3), (256, 38376, 11, 5), (128, 383760, 3, 1), (128, 383760, 7, 3), (128, 383760, 11, 5), (64, 767520, 3, 1), (64, 767520, 7, 3),
+SHAPES = [(256, 38376, 3, 1), (128, 383760, 3, 1), (128, 383760, 7, 3), (128, 383760, 11, 5), (64, 767520, 3, 1), (64, 767520, 7, 3),
           (64, 767520, 11, 5), (32, 1535040, 3, 1), (32, 1535040, 7, 3), (32, 1535040, 11, 5)]
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
