@@ -89,6 +89,7 @@ struct PairArgs {
   float slope = 0.1f;
   int acc2_mode = ACC2_NONE;
   float acc2_div = 1.f;
+  int xcd_order = 1;             // tiles in XCD-contiguous order (resblock.hip); 0: tile = blockIdx.x (RVCX_PAIR_XCD=0)
   int* ovf = nullptr;            // as ConvArgs::ovf
   int* ovf_layer = nullptr;      // as ConvArgs::ovf_layer (the pair reports as its first conv)
   int seq = 0;

@@ -77,7 +77,16 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
   const int pad1 = (K - 1) * a.dil / 2;
-  const int n0 = blockIdx.x * BN_OUT;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2:
+  // with tile = blockIdx.x neighbouring tiles always sit on DIFFERENT L2s, so the halo columns two tiles share are
+  // fetched from HBM twice and the cache line that straddles a tile boundary (BN_OUT is not a multiple of 32
+  // positions) is written back half-filled by two L2s.  Here XCD x works through a contiguous range of tiles.
+  int tile = blockIdx.x;
+  if (a.xcd_order) {
+    const int nt = gridDim.x, xcd = tile & 7, idx = tile >> 3, q = nt >> 3, r = nt & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n0 = tile * BN_OUT;
   const int len = a.lens ? a.lens[b] : a.T;
   const int wuse = N1 + (K - 1) * a.dil;        // input columns the tile really needs
   const int in_base = n0 - H2 - pad1;           // position of input-tile column 0
@@ -471,7 +480,10 @@ void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
   const PairCfg& c = *find_cfg(a.C, a.k);
   const int bn_out = c.n1 - (a.k - 1);
   dim3 grid(cdiv(a.T, bn_out), 1, a.B);
-  hipLaunchKernelGGL(c.kern, grid, dim3(c.threads), c.lds, stream, a);
+  static const int xcd = getenv("RVCX_PAIR_XCD") ? atoi(getenv("RVCX_PAIR_XCD")) : 1;
+  PairArgs b = a;
+  b.xcd_order = xcd;
+  hipLaunchKernelGGL(c.kern, grid, dim3(c.threads), c.lds, stream, b);
   RVCX_HIP(hipGetLastError());
 }
 
