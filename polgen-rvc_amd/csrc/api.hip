@@ -231,6 +231,12 @@ int64_t rvcx_fp32_layers(rvcx_ctx* ctx) {
 int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
 
 int rvcx_debug_inject(rvcx_ctx* ctx, int what) {
+  if (ctx && what == 2) {          // read and clear the raw device error word (debugging builds set extra bits)
+    int v = 0;
+    (void)hipMemcpy(&v, ctx->c.dev_err, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemset(ctx->c.dev_err, 0, sizeof(int));
+    return v;
+  }
   if (!ctx || what != 1) return -1;
   ctx->c.inject_gru_timeout = true;
   return 0;

@@ -88,6 +88,15 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// Partial sums in LDS: row r (= 4 rg + q) of one column slice lives at [q * NRG + rg], so a thread stores its four rows as
+// four ds_write_b32 and the 64 gate lanes read 64 different banks.  The natural layout ([r], one ds_write_b128 per
+// thread) is NOT used: with another LDS-heavy kernel (the time-major GEMM) resident on the same CU, gate lanes were seen
+// to read the PREVIOUS step's value in one dword q of the 16-byte stores of 16 consecutive lanes -- after s_waitcnt
+// lgkmcnt(0) + s_barrier, a few times per ten thousand steps, never without the co-resident kernel (round 3;
+// tools/check_gru_under_load.py reproduces it: 4-7 distinct results of 24 with b128, 1 of 24 with b32).
+template <int NRG>
+__device__ __forceinline__ int part_at(int row) { return (row & 3) * NRG + (row >> 2); }
+
 union Granule {
   unsigned long long u;
   struct {
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
   const int rg = tid % GRU_NRG, cs = tid / GRU_NRG;
   const float* W = whh_t + (long)dir * H * 3 * H;
   // this thread's 4 x 32 weights: W_hh[grow(rg*4+q)][cs*32 .. +32)  (whh_t is (H, 3H): column-major rows)
+  static_assert(GRU_RPT == 4, "part_at() places four rows per thread");
   float w[GRU_RPT][GRU_CPT];
 #pragma unroll
   for (int q = 0; q < GRU_RPT; ++q) {
@@ -184,16 +194,16 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
       }
     }
 #pragma unroll
-    for (int q = 0; q < GRU_RPT; ++q) part[cs][rg * GRU_RPT + q] = acc[q];
+    for (int q = 0; q < GRU_RPT; ++q) part[cs][q * GRU_NRG + rg] = acc[q];   // four 4-byte stores (see part_at)
     lds_barrier();
     // ---- gates for the owned units, publish h_t[ju] as a {value, step+1} granule
     if (tid < GRU_U) {
       float sr = 0.f, sz = 0.f, sn = 0.f;
 #pragma unroll
       for (int p = 0; p < GRU_NCS; ++p) {
-        sr += part[p][tid];
-        sz += part[p][GRU_U + tid];
-        sn += part[p][2 * GRU_U + tid];
+        sr += part[p][part_at<GRU_NRG>(tid)];
+        sz += part[p][part_at<GRU_NRG>(GRU_U + tid)];
+        sn += part[p][part_at<GRU_NRG>(2 * GRU_U + tid)];
       }
       const float ghr = sr + bh_r, ghz = sz + bh_z, ghn = sn + bh_n;
       // hardware exp2 / rcp (1-2 ulp): the gate chain is on the serial critical path of every step
@@ -237,7 +247,8 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
   RVCX_CHECK(H == GRU_H, "bigru: hidden size must be 256 (RMVPE)");
   // the cluster kernel needs all 2*B*NC workgroups co-resident (they spin on each other)
   static const int nc = getenv("RVCX_GRU_NC") ? atoi(getenv("RVCX_GRU_NC")) : GRU_NC;
-  if (scratch && err && 2 * B * nc <= 128 && !g_gru_no_cluster) {
+  static const bool plain = getenv("RVCX_GRU_PLAIN") && atoi(getenv("RVCX_GRU_PLAIN")) != 0;   // debugging: one WG per direction
+  if (scratch && err && 2 * B * nc <= 128 && !g_gru_no_cluster && !plain) {
     unsigned long long* xbuf = static_cast<unsigned long long*>(scratch);
     RVCX_HIP(hipMemsetAsync(scratch, 0, bigru_scratch_bytes(B), stream));
     static int colocate = -1;

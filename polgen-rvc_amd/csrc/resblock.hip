@@ -52,7 +52,10 @@ constexpr int pair_pady(int K, bool trim) { return trim ? K - 1 : kPairPadY; }
 // RESPF: when the residual x of the output tile is fetched.  0: in the epilogue, eight values at a time (four dependent
 // load -> store round trips per wave: ~5 us of every workgroup, 3 ms of a 30 s clip -- round-3 ablation); 1: all of a
 // wave's values in one go right behind the c2 loop; 2: ahead of the c2 loop, so that the loads fly under its MFMAs
-// (where 16 WM WN more registers fit).
+// (where 16 WM WN more registers fit).  3: the WIDE epilogue -- every 32 x 32 accumulator tile goes through a 4.5 KB LDS
+// tile of its wave and comes back transposed, a lane then owns 4 consecutive positions of one channel: residual loads and
+// output stores are 16 bytes per lane, a quarter of the memory instructions (the dword stores were store-ISSUE bound).
+// Needs 16-byte aligned rows (cs, T multiples of 4); the tile keeps a multiple of 4 output positions.
 template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool TRIM = false, int RESPF = 0>
 __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairArgs a) {
   constexpr int THREADS = 64 * WR * WC;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   constexpr int SL = NCS * KKT;                           // weight slots resident per stage
   constexpr int A_ELEMS = SL * 4 * C, NA = (A_ELEMS + THREADS - 1) / THREADS;
   constexpr int B_TASKS = NCS * 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
-  constexpr int BN_OUT = N1 - (K - 1), H2 = (K - 1) / 2;
+  constexpr int BN_OUT = RESPF == 3 ? ((N1 - (K - 1)) & ~3) : N1 - (K - 1), H2 = (K - 1) / 2;
   static_assert(WM >= 1 && WN >= 1 && WM * WR * 32 == C && WN * WC == NT, "bad tile");
   static_assert(NCS == 1 || KKT == K, "several chunks per stage only with all taps resident");
   static_assert(NCHUNK % NCS == 0, "chunk sets must tile the channels");
@@ -342,6 +345,57 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
       chunk = chunk1;
     }
   }
+  if constexpr (RESPF == 3) {
+    constexpr int P = 36;                              // floats per staged row: 16-byte aligned, rows 4 banks apart
+    static_assert(THREADS / 64 * 32 * P * 4 <= NCHUNK * 4 * N1P * 16, "staging tiles must fit the Y1 region");
+    __syncthreads();                                   // every wave is done reading Y1: the staging tiles overlay it
+    float* stg = reinterpret_cast<float*>(lds) + wave * (32 * P);
+    const int lr = lane >> 3, lc = (lane & 7) * 4;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * P + i] = acc[m][n][r] * inv;
+        __builtin_amdgcn_wave_barrier();               // same wave, in-order LDS queue: ordering for the compiler only
+        const int col0 = wc * (WN * 32) + n * 32 + lc;
+        const int pos0 = n0 + col0;
+        const bool ok = col0 < BN_OUT && pos0 < a.T && !((kAbl & 2) && acc[m][n][0] != 12345.678f);
+        float4 v[4], rv[4], pv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+          const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+          v[p] = *reinterpret_cast<const float4*>(stg + (lr + 8 * p) * P + lc);
+          rv[p] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          pv[p] = (ok && a.acc2_mode != ACC2_NONE && a.acc2_mode != ACC2_SET) ? *reinterpret_cast<const float4*>(a.y2 + off)
+                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+            const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+            const float bb = a.b2 ? a.b2[co] : 0.f;
+            float o[4] = {v[p].x + bb + rv[p].x, v[p].y + bb + rv[p].y, v[p].z + bb + rv[p].z, v[p].w + bb + rv[p].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pos0 + q < len ? o[q] : 0.f;
+            if (a.y) *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.acc2_mode != ACC2_NONE) {
+              const float pp[4] = {pv[p].x, pv[p].y, pv[p].z, pv[p].w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (a.acc2_mode == ACC2_ADD) o[q] = pp[q] + o[q];
+                else if (a.acc2_mode == ACC2_ADD_DIV) o[q] = (pp[q] + o[q]) / a.acc2_div;
+              }
+              *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+          }
+        }
+      }
+    return;
+  }
   // c2 epilogue: bias, residual (x itself: L2-hot, this workgroup staged it a moment ago), length mask, store
   if (RESPF == 1 && !(kAbl & 2)) load_res();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -389,13 +443,14 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
 }
 
 struct PairCfg {
-  int C, K, n1, threads, variant;
+  int C, K, n1, threads, variant, bn_out;
+  bool wide;                     // wide epilogue: rows must be 16-byte aligned
   size_t lds;
   void (*kern)(const PairArgs);
 };
 template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false, int RESPF = 0>
 constexpr PairCfg make_cfg() {
-  return {C, K, 32 * NT, 64 * WR * WC, V,
+  return {C, K, 32 * NT, 64 * WR * WC, V, RESPF == 3 ? ((32 * NT - (K - 1)) & ~3) : 32 * NT - (K - 1), RESPF == 3,
           (size_t)((C / 16) * 4 * (32 * NT + pair_pady(K, TRIM)) + NCS * KKT * 4 * C +
                    NCS * 4 * (32 * NT + pair_halo(K, TRIM))) * 16,
           resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM, RESPF>};
@@ -419,19 +474,33 @@ const PairCfg kPair[] = {
     make_cfg<32, 8, 1, 4, 3, 3, 2, 2, true>(),   make_cfg<32, 8, 1, 4, 7, 7, 1, 2, true>(),   make_cfg<32, 8, 1, 4, 11, 11, 1, 2, true>(),
     make_cfg<64, 4, 2, 2, 3, 3, 2, 2, true>(),   make_cfg<64, 4, 2, 2, 7, 7, 1, 2, true>(),   make_cfg<64, 4, 2, 2, 11, 4, 1, 2, true>(),
     make_cfg<128, 3, 2, 3, 3, 2, 1, 2, true>(),  make_cfg<128, 3, 2, 3, 7, 2, 1, 2, true>(),  make_cfg<128, 3, 2, 3, 11, 2, 1, 2, true>(),
+    // variant 4: the wide (LDS-transposed, 16 bytes per lane) epilogue -- the default whenever the rows are 16-byte aligned
+    make_cfg<32, 16, 1, 8, 3, 3, 2, 4, false, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 4, false, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 4, false, 3>(),
+    make_cfg<64, 8, 2, 4, 3, 3, 2, 4, false, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 4, false, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 4, false, 3>(),
+    make_cfg<128, 6, 4, 3, 3, 3, 1, 4, false, 3>(),  make_cfg<128, 4, 4, 2, 7, 7, 1, 4, false, 3>(),  make_cfg<128, 6, 4, 3, 11, 4, 1, 4, false, 3>(),
+    make_cfg<256, 3, 4, 3, 3, 2, 1, 4, false, 3>(),  make_cfg<256, 3, 4, 3, 7, 2, 1, 4, false, 3>(),  make_cfg<256, 3, 4, 3, 11, 2, 1, 4, false, 3>(),
     // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
     make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
     make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),
     make_cfg<128, 6, 4, 3, 3, 3, 1, 3>(),  make_cfg<128, 4, 4, 2, 7, 7, 1, 3>(),  make_cfg<128, 6, 4, 3, 11, 4, 1, 3>(),
 };
 constexpr int kPairBase = 12;
-const PairCfg* find_cfg(int C, int K) {
+// rows 16-byte aligned: what the wide epilogue needs
+bool pair_aligned(const PairArgs& a) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return a.cs % 4 == 0 && a.T % 4 == 0 && a.bs % 4 == 0 && al(a.x) && al(a.y) && al(a.y2);
+}
+
+const PairCfg* find_cfg(const PairArgs& a) {
+  const int C = a.C, K = a.k;
   static const int variant = getenv("RVCX_PAIR_VARIANT") ? atoi(getenv("RVCX_PAIR_VARIANT")) : 0;
-  if (variant != 0)
-    for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
-      if (kPair[i].variant == variant && kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   static const bool c256 = !getenv("RVCX_PAIR_C256") || atoi(getenv("RVCX_PAIR_C256")) != 0;
   if (C == 256 && (!c256 || K != 3)) return nullptr;     // k = 7 / 11 at C = 256: the two launches are faster (bench_pair)
+  const int want = variant != 0 ? variant : (pair_aligned(a) ? 4 : 0);
+  if (want != 0)
+    for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
+      if (kPair[i].variant == want && kPair[i].C == C && kPair[i].K == K && (!kPair[i].wide || pair_aligned(a)))
+        return &kPair[i];
   for (int i = 0; i < kPairBase; ++i)
     if (kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   return nullptr;
@@ -448,7 +517,7 @@ bool resblock_pair_ok(const PairArgs& a) {
   if (!resblock_pair_enabled() || !a.w1 || !a.w2) return false;
   if (a.dil < 1 || a.dil > 5 || (a.k - 1) * a.dil > kPairHalo - 14) return false;
   if ((long)a.C * a.cs * 4 >= kH3Oob || (long)a.k * a.C * a.C * 4 >= kH3Oob) return false;
-  return find_cfg(a.C, a.k) != nullptr;
+  return find_cfg(a) != nullptr;
 }
 
 int resblock_pair_slot(int C) { return C == 32 ? 50 : (C == 64 ? 51 : (C == 128 ? 52 : 58)); }
@@ -477,8 +546,8 @@ void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
   RVCX_CHECK(resblock_pair_ok(a), "resblock pair: unsupported shape");
   RVCX_CHECK(a.y != a.x && a.y2 != a.x, "resblock pair: in-place operation is a race (halo reads vs neighbours' stores)");
   resblock_pair_init();
-  const PairCfg& c = *find_cfg(a.C, a.k);
-  const int bn_out = c.n1 - (a.k - 1);
+  const PairCfg& c = *find_cfg(a);
+  const int bn_out = c.bn_out;
   dim3 grid(cdiv(a.T, bn_out), 1, a.B);
   static const int xcd = getenv("RVCX_PAIR_XCD") ? atoi(getenv("RVCX_PAIR_XCD")) : 1;
   PairArgs b = a;
