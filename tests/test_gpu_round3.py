@@ -169,3 +169,46 @@ def test_gru_cluster_timeout_falls_back_to_the_plain_kernel(ctx):
         assert c.gru_fallbacks() == n0 + 1 and np.array_equal(f0c, f0a)
     finally:
         c.close()
+
+
+def test_two_contexts_on_two_threads_reproduce_their_solo_results():
+    """Round 3 found a kernel (the BiGRU cluster kernel's 16-byte LDS stores) whose results varied only while ANOTHER
+    LDS-heavy kernel was resident on the same CU -- no single-context test saw it.  Here two contexts convert different
+    full-size clips at the same time from two host threads (their kernels share the CUs in every combination over the
+    repetitions); every result must equal, bit for bit, what the same context returned alone."""
+    import threading
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    seed, reps = 1900, 6
+    hcfg, rcfg, scfg = S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL, S.SYNTH_CFG_48K
+    hs, rs, ss = S.hubert_state(hcfg, seed), S.rmvpe_state(rcfg, seed), S.synth_state(scfg, seed)
+    params = _lib.Params(0.0, 50.0, 1100.0, 0.0, 0.33, 1.0, 0, 1, 6, 38, 41, 5)
+    ctxs, mids, clips, solo = [], [], [S.make_clip(25, 30.0), S.make_clip(26, 21.7)], []
+    try:
+        for k in range(2):
+            c = _lib.Context(0)
+            ctxs.append(c)
+            c.load_hubert(W.hubert_cfg_struct(hcfg), hs)
+            c.load_rmvpe(W.rmvpe_cfg_struct(rcfg), rs)
+            mids.append(c.load_synth(W.synth_cfg_struct(scfg, 768), ss))
+            solo.append(c.convert_batch(mids[k], [clips[k]], params)[0][0].copy())
+        outs, errs = [[], []], []
+
+        def work(k):
+            try:
+                for _ in range(reps):
+                    outs[k].append(ctxs[k].convert_batch(mids[k], [clips[k]], params)[0][0].copy())
+            except Exception as e:  # noqa: BLE001 -- reported by the assertion below
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for k in range(2):
+            bad = [i for i, o in enumerate(outs[k]) if not np.array_equal(o, solo[k])]
+            assert len(outs[k]) == reps and not bad, f"context {k}: runs {bad} differ from the solo result"
+            assert ctxs[k].gru_fallbacks() == 0 and ctxs[k].fp32_layers() == 0
+    finally:
+        for c in ctxs:
+            c.close()
