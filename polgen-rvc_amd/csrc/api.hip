@@ -153,10 +153,13 @@ int rvcx_create(int device, rvcx_ctx** out) {
     for (auto& e : h->c.ev_front) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : h->c.ev_done) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     {
-      // HuBERT gets its own stream, restricted to 232 of the 256 CUs: RMVPE's many small kernels (and the 8
-      // workgroups of its GRU) always find free CUs instead of queueing behind HuBERT's wide launches, and the
-      // two branches finish together (12.4 ms each instead of 14.0 / 9.0).  RVCX_HUBERT_CUS=0: main stream.
-      const int n = getenv("RVCX_HUBERT_CUS") ? atoi(getenv("RVCX_HUBERT_CUS")) : 232;
+      // HuBERT gets its own stream, restricted to 216 of the 256 CUs: RMVPE's many small kernels (and the 8
+      // workgroups of its GRU) always find free CUs instead of queueing behind HuBERT's wide launches.  Round-3 sweep
+      // with the time-major HuBERT (5.5 ms alone, F0 model 8.1 alone; C2, same box, two runs each): 96 CUs 904x,
+      // 128 951x, 160 973x, 192-200 989-993x, 216 991-998x, 224-232 980-985x.  The F0 model takes >= 9.9 ms beside
+      // HuBERT however few CUs HuBERT gets: what it loses is clock (the chip throttles under HuBERT's MFMA kernels and
+      // the latency-bound GRU steps stretch with it), not CUs.  RVCX_HUBERT_CUS=0: main stream.
+      const int n = getenv("RVCX_HUBERT_CUS") ? atoi(getenv("RVCX_HUBERT_CUS")) : 216;
       if (n > 0 && n < 256) {
         uint32_t mask[8] = {0};
         for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
