@@ -79,8 +79,11 @@ typedef struct {
   int32_t f0_method;      /* RVCX_F0_RMVPE ("rmvpe" / "rmvpe+", pipeline.py:142-167) or RVCX_F0_FCPE ("fcpe", :169-181) */
   int32_t resample_sr;    /* VC.pipeline's resample_sr (pipeline.py:453-454): >= 16000 and != tgt_sr resamples the output
                              before the peak normalisation; 0 (what rvc_infer passes, infer.py:144) = off */
+  int32_t hop_length;     /* VC.get_f0's hop_length: frame step of "mangio-crepe" in 16 kHz samples (pipeline.py:151-152);
+                             <= 0: 128, the reference's default */
+  int32_t reserved;
 } rvcx_params;
-enum { RVCX_F0_RMVPE = 0, RVCX_F0_FCPE = 1 };
+enum { RVCX_F0_RMVPE = 0, RVCX_F0_FCPE = 1, RVCX_F0_CREPE = 2 /* "mangio-crepe", pipeline.py:86-117, 151-152 */ };
 
 /* per-utterance extras of rvcx_convert_batch_ex */
 typedef struct {
@@ -90,6 +93,11 @@ typedef struct {
   const float* inp_f0;
   int32_t inp_f0_rows;
   int32_t reserved;
+  /* "mangio-crepe" only: the +-20 cent triangular dither torchcrepe adds to every decoded frame
+   * (convert.bins_to_cents -> dither: scipy.stats.triang.rvs on the GLOBAL numpy RNG), one float32 per frame in HOST
+   * memory (rvcx_crepe_frames(n_padded, hop) of them), or NULL: drawn from the call's Philox stream */
+  const float* crepe_dither;
+  int64_t crepe_dither_n;
 } rvcx_utt_extra;
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
@@ -106,6 +114,10 @@ int rvcx_load_rmvpe(rvcx_ctx*, const rvcx_rmvpe_cfg*, const rvcx_tensor* tbl, in
 /* replaces FCPEF0Predictor.__init__ / FCPEInfer.__init__ -- rvc/lib/predictors/FCPE.py:708-736, 806-826
  * (tbl: the checkpoint's "model" state_dict) */
 int rvcx_load_fcpe(rvcx_ctx*, const rvcx_fcpe_cfg*, const rvcx_tensor* tbl, int n);
+/* replaces torchcrepe.load.model (called by torchcrepe.predict, rvc/infer/pipeline.py:96): the state dict of
+ * torchcrepe's model.Crepe -- conv{1..6}.weight (Cout, Cin, K, 1) / .bias, conv{1..6}_BN.*, classifier.*; the capacity
+ * ("full" / "tiny" / ...) is read off the shapes.  torchcrepe is not vendored with the reference: parity unpinned */
+int rvcx_load_crepe(rvcx_ctx*, const rvcx_tensor* tbl, int n);
 /* replaces get_vc's Synthesizer construction -- rvc/infer/infer.py:78-105 */
 int rvcx_load_synth(rvcx_ctx*, const rvcx_synth_cfg*, const rvcx_tensor* tbl, int n, int* model_id);
 int rvcx_unload_synth(rvcx_ctx*, int model_id);
@@ -224,6 +236,22 @@ int rvcx_get_f0_x(rvcx_ctx*, const float* x_hd, int64_t n, const rvcx_params* p,
  * rvcx_utt_extra), coarse quantisation.  rmvpe+ returns 1 + n/160 frames, fcpe p_len frames (*frames). */
 int rvcx_get_f0_x_ex(rvcx_ctx*, const float* x_hd, int64_t n, int64_t p_len, const rvcx_params* p, const float* inp_f0,
                      int inp_f0_rows, int32_t* coarse, float* f0, int64_t* frames);
+/* frames torchcrepe.predict(..., pad=True) returns for n samples at frame step hop: 1 + n / hop */
+int64_t rvcx_crepe_frames(int64_t n, int hop);
+/* VC.get_f0_crepe up to the resize (rvc/infer/pipeline.py:90-106): x / quantile(|x|, 0.999), then
+ * torchcrepe.predict(x, 16000, hop, fmin, fmax, model, batch_size = 2 * hop, pad = True) with its default Viterbi decoder.
+ * dither: rvcx_crepe_frames(n, hop) floats (see rvcx_utt_extra) or NULL (Philox, `seed`).  Writes the pitch track (Hz) and,
+ * when non-NULL, the network's sigmoid outputs (360, frames) and the decoded bins. */
+int rvcx_crepe_predict(rvcx_ctx*, const float* x_hd, int64_t n, int hop, float fmin, float fmax, const float* dither_hd,
+                       uint64_t seed, float* pitch_hd, float* probs_hd, int32_t* bins_hd);
+/* op level: core.postprocess + decode.viterbi + convert.bins_to_frequency on given sigmoid outputs (360, F), one Viterbi
+ * pass per `batch` frames */
+int rvcx_op_crepe_decode(rvcx_ctx*, const float* probs_hd, int64_t F, int batch, float fmin, float fmax,
+                         const float* dither_hd, float* pitch_hd, int32_t* bins_hd);
+/* VC.get_f0(..., f0_method="mangio-crepe", hop_length = p->hop_length) on the padded signal x: get_f0_crepe incl. the
+ * resize to p_len frames, pitch shift, f0-file table, coarse quantisation (pipeline.py:86-117, 151-152, 183-201) */
+int rvcx_get_f0_crepe_x(rvcx_ctx*, const float* x_hd, int64_t n, int64_t p_len, const rvcx_params* p, const float* inp_f0,
+                        int inp_f0_rows, const float* dither_hd, int64_t dither_n, int32_t* coarse, float* f0);
 /* host only (no GPU needed): the 100 Hz track VC.get_f0 builds from an f0 file's rows (pipeline.py:186-189: delta_t in
  * float32, np.interp in float64).  Writes min(count, cap) values, returns count. */
 int rvcx_f0_file_track(const float* inp_f0, int rows, double* track, int cap);

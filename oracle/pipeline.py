@@ -230,15 +230,19 @@ def hubert_frames(n: int, cfg) -> int:
 def pipeline(models: Models, geo: Geometry, audio: np.ndarray, pitch: float = 0, sid: int = 0,
              big_npy=None, index_rate: float = 0.0, volume_envelope: float = 1.0,
              protect: float = 0.33, f0_min=50, f0_max=1100, noises=None, seed: int = 0,
-             return_parts=False, f0_method: str = "rmvpe+", inp_f0=None):
-    """VC.pipeline (pipeline.py:289-467) with f0_method="rmvpe+" or "fcpe" (models.fcpe_sd), pitch_guidance=1,
+             return_parts=False, f0_method: str = "rmvpe+", inp_f0=None, hop_length: int = 128, crepe_dither=None):
+    """VC.pipeline (pipeline.py:289-467) with f0_method="rmvpe+", "fcpe" (models.fcpe_sd) or "mangio-crepe"
+    (models.crepe_sd, hop_length, crepe_dither: see oracle/crepe.py), pitch_guidance=1,
     resample_sr=0, f0_file=None.  ``noises`` = list of (z_noise, src_noise) per chunk; drawn from
     torch.manual_seed(seed) in the reference's order (z first, then source) if None."""
     audio = highpass(np.asarray(audio, dtype=np.float64))
     opt_ts = chunk_points(audio, geo)
     audio_pad = np.pad(audio, (geo.t_pad, geo.t_pad), mode="reflect")
     p_len = audio_pad.shape[0] // WINDOW
-    if f0_method == "fcpe":                                   # pipeline.py:169-181
+    if f0_method == "mangio-crepe":                           # pipeline.py:151-152
+        from . import crepe as O_crepe
+        f0 = O_crepe.get_f0_crepe(models.crepe_sd, audio_pad, f0_min, f0_max, p_len, int(hop_length), crepe_dither)
+    elif f0_method == "fcpe":                                 # pipeline.py:169-181
         f0 = O_fcpe.compute_f0(models.fcpe_sd, audio_pad.astype(np.float32), p_len, 0.03)
     else:
         f0 = O_rmvpe.infer_f0(models.rmvpe_sd, models.rmvpe_cfg, audio_pad, 0.03, f0_min, f0_max)

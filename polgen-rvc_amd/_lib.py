@@ -58,14 +58,15 @@ class Params(C.Structure):
                 ("index_rate", C.c_float), ("protect", C.c_float), ("volume_envelope", C.c_float),
                 ("sid", C.c_int32), ("x_pad", C.c_int32), ("x_query", C.c_int32),
                 ("x_center", C.c_int32), ("x_max", C.c_int32), ("seed", C.c_uint64),
-                ("f0_method", C.c_int32), ("resample_sr", C.c_int32)]
+                ("f0_method", C.c_int32), ("resample_sr", C.c_int32), ("hop_length", C.c_int32), ("reserved", C.c_int32)]
 
 
 class UttExtra(C.Structure):
-    _fields_ = [("inp_f0", C.POINTER(C.c_float)), ("inp_f0_rows", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("inp_f0", C.POINTER(C.c_float)), ("inp_f0_rows", C.c_int32), ("reserved", C.c_int32),
+                ("crepe_dither", C.POINTER(C.c_float)), ("crepe_dither_n", C.c_int64)]
 
 
-F0_RMVPE, F0_FCPE = 0, 1        # rvcx_params.f0_method
+F0_RMVPE, F0_FCPE, F0_CREPE = 0, 1, 2        # rvcx_params.f0_method
 
 
 _lib = None
@@ -73,7 +74,7 @@ _lib = None
 # every symbol include/rvcx.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
-    "rvcx_load_rmvpe", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
+    "rvcx_load_rmvpe", "rvcx_load_crepe", "rvcx_crepe_frames", "rvcx_crepe_predict", "rvcx_op_crepe_decode", "rvcx_get_f0_crepe_x", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
     "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_weights_clone", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
@@ -104,6 +105,7 @@ def lib() -> C.CDLL:
         _lib.rvcx_gru_fallbacks.restype = C.c_int64
         _lib.rvcx_resample_len.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
+        _lib.rvcx_crepe_frames.restype = C.c_int64
     return _lib
 
 
@@ -366,6 +368,55 @@ class Context:
         self._ck(lib().rvcx_load_fcpe(self._h, C.byref(cfg_struct), tbl, len(tbl)), "load_fcpe")
         self.fcpe_loaded = True
 
+    def load_crepe(self, state: dict):
+        """torchcrepe's model.Crepe state dict (capacity read off the shapes)."""
+        tbl, keep = make_table(state)
+        self._ck(lib().rvcx_load_crepe(self._h, tbl, len(tbl)), "load_crepe")
+        self.crepe_loaded = True
+
+    @staticmethod
+    def crepe_frames(n: int, hop: int) -> int:
+        return int(lib().rvcx_crepe_frames(C.c_int64(int(n)), int(hop)))
+
+    def crepe_predict(self, x, hop, fmin, fmax, dither=None, seed=0, return_parts=False):
+        """get_f0_crepe up to the resize: x / quantile -> torchcrepe.predict(..., batch_size=2*hop, pad=True): pitch (F,)
+        [, sigmoid outputs (F, 360), Viterbi bins (F,)]."""
+        x = f32(x)
+        F = self.crepe_frames(x.shape[0], hop)
+        pitch = np.empty(F, np.float32)
+        probs = np.empty((360, F), np.float32) if return_parts else None
+        bins = np.empty(F, np.int32) if return_parts else None
+        d = None if dither is None else f32(dither)
+        if d is not None and d.shape[0] < F:
+            raise RvcxError("crepe dither shorter than the frame count")
+        self._ck(lib().rvcx_crepe_predict(self._h, _p(x), C.c_int64(x.shape[0]), int(hop), C.c_float(fmin), C.c_float(fmax),
+                                          _p(d), C.c_uint64(seed), _p(pitch), _p(probs), _p(bins, C.c_int32)), "crepe_predict")
+        if return_parts:
+            return pitch, np.ascontiguousarray(probs.T), bins
+        return pitch
+
+    def crepe_decode(self, probs, batch, fmin, fmax, dither):
+        """core.postprocess + Viterbi + bins_to_frequency on sigmoid outputs (F, 360): (pitch (F,), bins (F,))."""
+        pr = np.ascontiguousarray(f32(probs).T)
+        F = pr.shape[1]
+        d = f32(dither)
+        pitch, bins = np.empty(F, np.float32), np.empty(F, np.int32)
+        self._ck(lib().rvcx_op_crepe_decode(self._h, _p(pr), C.c_int64(F), int(batch), C.c_float(fmin), C.c_float(fmax),
+                                            _p(d), _p(pitch), _p(bins, C.c_int32)), "crepe_decode")
+        return pitch, bins
+
+    def get_f0_crepe_x(self, x, p_len, params: "Params", inp_f0=None, dither=None):
+        """VC.get_f0(..., "mangio-crepe", hop_length=params.hop_length) on the padded signal: (coarse, f0) of p_len frames."""
+        x = f32(x)
+        coarse, f0 = np.empty(int(p_len), np.int32), np.empty(int(p_len), np.float32)
+        tab = None if inp_f0 is None else np.ascontiguousarray(inp_f0, dtype=np.float32).reshape(-1, 2)
+        d = None if dither is None else f32(dither)
+        self._ck(lib().rvcx_get_f0_crepe_x(self._h, _p(x), C.c_int64(x.shape[0]), C.c_int64(int(p_len)), C.byref(params),
+                                           _p(tab), 0 if tab is None else tab.shape[0], _p(d),
+                                           C.c_int64(0 if d is None else d.shape[0]), _p(coarse, C.c_int32), _p(f0)),
+                 "get_f0_crepe_x")
+        return coarse, f0
+
     def fcpe_f0(self, audio, threshold=0.05, return_salience=False, return_mel=False):
         """FCPEInfer.__call__: audio (n,) or (B,n) at 16 kHz -> Hz (B, n//160 + 1) [, salience (B,F,360)] [, mel (B,128,F)]."""
         audio = f32(audio)
@@ -496,7 +547,7 @@ class Context:
     def noise_capacity(self, model_id, n, params) -> int:
         return int(lib().rvcx_noise_len(self._h, model_id, C.c_int64(n), C.byref(params)))
 
-    def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False, inp_f0=None):
+    def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False, inp_f0=None, crepe_dither=None):
         """VC.pipeline for a list of 16 kHz mono clips -> list of int16 arrays (and the pre-quantisation
         float waveforms when want_f32).  float64 clips (what the reference's load_audio returns) cross the
         ABI as float64; anything else as float32.  Equal-length clips are converted as micro-batches."""
@@ -529,9 +580,14 @@ class Context:
                 nz.append(buf)
             npp = (C.POINTER(C.c_float) * B)(*[_p(b) for b in nz])
         out_n = (C.c_int64 * B)()
-        if inp_f0 is not None:                 # f0 files: (rows, 2) float32 tables of (time [s], f0 [Hz]) per utterance
-            tabs = [None if t is None else np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2) for t in inp_f0]
-            ex = (UttExtra * B)(*[UttExtra(None, 0, 0) if t is None else UttExtra(_p(t), t.shape[0], 0) for t in tabs])
+        if inp_f0 is not None or crepe_dither is not None:
+            # f0 files: (rows, 2) float32 tables of (time [s], f0 [Hz]) per utterance; crepe dither: one float per frame
+            tabs = [None if (inp_f0 is None or t is None) else np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2)
+                    for t in (inp_f0 if inp_f0 is not None else [None] * B)]
+            dith = [None if (crepe_dither is None or d is None) else f32(d).ravel()
+                    for d in (crepe_dither if crepe_dither is not None else [None] * B)]
+            ex = (UttExtra * B)(*[UttExtra(_p(t), 0 if t is None else t.shape[0], 0, _p(d), 0 if d is None else d.shape[0])
+                                  for t, d in zip(tabs, dith)])
             wv = (C.c_void_p * B)(*[w.ctypes.data for w in wavs])
             self._ck(lib().rvcx_convert_batch_ex(self._h, model_id, B, wv, 1 if is64 else 0, ns, C.byref(params), npp, ex,
                                                  op, fp, out_n), "convert_batch_ex")

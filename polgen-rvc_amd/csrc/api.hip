@@ -665,6 +665,7 @@ static std::vector<WeightRegion*> all_regions(Ctx& c, uint64_t* hash) {
   add(c.hubert ? c.hubert->region.get() : nullptr, 1);
   add(c.rmvpe ? c.rmvpe->region.get() : nullptr, 2);
   add(c.fcpe ? c.fcpe->region.get() : nullptr, 4);
+  add(c.crepe ? c.crepe->region.get() : nullptr, 5);
   for (size_t i = 0; i < c.synths.size(); ++i) add(c.synths[i] ? c.synths[i]->region.get() : nullptr, 16 + i);
   add(c.index ? c.index->region.get() : nullptr, 3);
   if (hash) *hash = h;
@@ -926,6 +927,98 @@ int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor*
   API_END
 }
 
+int rvcx_load_crepe(rvcx_ctx* ctx, const rvcx_tensor* tbl, int n) {
+  API_BEGIN_ONCE(ctx)
+  TensorTable t = make_table(tbl, n);
+  C->crepe = crepe_load(*C, t);
+  API_END
+}
+
+int64_t rvcx_crepe_frames(int64_t n, int hop) { return hop > 0 ? 1 + n / hop : -1; }
+
+int rvcx_crepe_predict(rvcx_ctx* ctx, const float* x, int64_t n, int hop, float fmin, float fmax, const float* dither,
+                       uint64_t seed, float* pitch, float* probs, int32_t* bins) {
+  API_BEGIN(ctx)
+  if (!C->crepe) fail("crepe not loaded");
+  if (!x || !pitch || n <= 0 || hop <= 0) fail("crepe_predict: bad argument");
+  const long F = crepe_frames(n, hop);
+  C->arena.reserve(crepe_arena_bytes(*C->crepe, n, hop) + (size_t)n * 8 + (size_t)F * (360 + 16) * 4 + (64 << 20));
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  float* dx = any_to_dev(*C, x, (size_t)n);
+  std::vector<float> h((size_t)n);
+  RVCX_HIP(hipMemcpyAsync(h.data(), dx, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  const float scale = (float)crepe_quantile999(h);
+  if (!(scale > 0.f)) fail("crepe: the signal is silent (its 99.9 % quantile is 0)");
+  float* dd = C->arena.alloc<float>((size_t)F);
+  if (dither) RVCX_HIP(hipMemcpyAsync(dd, dither, (size_t)F * 4, hipMemcpyDefault, s));
+  else launch_crepe_dither(dd, F, seed + 0x63726570ull, 0, s);
+  float* dp = C->arena.alloc<float>((size_t)F);
+  float* dpr = probs ? C->arena.alloc<float>((size_t)F * 360) : nullptr;
+  int* db = bins ? C->arena.alloc<int>((size_t)F) : nullptr;
+  crepe_forward(*C, *C->crepe, dx, n, scale, hop, fmin, fmax, dd, dp, dpr, db, s);
+  RVCX_HIP(hipMemcpyAsync(pitch, dp, (size_t)F * 4, hipMemcpyDefault, s));
+  if (probs) RVCX_HIP(hipMemcpyAsync(probs, dpr, (size_t)F * 360 * 4, hipMemcpyDefault, s));
+  if (bins) RVCX_HIP(hipMemcpyAsync(bins, db, (size_t)F * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  C->check_dev_err();
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_op_crepe_decode(rvcx_ctx* ctx, const float* probs, int64_t F, int batch, float fmin, float fmax, const float* dither,
+                         float* pitch, int32_t* bins) {
+  API_BEGIN(ctx)
+  if (!C->crepe) fail("crepe not loaded");
+  if (!probs || !dither || !pitch || F <= 0 || batch <= 0) fail("crepe_decode: bad argument");
+  C->arena.reserve((size_t)F * (2 * 360 * 4 + 360 * 2 + 64) + (64 << 20));
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  float* dpr = any_to_dev(*C, probs, (size_t)F * 360);
+  float* dd = any_to_dev(*C, dither, (size_t)F);
+  float* dp = C->arena.alloc<float>((size_t)F);
+  int* db = C->arena.alloc<int>((size_t)F);
+  crepe_decode(*C, *C->crepe, dpr, (long)F, batch, fmin, fmax, dd, dp, db, s);
+  RVCX_HIP(hipMemcpyAsync(pitch, dp, (size_t)F * 4, hipMemcpyDefault, s));
+  if (bins) RVCX_HIP(hipMemcpyAsync(bins, db, (size_t)F * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  C->arena.reset();
+  API_END
+}
+
+int rvcx_get_f0_crepe_x(rvcx_ctx* ctx, const float* x, int64_t n, int64_t p_len, const rvcx_params* p, const float* inp_f0,
+                        int inp_f0_rows, const float* dither, int64_t dither_n, int32_t* coarse, float* f0) {
+  API_BEGIN(ctx)
+  if (!p || !x || !coarse || !f0 || n <= 0 || p_len <= 0) fail("get_f0_crepe: bad argument");
+  if (!C->crepe) fail("crepe not loaded");
+  const std::vector<double> track = f0_file_track(inp_f0, inp_f0 ? inp_f0_rows : 0);
+  C->arena.reserve(crepe_arena_bytes(*C->crepe, n, crepe_hop(*p)) + (size_t)n * 8 + (size_t)p_len * 48 + track.size() * 8 +
+                   (64 << 20));
+  C->arena.reset();
+  hipStream_t s = C->stream;
+  float* dx = any_to_dev(*C, x, (size_t)n);
+  float* fraw = C->arena.alloc<float>((size_t)p_len);
+  int* dc = C->arena.alloc<int>((size_t)p_len);
+  float* df = C->arena.alloc<float>((size_t)p_len);
+  F0Extra ex;
+  ex.dither = dither;
+  ex.dither_n = dither ? dither_n : 0;
+  crepe_f0_device(*C, dx, n, *p, p_len, &ex, fraw, s);
+  launch_f0_coarse(fraw, df, dc, (int)p_len, p->pitch, p->f0_min, p->f0_max, s);
+  if (!track.empty()) {
+    double* rep = C->arena.alloc<double>(track.size());
+    RVCX_HIP(hipMemcpyAsync(rep, track.data(), track.size() * 8, hipMemcpyHostToDevice, s));
+    launch_f0_override(rep, (int)track.size(), 100 * p->x_pad, df, dc, (int)p_len, p->f0_min, p->f0_max, s);
+  }
+  RVCX_HIP(hipMemcpyAsync(coarse, dc, (size_t)p_len * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipMemcpyAsync(f0, df, (size_t)p_len * 4, hipMemcpyDefault, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  C->check_dev_err();
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_load_fcpe(rvcx_ctx* ctx, const rvcx_fcpe_cfg* cfg, const rvcx_tensor* tbl, int n) {
   API_BEGIN_ONCE(ctx)
   TensorTable t = make_table(tbl, n);
@@ -1175,6 +1268,8 @@ static int convert_impl(rvcx_ctx* ctx, int model_id, int B, const float* const* 
     if (extra) {
       u.inp_f0 = extra[i].inp_f0;
       u.inp_f0_rows = extra[i].inp_f0 ? extra[i].inp_f0_rows : 0;
+      u.crepe_dither = extra[i].crepe_dither;
+      u.crepe_dither_n = extra[i].crepe_dither ? extra[i].crepe_dither_n : 0;
     }
     if (!(u.wav || u.wav64) || !u.out) fail("convert_batch: null buffer for utterance " + std::to_string(i));
   }
@@ -1271,6 +1366,7 @@ int rvcx_get_f0_x_ex(rvcx_ctx* ctx, const float* x, int64_t n, int64_t p_len, co
   API_BEGIN(ctx)
   if (!p || !x) fail("get_f0: null argument");
   check_f0_backend(*C, *p);
+  if (p->f0_method == RVCX_F0_CREPE) fail("get_f0: mangio-crepe takes its dither through rvcx_get_f0_crepe_x");
   const bool fcpe = p->f0_method == RVCX_F0_FCPE;
   const long F = fcpe ? (long)p_len : 1 + n / 160;        // rmvpe+: un-truncated; fcpe: compute_f0 resizes to p_len
   if (F <= 0) fail("get_f0: p_len must be positive");

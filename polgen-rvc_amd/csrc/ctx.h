@@ -12,6 +12,7 @@ namespace rvcx {
 struct SynthModel;
 struct RmvpeModel;
 struct FcpeModel;
+struct CrepeModel;
 struct HubertModel;
 struct IndexData;
 
@@ -201,6 +202,7 @@ struct Ctx {
   std::unique_ptr<HubertModel> hubert;
   std::unique_ptr<RmvpeModel> rmvpe;
   std::unique_ptr<FcpeModel> fcpe;
+  std::unique_ptr<CrepeModel> crepe;
   std::vector<std::unique_ptr<SynthModel>> synths;
   std::unique_ptr<IndexData> index;
   Ctx();

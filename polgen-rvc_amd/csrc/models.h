@@ -119,6 +119,29 @@ struct FcpeModel {
   const float* cent_table = nullptr;
 };
 ConvW make_stft_conv(Ctx& c);      // rmvpe.hip
+
+// ------------------------------------------------------------------------------ CREPE (crepe.hip; torchcrepe's model.Crepe)
+struct CrepeModel {
+  std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();
+  int filters[6] = {0, 0, 0, 0, 0, 0};
+  int in_features = 0;               // 4 * filters[5]
+  ConvW conv[6];                     // conv[0]: the stride-4 / 512-tap layer as a dense 128-tap conv over 4 phase channels
+  const float* bn_scale[6] = {};     // eval BatchNorm as x * scale + shift (applied after the ReLU)
+  const float* bn_shift[6] = {};
+  ConvW classifier;                  // Linear(in_features, 360) + sigmoid
+  const double* band = nullptr;      // log of the Viterbi transition band, (360, 23)
+  double log_far = 0.0, log_init = 0.0;
+};
+std::unique_ptr<CrepeModel> crepe_load(Ctx& c, const TensorTable& t);
+int crepe_frames(int64_t n, int hop);
+double crepe_quantile999(std::vector<float>& abs_scratch);     // host: np.quantile(|x|, 0.999); clobbers its argument
+size_t crepe_arena_bytes(const CrepeModel& m, int64_t n, int hop);
+void crepe_decode(Ctx& c, const CrepeModel& m, const float* probs, long F, int batch, float fmin, float fmax,
+                  const float* dither, float* pitch, int* bins_out, hipStream_t s);
+void crepe_forward(Ctx& c, const CrepeModel& m, const float* x, int64_t n, float scale, int hop, float fmin, float fmax,
+                   const float* dither, float* pitch, float* probs_out, int* bins_out, hipStream_t s);
+void launch_crepe_dither(float* out, long n, uint64_t seed, uint64_t offset, hipStream_t s);
+void launch_crepe_resize(const float* pitch, long L, long p_len, float* f0, hipStream_t s);
 std::unique_ptr<FcpeModel> fcpe_load(Ctx& c, const rvcx_fcpe_cfg& cfg, const TensorTable& t);
 size_t fcpe_arena_bytes(const FcpeModel& m, int B, int64_t n);
 // FCPEInfer.__call__ (FCPE.py:739-745): audio device (B,n) f32 -> f0 device (B, n/160 + 1) Hz, 0 = below `threshold`.

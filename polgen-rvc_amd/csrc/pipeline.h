@@ -35,6 +35,14 @@ struct UttIO {
   int seed_offset = 0;             // Philox stream of this utterance = params.seed + seed_offset
   const float* inp_f0 = nullptr;   // f0 file table, rows of (time [s], f0 [Hz]) float32 in HOST memory (pipeline.py:349-360)
   int inp_f0_rows = 0;
+  const float* crepe_dither = nullptr;   // "mangio-crepe": per-frame dither in HOST memory or null (rvcx_utt_extra)
+  long crepe_dither_n = 0;
+};
+// per batch item of get_f0_device: the crepe dither (host) and the item's Philox stream offset
+struct F0Extra {
+  const float* dither = nullptr;
+  long dither_n = 0;
+  int seed_offset = 0;
 };
 // VC.pipeline for a list of utterances: equal-length utterances run as micro-batches (B > 1 through every network).
 void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& utts, const rvcx_params& p, float* stage_ms /*9 or null*/);
@@ -43,8 +51,12 @@ int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p);   /
 // F0 back-end selected by params.f0_method: throws unless its model is resident; workspace for B signals of n_pad samples
 void check_f0_backend(const Ctx& c, const rvcx_params& p);
 size_t f0_arena_bytes(const Ctx& c, const rvcx_params& p, int B, long n_pad);
+int crepe_hop(const rvcx_params& p);
+void crepe_f0_device(Ctx& c, const float* x, long n, const rvcx_params& p, long p_len, const F0Extra* ex, float* f0raw,
+                     hipStream_t s);   // VC.get_f0_crepe for one padded signal on the device          // "mangio-crepe" frame step: params.hop_length, 128 when unset
 // VC.get_f0 on device for B equal-length reflect-padded signals: coarse/f0 rows of out_stride elements
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s, int B = 1, long out_stride = 0, const std::function<void()>* mid = nullptr);
+                   hipStream_t s, int B = 1, long out_stride = 0, const std::function<void()>* mid = nullptr,
+                   const F0Extra* extra = nullptr);
 
 }  // namespace rvcx

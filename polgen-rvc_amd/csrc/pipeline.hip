@@ -418,6 +418,8 @@ void check_f0_backend(const Ctx& c, const rvcx_params& p) {
     RVCX_CHECK(c.rmvpe != nullptr, "get_f0: rmvpe not loaded");
   } else if (p.f0_method == RVCX_F0_FCPE) {
     RVCX_CHECK(c.fcpe != nullptr, "get_f0: fcpe not loaded");
+  } else if (p.f0_method == RVCX_F0_CREPE) {
+    RVCX_CHECK(c.crepe != nullptr, "get_f0: crepe not loaded");
   } else {
     fail("get_f0: unknown f0_method " + std::to_string(p.f0_method));
   }
@@ -426,15 +428,55 @@ void check_f0_backend(const Ctx& c, const rvcx_params& p) {
 size_t f0_arena_bytes(const Ctx& c, const rvcx_params& p, int B, long n_pad) {
   check_f0_backend(c, p);
   if (p.f0_method == RVCX_F0_FCPE) return fcpe_arena_bytes(*c.fcpe, B, n_pad) + (size_t)B * (n_pad / 160 + 8) * 16;
+  if (p.f0_method == RVCX_F0_CREPE)   // one item at a time
+    return crepe_arena_bytes(*c.crepe, n_pad, crepe_hop(p)) + (size_t)B * (n_pad / 160 + 8) * 16;
   return rmvpe_arena_bytes(*c.rmvpe, B, n_pad);
 }
 
+int crepe_hop(const rvcx_params& p) { return p.hop_length > 0 ? p.hop_length : 128; }
+
+// VC.get_f0_crepe (pipeline.py:86-117) for one padded signal on the device: f0raw receives p_len frames
+void crepe_f0_device(Ctx& c, const float* x, long n, const rvcx_params& p, long p_len, const F0Extra* ex, float* f0raw,
+                     hipStream_t s) {
+  const CrepeModel& m = *c.crepe;
+  const int hop = crepe_hop(p);
+  const long F = crepe_frames(n, hop);
+  // x /= np.quantile(np.abs(x), 0.999): an order statistic of the whole signal -- read back and selected on the host
+  // (this optional back-end is not on the headline path; the frames are renormalised to unit variance right after)
+  std::vector<float> h((size_t)n);
+  RVCX_HIP(hipMemcpyAsync(h.data(), x, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+  RVCX_HIP(hipStreamSynchronize(s));
+  const float scale = (float)crepe_quantile999(h);
+  RVCX_CHECK(scale > 0.f && std::isfinite(scale), "crepe: the signal is silent (its 99.9 % quantile is 0)");
+  float* dith = c.arena.alloc<float>((size_t)F);
+  if (ex && ex->dither) {
+    RVCX_CHECK(ex->dither_n >= F, "crepe: the dither array is shorter than the frame count");
+    RVCX_HIP(hipMemcpyAsync(dith, ex->dither, (size_t)F * sizeof(float), hipMemcpyHostToDevice, s));
+  } else {
+    launch_crepe_dither(dith, F, p.seed + 0x63726570ull, (uint64_t)(ex ? ex->seed_offset : 0) << 32, s);
+  }
+  float* pitch = c.arena.alloc<float>((size_t)F);
+  crepe_forward(c, m, x, n, scale, hop, p.f0_min, p.f0_max, dith, pitch, nullptr, nullptr, s);
+  launch_crepe_resize(pitch, F, p_len, f0raw, s);
+}
+
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s, int B, long out_stride, const std::function<void()>* mid) {
+                   hipStream_t s, int B, long out_stride, const std::function<void()>* mid, const F0Extra* extra) {
   // VC.get_f0 (pipeline.py:132-201) on already reflect-padded signals (B, n_pad); coarse / f0 rows of out_stride
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
   check_f0_backend(c, p);
   float* f0raw = c.arena.alloc<float>((size_t)B * F);
+  if (p.f0_method == RVCX_F0_CREPE) {   // pipeline.py:151-152: get_f0_crepe(x, f0_min, f0_max, p_len, hop_length)
+    if (mid) (*mid)();
+    for (int b = 0; b < B; ++b) {
+      const size_t mark = c.arena.mark();
+      crepe_f0_device(c, apad + (size_t)b * n_pad, n_pad, p, p_len, extra ? extra + b : nullptr, f0raw + (size_t)b * F, s);
+      c.arena.reset(mark);
+      launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)p_len,
+                       p.pitch, p.f0_min, p.f0_max, s);
+    }
+    return p_len;
+  }
   if (p.f0_method == RVCX_F0_FCPE) {   // pipeline.py:169-181: threshold 0.03, compute_f0(x, p_len)
     fcpe_forward(c, *c.fcpe, B, apad, n_pad, 0.03f, f0raw, nullptr, nullptr, s, mid);
     fcpe_post_coarse(c, f0raw, B, (int)F, (int)p_len, f0, coarse, out_stride, p.pitch, p.f0_min, p.f0_max, s);
@@ -671,7 +713,14 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     c.arena_f0.reset();
     c.arena.swap(c.arena_f0);
     try {
-      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8, mid);
+      std::vector<F0Extra> fx(mb.count);
+      for (int b = 0; b < mb.count; ++b) {
+        const UttIO& io = ios[order[mb.first + b]];
+        fx[b].dither = io.crepe_dither;
+        fx[b].dither_n = io.crepe_dither_n;
+        fx[b].seed_offset = io.seed_offset;
+      }
+      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8, mid, fx.data());
     } catch (...) {
       c.arena.swap(c.arena_f0);
       throw;

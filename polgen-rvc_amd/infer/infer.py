@@ -4,6 +4,7 @@ rvc/scripts/edge_tts_conversion.py:79-104), backed by librvcx.so.
 """
 from __future__ import annotations
 
+import os
 import wave
 from multiprocessing import cpu_count
 
@@ -100,6 +101,27 @@ def load_rmvpe(device, model_path=None, state=None, cfg=None):
         state = _torch_load(model_path)
     ctx.load_rmvpe(weights.rmvpe_cfg_struct(cfg or weights.rmvpe_cfg_from_state(state)), state)
     ctx.rmvpe_loaded = True
+    _RESIDENT.pop(slot, None)
+    if key is not None:
+        _RESIDENT[slot] = (key, True)
+
+
+def load_crepe(device, model_path=None, state=None):
+    """torchcrepe.load.model (called inside torchcrepe.predict, rvc/infer/pipeline.py:96): the state dict of
+    torchcrepe's model.Crepe -- its packaged ``assets/full.pth`` (or ``tiny.pth``), copied to ``model_path``, or given
+    as ``state``.  The capacity is read off the tensor shapes.  Stays resident like the other predictors."""
+    ctx = _context(device)
+    slot, key = (_dev_index(device), "crepe"), None
+    if state is None:
+        if not model_path or not os.path.exists(model_path):
+            raise FileNotFoundError(f"mangio-crepe needs torchcrepe's weights (assets/full.pth) at {model_path!r} "
+                                    "or through infer.load_crepe(device, state=...)")
+        key = _file_key(model_path)
+        if slot in _RESIDENT and _RESIDENT[slot][0] == key and getattr(ctx, "crepe_loaded", False):
+            return
+        state = _torch_load(model_path)
+    ctx.load_crepe(state)
+    ctx.crepe_loaded = True
     _RESIDENT.pop(slot, None)
     if key is not None:
         _RESIDENT[slot] = (key, True)

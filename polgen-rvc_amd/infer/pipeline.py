@@ -4,9 +4,13 @@ the int16 output array runs on the GPU through the C ABI; there is no CPU fallba
 
 Differences that are deliberate and documented:
   * ``f0_file``: read like the reference (an object with ``.name``; rows "time,f0"), applied on the device.
-  * ``f0_method``: "rmvpe+" (with its BASELINE alias "rmvpe") and "fcpe" are implemented; "mangio-crepe" raises
-    ValueError, as does anything else (the reference hits an accidental UnboundLocalError, pipeline.py:152-183).
-  * ``filter_radius`` / ``hop_length`` are accepted and unused, as in the reference for rmvpe+ and fcpe.
+  * ``f0_method``: "rmvpe+" (with its BASELINE alias "rmvpe"), "fcpe" and "mangio-crepe" are implemented; anything
+    else raises ValueError (the reference hits an accidental UnboundLocalError, pipeline.py:152-183).
+    "mangio-crepe" is torchcrepe's network and Viterbi decoder restated (csrc/crepe.hip; torchcrepe is not vendored
+    with the reference: parity unpinned).  Its weights are torchcrepe's ``assets/full.pth`` state dict, looked up at
+    ``CREPE_DIR`` or handed to ``infer.load_crepe``; the +-20 cent dither torchcrepe draws from scipy's global RNG is
+    drawn the same way here (``_crepe_dither``) and crosses the ABI as an array.
+  * ``filter_radius`` is accepted and unused, as in the reference; ``hop_length`` is used by "mangio-crepe" only.
   * ``model`` / ``net_g`` are opaque handles (``HubertHandle`` / ``SynthHandle`` from .infer); ``index`` is
     the handle ``_load_index`` returns (the vectors live in HBM), ``big_npy`` the matrix or ``True``.
   * keyword-only extras after the reference's parameters (``noise`` / ``z_noise`` / ``src_noise`` replace the
@@ -26,8 +30,21 @@ from ._state import _INDEX_RESIDENT
 # rvc/infer/pipeline.py:14-16 -- resolved against the working directory at import, like the reference
 RMVPE_DIR = os.path.join(os.getcwd(), "rvc", "models", "predictors", "rmvpe.pt")
 FCPE_DIR = os.path.join(os.getcwd(), "rvc", "models", "predictors", "fcpe.pt")
+# torchcrepe reads <site-packages>/torchcrepe/assets/full.pth; a deployment copies that file here (or calls infer.load_crepe)
+CREPE_DIR = os.path.join(os.getcwd(), "rvc", "models", "predictors", "crepe_full.pth")
 
-F0_METHODS = ("rmvpe+", "rmvpe", "fcpe")
+F0_METHODS = ("rmvpe+", "rmvpe", "fcpe", "mangio-crepe")
+_F0_CODE = {"rmvpe+": _lib.F0_RMVPE, "rmvpe": _lib.F0_RMVPE, "fcpe": _lib.F0_FCPE, "mangio-crepe": _lib.F0_CREPE}
+
+
+def _crepe_dither(n: int) -> np.ndarray:
+    """torchcrepe.convert.dither: scipy.stats.triang.rvs(c=0.5, loc=-20, scale=40, size=n) on numpy's GLOBAL generator
+    (a caller who seeds numpy gets the reference's draws); numpy's own triangular law when scipy is absent."""
+    try:
+        import scipy.stats
+        return scipy.stats.triang.rvs(c=0.5, loc=-20, scale=40, size=int(n)).astype(np.float32)
+    except ImportError:
+        return np.random.triangular(-20.0, 0.0, 20.0, size=int(n)).astype(np.float32)
 
 
 def _np(a, dtype=None):
@@ -70,14 +87,16 @@ class VC:
     def _ctx(self):
         return _state.context(self.device)
 
-    def _params(self, pitch, index_rate, volume_envelope, protect, f0_min, f0_max, sid=0, f0_method="rmvpe+"):
+    def _params(self, pitch, index_rate, volume_envelope, protect, f0_min, f0_max, sid=0, f0_method="rmvpe+",
+                hop_length=128):
         p = _lib.Params()
         p.pitch, p.f0_min, p.f0_max = float(pitch), float(f0_min), float(f0_max)
         p.index_rate, p.protect, p.volume_envelope = float(index_rate), float(protect), float(volume_envelope)
         p.sid = int(sid)
         p.x_pad, p.x_query, p.x_center, p.x_max = self.x_pad, self.x_query, self.x_center, self.x_max
         p.seed = _state.next_seed() if self.seed is None else int(self.seed)
-        p.f0_method = _lib.F0_FCPE if f0_method == "fcpe" else _lib.F0_RMVPE
+        p.f0_method = _F0_CODE.get(f0_method, _lib.F0_RMVPE)
+        p.hop_length = int(hop_length) if hop_length else 128
         return p
 
     @staticmethod
@@ -102,13 +121,31 @@ class VC:
             infer.load_fcpe(self.device, FCPE_DIR)
         return ctx
 
+    def _ensure_crepe(self, ctx=None):
+        """torchcrepe.predict loads its packaged weights on first use (torchcrepe.load.model); here from CREPE_DIR."""
+        ctx = ctx or self._ctx()
+        if not getattr(ctx, "crepe_loaded", False):
+            from . import infer
+            infer.load_crepe(self.device, CREPE_DIR)
+        return ctx
+
     def _ensure_f0_model(self, f0_method, ctx=None):
+        if f0_method == "mangio-crepe":
+            return self._ensure_crepe(ctx)
         return self._ensure_fcpe(ctx) if f0_method == "fcpe" else self._ensure_rmvpe(ctx)
 
     # ------------------------------------------------------------------------------------
-    def get_f0_crepe(self, x, f0_min, f0_max, p_len, hop_length, model="full"):
-        """pipeline.py:86-117 (torchcrepe): not on the north-star path."""
-        raise ValueError("f0_method='mangio-crepe' is not implemented by rvcx (SURVEY.md §8 f4)")
+    def get_f0_crepe(self, x, f0_min, f0_max, p_len, hop_length, model="full", *, dither=None):
+        """pipeline.py:86-117: quantile normalisation, torchcrepe.predict (Viterbi decoder, batches of 2 * hop_length
+        frames), resize to p_len -> f0 in Hz (float64, unshifted).  ``model`` names torchcrepe's capacity; the weights that
+        are resident decide it here."""
+        ctx = self._ensure_crepe()
+        x = _np(x, np.float32)
+        p_len = p_len or x.shape[0] // int(hop_length)
+        p = self._params(0, 0, 1, 0.5, f0_min, f0_max, f0_method="mangio-crepe", hop_length=hop_length)
+        if dither is None:
+            dither = _crepe_dither(ctx.crepe_frames(x.shape[0], p.hop_length))
+        return ctx.get_f0_crepe_x(x, p_len, p, None, dither)[1].astype(np.float64)
 
     def get_f0_rmvpe(self, x, f0_min=1, f0_max=40000, *args, **kwargs):
         """pipeline.py:119-130 -> f0 in Hz, 1 + len(x)//160 frames; out-of-range frames are 0 (rmvpe+)."""
@@ -117,7 +154,7 @@ class VC:
         return f0.astype(np.float64)
 
     def get_f0(self, input_audio_path, x, p_len, pitch, f0_method, filter_radius, hop_length, inp_f0=None,
-               f0_min=50, f0_max=1100):
+               f0_min=50, f0_max=1100, *, crepe_dither=None):
         """pipeline.py:132-201.  ``x`` is the reflect-padded, high-passed signal, as in the reference; returns
         (f0_coarse int array, f0 float array): 1 + len(x)//160 frames for rmvpe+ (the caller truncates to p_len),
         p_len frames for fcpe (FCPEF0Predictor.compute_f0 resizes to p_len itself, FCPE.py:869-877)."""
@@ -126,8 +163,14 @@ class VC:
         x = _np(x, np.float32)
         # the whole of get_f0 -- F0 model, pitch shift, the optional f0-file table (pipeline.py:185-191), coarse
         # quantisation -- runs behind the C ABI (rvcx_get_f0_x_ex); rvc_infer never passes inp_f0 (f0_file=None, infer.py:149)
-        p = self._params(pitch, 0, 1, 0.5, f0_min, f0_max, f0_method=f0_method)
-        coarse, f0 = ctx.get_f0_x_ex(x, p_len, p, None if inp_f0 is None else _np(inp_f0, np.float32))
+        p = self._params(pitch, 0, 1, 0.5, f0_min, f0_max, f0_method=f0_method, hop_length=hop_length)
+        tab = None if inp_f0 is None else _np(inp_f0, np.float32)
+        if f0_method == "mangio-crepe":                   # pipeline.py:151-152; p_len frames, like fcpe
+            if crepe_dither is None:
+                crepe_dither = _crepe_dither(ctx.crepe_frames(x.shape[0], p.hop_length))
+            coarse, f0 = ctx.get_f0_crepe_x(x, p_len, p, tab, crepe_dither)
+        else:
+            coarse, f0 = ctx.get_f0_x_ex(x, p_len, p, tab)
         return coarse.astype(np.int64), f0.astype(np.float64)
 
     def vc(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect, *,
@@ -210,18 +253,19 @@ class VC:
 
     def pipeline(self, model, net_g, sid, audio, input_audio_path, pitch, f0_method, file_index, index_rate,
                  pitch_guidance, filter_radius, tgt_sr, resample_sr, volume_envelope, version, protect,
-                 hop_length, f0_file, f0_min=50, f0_max=1100, *, noise=None, return_f32=False):
+                 hop_length, f0_file, f0_min=50, f0_max=1100, *, noise=None, return_f32=False, crepe_dither=None):
         """pipeline.py:289-467 -> np.ndarray[int16]."""
         if noise is None:
             noise = getattr(self, "parity_noise", None)      # test hook for callers that cannot pass `noise`
         return self.pipeline_batch(model, net_g, sid, [audio], pitch, f0_method, file_index, index_rate,
                                    pitch_guidance, tgt_sr, resample_sr, volume_envelope, version, protect, f0_file,
                                    f0_min, f0_max, noise=None if noise is None else [noise],
-                                   return_f32=return_f32, _single=True)
+                                   return_f32=return_f32, _single=True, hop_length=hop_length,
+                                   crepe_dither=None if crepe_dither is None else [crepe_dither])
 
     def pipeline_batch(self, model, net_g, sid, audios, pitch, f0_method, file_index, index_rate, pitch_guidance,
                        tgt_sr, resample_sr, volume_envelope, version, protect, f0_file=None, f0_min=50, f0_max=1100,
-                       *, noise=None, return_f32=False, _single=False):
+                       *, noise=None, return_f32=False, _single=False, hop_length=128, crepe_dither=None):
         """VC.pipeline over a list of utterances in one call (the reference lists batch conversion as not
         done, TODO.md:11): equal-length clips run through the networks together."""
         self._check_method(f0_method)
@@ -243,7 +287,8 @@ class VC:
         self._ensure_f0_model(f0_method, ctx)
         index, _ = self._load_index(ctx, file_index, index_rate)
         p = self._params(pitch, index_rate if index is not None else 0.0, volume_envelope, protect, f0_min, f0_max,
-                         int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid, f0_method=f0_method)
+                         int(_np(sid).ravel()[0]) if not isinstance(sid, int) else sid, f0_method=f0_method,
+                         hop_length=hop_length)
         # pipeline.py:453-454: librosa.resample(audio_opt, orig_sr=tgt_sr, target_sr=resample_sr) ahead of the peak
         # normalisation -- on the device (csrc/audio.hip); rvc_infer passes 0 (infer.py:144)
         p.resample_sr = int(resample_sr) if (resample_sr >= self.sample_rate and tgt_sr != resample_sr) else 0
@@ -251,8 +296,11 @@ class VC:
         clips = [a if _np(a).dtype == np.float64 else _np(a, np.float32) for a in map(_np, audios)]
         if not all(c.dtype == clips[0].dtype for c in clips):
             clips = [c.astype(np.float64) for c in clips]
+        if f0_method == "mangio-crepe" and crepe_dither is None:     # one value per frame of each PADDED clip, drawn in order
+            crepe_dither = [_crepe_dither(ctx.crepe_frames(c.shape[0] + 2 * self.t_pad, p.hop_length)) for c in clips]
         res = ctx.convert_batch(net_g.model_id, clips, p, noise, want_f32=return_f32,
-                                inp_f0=None if inp_f0 is None else [inp_f0] * len(clips))
+                                inp_f0=None if inp_f0 is None else [inp_f0] * len(clips),
+                                crepe_dither=crepe_dither if f0_method == "mangio-crepe" else None)
         if _single:
             return (res[0][0], res[1][0]) if return_f32 else res[0]
         return res

@@ -333,6 +333,31 @@ def fcpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
 
 FCPE_BIAS = 14.2
 
+# torchcrepe's two capacities (model.Crepe.__init__): filters per layer; kernels 512 then 5 x 64, strides 4 then 1
+CREPE_FILTERS = {"full": [1024, 128, 128, 128, 256, 512], "tiny": [128, 16, 16, 16, 32, 64]}
+
+
+def crepe_state(capacity: str = "full", seed: int = 0) -> Dict[str, np.ndarray]:
+    """A state dict with torchcrepe's keys and shapes (conv{i}.weight (Cout, Cin, K, 1), conv{i}_BN.*, classifier.*).
+    The classifier rows are smooth across the 360 pitch bins (as a trained salience head is), so the per-frame maxima
+    move along the bins instead of jumping: Viterbi paths that mean something."""
+    out = CREPE_FILTERS[capacity]
+    cin = [1] + out[:-1]
+    T = _Table(seed + 71)
+    for i, (ci, co) in enumerate(zip(cin, out), 1):
+        k = 512 if i == 1 else 64
+        T.conv(f"conv{i}", (co, ci, k, 1), gain=1.6, bias_std=0.1)
+        T.normal(f"conv{i}_BN.weight", (co,), 0.15, mean=1.0)
+        T.normal(f"conv{i}_BN.bias", (co,), 0.1)
+        T.normal(f"conv{i}_BN.running_mean", (co,), 0.1, mean=0.35)
+        T.t[f"conv{i}_BN.running_var"] = (0.5 + np.abs(_normal(f"conv{i}_BN.running_var", (co,), 0.2, seed + 71))).astype(np.float32)
+    nin = 4 * out[-1]
+    w = _smooth_axis0(_normal("classifier.w", (360, nin), 1.0, seed + 71), 2.5)
+    T.t["classifier.weight"] = (w * np.float32(3.0 / math.sqrt(nin))).astype(np.float32)
+    T.t["classifier.bias"] = (_smooth_axis0(_normal("classifier.b", (360,), 1.0, seed + 71), 12.0) * np.float32(0.5)
+                              - np.float32(2.0)).astype(np.float32)
+    return T.t
+
 
 def fcpe_checkpoint(cfg: dict = None, seed: int = 0) -> dict:
     """The container FCPEInfer.__init__ reads (FCPE.py:708-736)."""

@@ -68,7 +68,8 @@ def test_mirror_signatures_match_reference():
     assert (sig["f0_min"].default, sig["f0_max"].default) == (1, 40000)
     assert P.RMVPE_DIR == os.path.join(os.getcwd(), "rvc", "models", "predictors", "rmvpe.pt")   # pipeline.py:14-16
     assert P.FCPE_DIR == os.path.join(os.getcwd(), "rvc", "models", "predictors", "fcpe.pt")
-    assert set(P.F0_METHODS) == {"rmvpe+", "rmvpe", "fcpe"}      # pipeline.py:142-181 minus mangio-crepe
+    assert set(P.F0_METHODS) == {"rmvpe+", "rmvpe", "fcpe", "mangio-crepe"}      # pipeline.py:142-181 (+ the "rmvpe" alias)
+    assert inspect.signature(P.VC.get_f0_crepe).parameters["model"].default == "full"
     assert list(inspect.signature(I.get_vc).parameters)[:4] == ["device", "is_half", "config", "model_path"]
     assert list(inspect.signature(I.load_hubert).parameters)[:3] == ["device", "is_half", "model_path"]
     cfg = I.Config()
