@@ -178,6 +178,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
 //                 V's LDS image [dt][k16-step][op][h][d] stores the keys of each element in that same order.
 typedef _Float16 ahalf8 __attribute__((ext_vector_type(8)));
 constexpr float kAttS = 256.f;
+// timing ablations (tools/build_variant.sh ... -DRVCX_ATT_ABL=n; results are garbage, only the clock counts):
+//   1 no MFMAs   2 no global loads   4 no commit (LDS stores + conversion)   8 no exp   16 one barrier per tile
+#ifndef RVCX_ATT_ABL
+#define RVCX_ATT_ABL 0
+#endif
+constexpr int kAttAbl = RVCX_ATT_ABL;
 __device__ __forceinline__ f32x16 att_mfma(ahalf8 a, ahalf8 b, f32x16 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -332,10 +338,12 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
   const int khi = min(len, (int)((long)tiles * (split + 1) / nsplit) * 32);
   if (klo < khi) fetch(klo);
   for (int k0 = klo; k0 < khi; k0 += 32) {
+    if (!(kAttAbl & 16)) __syncthreads();
+    if (!(kAttAbl & 4) || k0 == klo) commit();
     __syncthreads();
-    commit();
-    if (k0 + 32 < khi) fetch(k0 + 32);
-    __syncthreads();
+    // the next tile is requested BEHIND the barrier (__syncthreads() waits vmcnt(0): issued in front of it, the loads'
+    // whole round trip sat on every stage -- round 3) and lands under this tile's 36 MFMAs and the softmax
+    if (k0 + 32 < khi && !(kAttAbl & 2)) fetch(k0 + 32);
     // ---- S^T tile (scaled by S): rows = keys, cols = queries
     f32x16 sacc;
 #pragma unroll
@@ -346,6 +354,10 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
         const ahalf8 a0 = __builtin_bit_cast(ahalf8, Ks[((s * 2 + 0) * 2 + h) * 32 + i]);
         const ahalf8 a2 = __builtin_bit_cast(ahalf8, Ks[((s * 2 + 1) * 2 + h) * 32 + i]);
         const ahalf8 a1 = a0 * (_Float16)invS;
+        if (kAttAbl & 1) {
+          sacc[s] += (float)a0[0] + (float)a2[1] + (float)a1[2];
+          continue;
+        }
         sacc = att_mfma(a0, qh[s], sacc);
         sacc = att_mfma(a1, ql[s], sacc);
         sacc = att_mfma(a2, qh[s], sacc);
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
     ahalf8 ph[2], pl[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = (sacc[r] == -INFINITY) ? 0.f : __expf(sacc[r] - m_new);
+      const float p = (sacc[r] == -INFINITY) ? 0.f : ((kAttAbl & 8) ? sacc[r] - m_new : __expf(sacc[r] - m_new));
       lloc += p;
       const _Float16 vh = (_Float16)p;
       ph[r >> 3][r & 7] = vh;
@@ -392,6 +404,10 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
         const ahalf8 a0 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 2 + 0) * 2 + h) * 32 + i]);
         const ahalf8 a2 = __builtin_bit_cast(ahalf8, Vs[(((dt * 2 + s2) * 2 + 1) * 2 + h) * 32 + i]);
         const ahalf8 a1 = a0 * (_Float16)invS;
+        if (kAttAbl & 1) {
+          acc_o[dt][s2] += (float)a0[0] + (float)a2[1] + (float)a1[2] + (float)ph[s2][0] + (float)pl[s2][1];
+          continue;
+        }
         acc_o[dt] = att_mfma(a0, ph[s2], acc_o[dt]);
         acc_o[dt] = att_mfma(a1, pl[s2], acc_o[dt]);
         acc_o[dt] = att_mfma(a2, ph[s2], acc_o[dt]);
