@@ -296,6 +296,9 @@ int64_t rvcx_fp32_reruns(rvcx_ctx*);
 int64_t rvcx_fp32_layers(rvcx_ctx*);
 /* calls repeated with the single-workgroup BiGRU kernel because the cluster kernel's workgroups were not co-resident */
 int64_t rvcx_gru_fallbacks(rvcx_ctx*);
+/* retrieval: queries whose 8 neighbours could not be certified from the split-fp16 pre-filter and were searched
+ * exhaustively instead (csrc/index.hip) since the last call of this function; waits for the device.  -1: no index */
+int64_t rvcx_index_exhaustive(rvcx_ctx*);
 /* test hook: what = 1 makes the next call behave as if the BiGRU cluster kernel had timed out */
 int rvcx_debug_inject(rvcx_ctx*, int what);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */

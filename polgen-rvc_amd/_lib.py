@@ -74,7 +74,7 @@ _lib = None
 # every symbol include/rvcx.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
-    "rvcx_load_rmvpe", "rvcx_load_crepe", "rvcx_crepe_frames", "rvcx_crepe_predict", "rvcx_op_crepe_decode", "rvcx_get_f0_crepe_x", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
+    "rvcx_load_rmvpe", "rvcx_index_exhaustive", "rvcx_load_crepe", "rvcx_crepe_frames", "rvcx_crepe_predict", "rvcx_op_crepe_decode", "rvcx_get_f0_crepe_x", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
     "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_weights_clone", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
         _lib.rvcx_resample_len.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
         _lib.rvcx_crepe_frames.restype = C.c_int64
+        _lib.rvcx_index_exhaustive.restype = C.c_int64
     return _lib
 
 
@@ -742,6 +743,10 @@ class Context:
     def fp32_layers(self) -> int:
         """layers pinned to the exact-fp32 kernels after an activation left fp16 range (sticky per model)"""
         return int(lib().rvcx_fp32_layers(self._h))
+
+    def index_exhaustive(self) -> int:
+        """queries searched exhaustively (pre-filter not certifiable) since the last call; clears the counter"""
+        return int(lib().rvcx_index_exhaustive(self._h))
 
     def gru_fallbacks(self) -> int:
         return int(lib().rvcx_gru_fallbacks(self._h))

@@ -233,6 +233,15 @@ int64_t rvcx_fp32_layers(rvcx_ctx* ctx) {
 
 int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
 
+int64_t rvcx_index_exhaustive(rvcx_ctx* ctx) {
+  if (!ctx || !ctx->c.index || !ctx->c.index->exhaustive) return -1;
+  int v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  (void)hipMemcpy(&v, ctx->c.index->exhaustive, sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipMemset(ctx->c.index->exhaustive, 0, sizeof(int));
+  return v;
+}
+
 int rvcx_debug_inject(rvcx_ctx* ctx, int what) {
   if (ctx && what == 2) {          // read and clear the raw device error word (debugging builds set extra bits)
     int v = 0;

@@ -184,6 +184,8 @@ struct IndexData {
   ConvW mat;                    // big_npy (N, dim) packed as a 1x1 conv (N out channels)
   const float* rows = nullptr;  // (N, dim) row-major for the gather
   const float* norms = nullptr; // |b|^2 (N)
+  float max_norm = 0.f;         // max |b|^2 (error bound of the pre-filter, index.hip)
+  int* exhaustive = nullptr;    // device counter: queries that needed the exhaustive search (rvcx_index_exhaustive)
   int64_t n = 0;
   int dim = 0;
   // IVF (faiss "IVF{nlist},Flat" searched with nprobe = 1, what RVC's training writes): the coarse centroids and

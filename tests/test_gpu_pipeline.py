@@ -162,6 +162,34 @@ def test_index_blend_ids_exact(ctx):
     ctx.load_index(None)
 
 
+def test_index_with_duplicated_rows_is_searched_exhaustively_and_exactly(ctx):
+    """Round 3: the N x T dot products are a split-fp16 PRE-FILTER; the 16 best rows per query are re-scored exactly and
+    the best 8 certified against the pre-filter's error bound (csrc/index.hip).  An index whose rows come in 24 identical
+    copies defeats the certificate for every query (the 8th and the 16th candidate tie): those queries must take the
+    exhaustive exact search and still return what a stable float64 argsort returns -- the 8 lowest ids of the nearest
+    vector's copies.  A well-separated index must certify everything."""
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import synthetic as S
+    base = S.make_index(256, 128, 5)
+    big = np.ascontiguousarray(np.tile(base, (24, 1)))            # row r = base[r % 256]
+    g = np.random.Generator(np.random.PCG64(4))
+    pick = g.integers(0, 256, 200)
+    q = (base[pick] + 0.05 * g.standard_normal((200, 128))).astype(np.float32)
+    ctx.load_index(big)
+    ctx.index_exhaustive()
+    out, ids, dist = ctx.index_blend(q, 0.5)
+    n_ex = ctx.index_exhaustive()
+    ref, rids, rdist = OP.index_blend(q, big, 0.5)
+    assert n_ex == 200, n_ex
+    assert (ids == rids).all() and (ids % 256 == pick[:, None]).all() and (ids // 256 == np.arange(8)[None, :]).all()
+    assert rms(out - ref) / rms(ref) < 1e-5
+    big2 = S.make_index(4096, 128, 0)
+    ctx.load_index(big2)
+    out, ids, dist = ctx.index_blend(q, 0.5)
+    assert ctx.index_exhaustive() == 0 and (ids == OP.index_blend(q, big2, 0.5)[1]).all()
+    ctx.load_index(None)
+
+
 @pytest.mark.parametrize("tag", ["c1_5s_40k", "c2_30s_48k"])
 def test_full_size_pipeline_vs_reference_golden(ctx, tag):
     """BASELINE configs C1 (5 s, 40 k) and C2 (30 s, 48 k) at full model size against the reference's own
