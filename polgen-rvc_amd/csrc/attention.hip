@@ -213,9 +213,65 @@ __device__ __forceinline__ float att_load(const AttRsrc& b, int off) {   // offs
 }
 constexpr int kAttOob = 0x7ffffff0;
 
+// K and V in the attention kernel's LDS layout, split once per call (round 3).  Before, every workgroup converted the
+// key tiles it walked -- the 25 query blocks of the TextEncoder each re-split all of K and V, and the conversion plus the
+// 32 dword loads per thread and stage made the kernel VALU-issue bound (rocprofv3 --pmc: SQ_ACTIVE_INST_VALU 29 % of the
+// wave cycles with ONE wave per SIMD, 760 VALU instructions per 32-key stage against 36 MFMAs).  Images per
+// (batch, head, 32-key tile):  K [s][op {S kh, S kl}][h][key],  V [dt][s2][op {S vh, S vl}][h][d]  (16 B = 8 halves).
+template <int DT>
+__global__ __launch_bounds__(256) void att_presplit_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                           uint4* __restrict__ kimg, uint4* __restrict__ vimg, int H, int D,
+                                                           int T, int ld, long in_bs, const int* lens, int* ovf_word,
+                                                           int* ovf_layer, int seq) {
+  constexpr int NS = 2 * DT;
+  constexpr int K_ELEMS = NS * 2 * 32, V_ELEMS = DT * 2 * 2 * 32;
+  const int kt = blockIdx.x, hd = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int len = lens ? lens[b] : T;
+  const int k0 = kt * 32;
+  const long base = (long)b * in_bs + (long)hd * D * ld;
+  const float* kb = k + base;
+  const float* vb = v + base;
+  uint4* ko = kimg + (((long)b * H + hd) * gridDim.x + kt) * (2 * K_ELEMS);
+  uint4* vo = vimg + (((long)b * H + hd) * gridDim.x + kt) * (2 * V_ELEMS);
+  bool ovf = false;
+  for (int e0 = tid; e0 < K_ELEMS; e0 += 256) {
+    const int key = e0 & 31, hh = (e0 >> 5) & 1, s = e0 >> 6;
+    ahalf8 a0, a2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = 16 * s + 8 * hh + e;
+      const float val = (d < D && k0 + key < len) ? kb[(long)d * ld + k0 + key] : 0.f;
+      ovf |= !(fabsf(val) < kH3ActLimit / kAttS);
+      const _Float16 vh = (_Float16)val;
+      a0[e] = (_Float16)((float)vh * kAttS);
+      a2[e] = (_Float16)((val - (float)vh) * kAttS);
+    }
+    ko[((s * 2 + 0) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a0);
+    ko[((s * 2 + 1) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a2);
+  }
+  for (int e0 = tid; e0 < V_ELEMS; e0 += 256) {
+    const int dd = e0 & 31, hh = (e0 >> 5) & 1, s2 = (e0 >> 6) & 1, dt = e0 >> 7;
+    const int d = dt * 32 + dd;
+    ahalf8 a0, a2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * s2 + e;
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float val = (d < D && key < len) ? vb[(long)d * ld + key] : 0.f;
+      ovf |= !(fabsf(val) < kH3ActLimit / kAttS);
+      const _Float16 vh = (_Float16)val;
+      a0[e] = (_Float16)((float)vh * kAttS);
+      a2[e] = (_Float16)((val - (float)vh) * kAttS);
+    }
+    vo[(((dt * 2 + s2) * 2 + 0) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a0);
+    vo[(((dt * 2 + s2) * 2 + 1) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a2);
+  }
+  if (ovf) report_h3_overflow(ovf_word, ovf_layer, seq);
+}
+
 template <int DT>  // D <= 32*DT
-__global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, float* __restrict__ out,
+__global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ q, const uint4* __restrict__ kimg,
+                                                      const uint4* __restrict__ vimg, float* __restrict__ out,
                                                       float* __restrict__ m_out, float* __restrict__ l_out,
                                                       const float* __restrict__ relq, int H, int D, int T,
                                                       int ld, long in_bs, long out_bs, float scale, int window,
@@ -233,10 +289,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
   const long base = (long)b * in_bs + (long)hd * D * ld;
   const long obase = (long)b * out_bs + (long)hd * D * ld;
   const float* qb = q + base;
-  const float* kb = k + base;
-  const float* vb = v + base;
 
-  // K and V are held as S-scaled fp16 halves: they must stay below 65504 / S; Q below 65504 (conv.h: kH3ActLimit)
+  // K and V arrive split (att_presplit_kernel checked their range); Q must stay below 65504 (conv.h: kH3ActLimit)
   bool ovf = false;
   // Q fragment: lane (query i, half h), step s, slot e -> Q[16 s + 8 h + e][q0 + i] * scale, split {qh, S ql}
   ahalf8 qh[NS], ql[NS];
@@ -262,75 +316,29 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
   const int nrel = 2 * window + 1;
   const float* relrow = relq ? relq + (((long)b * H + hd) * T + min(qi, T - 1)) * nrel : nullptr;
 
-  // staging: element e0 = tid + 256 j is 8 values (K: 8 head dims of one key; V: 8 permuted keys of one head dim).
-  // Loads are buffer loads (out-of-range offset -> 0: no branches) issued one key tile ahead into registers.
-  constexpr int K_ELEMS = NS * 2 * 32;             // (s, h, key)
-  constexpr int V_ELEMS = DT * 2 * 2 * 32;         // (dt, s2, h, d)
-  constexpr int NKE = (K_ELEMS + 255) / 256, NVE = (V_ELEMS + 255) / 256;
+  // staging: a key tile's two images are 2 NS x 128 elements of 16 bytes, already in LDS order: plain coalesced copies,
+  // requested one tile ahead into registers
   constexpr float invS = 1.f / kAttS;
-  const AttRsrc kr = att_rsrc(kb, D * ld * 4), vr = att_rsrc(vb, D * ld * 4);
-  float rk[NKE][8], rv[NVE][8];
+  constexpr int KSZ = NS * 2 * 2 * 32, VSZ = DT * 2 * 2 * 2 * 32;
+  constexpr int NKE = KSZ / 256, NVE = VSZ / 256;
+  static_assert(KSZ % 256 == 0 && VSZ % 256 == 0, "image sizes are multiples of the workgroup");
+  const int ntile = (T + 31) / 32;
+  const uint4* kt_base = kimg + ((long)b * H + hd) * ntile * KSZ;
+  const uint4* vt_base = vimg + ((long)b * H + hd) * ntile * VSZ;
+  uint4 rk[NKE], rv[NVE];
   auto fetch = [&](int k0) {
+    const uint4* kp = kt_base + (long)(k0 >> 5) * KSZ;
+    const uint4* vp = vt_base + (long)(k0 >> 5) * VSZ;
 #pragma unroll
-    for (int j = 0; j < NKE; ++j) {
-      const int e0 = tid + 256 * j;
-      const int key = e0 & 31, hh = (e0 >> 5) & 1, s = e0 >> 6;
-      const bool ok = e0 < K_ELEMS && k0 + key < len;
+    for (int j = 0; j < NKE; ++j) rk[j] = kp[tid + 256 * j];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rk[j][e] = att_load(kr, ok ? ((16 * s + 8 * hh + e) * ld + k0 + key) * 4 : kAttOob);
-    }
-#pragma unroll
-    for (int j = 0; j < NVE; ++j) {
-      const int e0 = tid + 256 * j;
-      const int dd = e0 & 31, hh = (e0 >> 5) & 1, s2 = (e0 >> 6) & 1, dt = e0 >> 7;
-      const int d = dt * 32 + dd;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int r = 8 * s2 + e;
-        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        rv[j][e] = att_load(vr, (e0 < V_ELEMS && key < len) ? (d * ld + key) * 4 : kAttOob);
-      }
-    }
+    for (int j = 0; j < NVE; ++j) rv[j] = vp[tid + 256 * j];
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < NKE; ++j) {
-      const int e0 = tid + 256 * j;
-      if (NKE * 256 == K_ELEMS || e0 < K_ELEMS) {
-        const int key = e0 & 31, hh = (e0 >> 5) & 1, s = e0 >> 6;
-        ahalf8 a0, a1, a2;
+    for (int j = 0; j < NKE; ++j) Ks[tid + 256 * j] = rk[j];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float val = rk[j][e];
-          ovf |= !(fabsf(val) < kH3ActLimit / kAttS);
-          const _Float16 vh = (_Float16)val;
-          a0[e] = (_Float16)((float)vh * kAttS);
-          a1[e] = vh;
-          a2[e] = (_Float16)((val - (float)vh) * kAttS);
-        }
-        Ks[((s * 2 + 0) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a0);
-        Ks[((s * 2 + 1) * 2 + hh) * 32 + key] = __builtin_bit_cast(uint4, a2);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NVE; ++j) {
-      const int e0 = tid + 256 * j;
-      if (NVE * 256 == V_ELEMS || e0 < V_ELEMS) {
-        const int dd = e0 & 31, hh = (e0 >> 5) & 1, s2 = (e0 >> 6) & 1, dt = e0 >> 7;
-        ahalf8 a0, a1, a2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float val = rv[j][e];
-          ovf |= !(fabsf(val) < kH3ActLimit / kAttS);
-          const _Float16 vh = (_Float16)val;
-          a0[e] = (_Float16)((float)vh * kAttS);
-          a1[e] = vh;
-          a2[e] = (_Float16)((val - (float)vh) * kAttS);
-        }
-        Vs[(((dt * 2 + s2) * 2 + 0) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a0);
-        Vs[(((dt * 2 + s2) * 2 + 1) * 2 + hh) * 32 + dd] = __builtin_bit_cast(uint4, a2);
-      }
-    }
+    for (int j = 0; j < NVE; ++j) Vs[tid + 256 * j] = rv[j];
   };
 
   const int tiles = (len + 31) / 32;
@@ -636,15 +644,27 @@ void launch_attention(const float* q, const float* k, const float* v, float* out
   dim3 grid(cdiv(T, 128) * nsplit, H, B);
   static const int h3_env = getenv("RVCX_ATT_H3") ? atoi(getenv("RVCX_ATT_H3")) : 1;   // 0: exact-fp32 MFMA attention
   const int h3 = h3_env && !g_force_fp32 && allow_h3;
-  if (h3 && DT == 1)
-    hipLaunchKernelGGL(attn_h3_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
-  else if (h3 && DT == 2)
-    hipLaunchKernelGGL(attn_h3_kernel<2>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
-  else if (h3)
-    hipLaunchKernelGGL(attn_h3_kernel<3>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
-                       out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
+  if (h3) {
+    // K / V split once into the kernel's LDS images (behind the split-KV partials in split_scratch)
+    RVCX_CHECK(split_scratch != nullptr, "attention: the split-fp16 kernel needs its scratch");
+    const int ntile = cdiv(T, 32);
+    uint4* kimg = reinterpret_cast<uint4*>(split_scratch + (size_t)B * H * 8 * 98 * T);
+    uint4* vimg = kimg + (size_t)B * H * ntile * (DT * 256);
+    const dim3 pg(ntile, H, B);
+    if (DT == 1) {
+      hipLaunchKernelGGL(att_presplit_kernel<1>, pg, dim3(256), 0, stream, k, v, kimg, vimg, H, D, T, ld, in_bs, lens, ovf, ovf_layer, seq);
+      hipLaunchKernelGGL(attn_h3_kernel<1>, grid, dim3(256), 0, stream, q, kimg, vimg, out, mo, lo, relq, H, D, T, ld, in_bs,
+                         out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
+    } else if (DT == 2) {
+      hipLaunchKernelGGL(att_presplit_kernel<2>, pg, dim3(256), 0, stream, k, v, kimg, vimg, H, D, T, ld, in_bs, lens, ovf, ovf_layer, seq);
+      hipLaunchKernelGGL(attn_h3_kernel<2>, grid, dim3(256), 0, stream, q, kimg, vimg, out, mo, lo, relq, H, D, T, ld, in_bs,
+                         out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
+    } else {
+      hipLaunchKernelGGL(att_presplit_kernel<3>, pg, dim3(256), 0, stream, k, v, kimg, vimg, H, D, T, ld, in_bs, lens, ovf, ovf_layer, seq);
+      hipLaunchKernelGGL(attn_h3_kernel<3>, grid, dim3(256), 0, stream, q, kimg, vimg, out, mo, lo, relq, H, D, T, ld, in_bs,
+                         out_bs, scale, window, lens, nsplit, opart, ovf, ovf_layer, seq);
+    }
+  }
   else if (DT == 1)
     hipLaunchKernelGGL(attn_kernel<1>, grid, dim3(256), 0, stream, q, k, v, out, mo, lo, relq, H, D, T, ld, in_bs,
                        out_bs, scale, window, lens, nsplit, opart);
@@ -670,7 +690,8 @@ size_t attention_scratch_floats(int B, int H, int T, int window) {
 }
 
 // scratch for the split-KV partials (worst case 8 splits, head dim padded to 96, + m and l rows)
-size_t attention_split_floats(int B, int H, int T) { return (size_t)B * H * 8 * 98 * T; }
+// + the split K / V images of the split-fp16 kernel: 2 x 96 x 4 bytes per (head, key), keys rounded up to tiles of 32
+size_t attention_split_floats(int B, int H, int T) { return (size_t)B * H * (8 * 98 * (size_t)T + 2 * 96 * ((size_t)T + 32)); }
 
 double attention_flops(int B, int H, int D, int T) { return 4.0 * B * H * (double)T * T * D; }
 

@@ -79,7 +79,7 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
   const int64_t t0 = (n - m.cfg.conv_kernels[0]) / m.cfg.conv_strides[0] + 1;
   const int T = hubert_frames(m, n);
   size_t conv = 2 * (size_t)m.cfg.conv_dim * t0;
-  size_t enc = (size_t)T * (size_t)(11 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + 8 * 98 * m.cfg.heads);
+  size_t enc = (size_t)T * (size_t)(11 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + (8 * 98 + 2 * 96 + 8) * m.cfg.heads);
   return (size_t)B * (conv + enc) * sizeof(float) + ((size_t)64 << 20);
 }
 

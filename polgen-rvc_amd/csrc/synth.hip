@@ -147,7 +147,7 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
 size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
   const auto& cf = m.cfg;
   size_t enc = (size_t)B * T * (size_t)(cf.input_dim + 8 * cf.hidden_channels + 2 * cf.filter_channels +
-                                        4 * cf.inter_channels + 64 + 8 * 98 * cf.n_heads);
+                                        4 * cf.inter_channels + 64 + (8 * 98 + 2 * 96 + 8) * cf.n_heads);
   size_t dec = (size_t)B * T * m.upp * 3;  // har, noise, out
   size_t mx = 0, sum = (size_t)B * T * cf.up_initial_channel;
   long tt = T;
