@@ -52,11 +52,13 @@ CPU_SAMPLE_SECONDS = 8.0
 PMC_FILES = ("pmc_traffic_r03.json", "pmc_traffic_r02.json")     # newest first
 
 
-def load_models(ctx, zero=False, fcpe=False, also_40k=False):
+def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False):
     def z(state):
         return {k: np.zeros_like(v) for k, v in state.items()} if zero else state
     ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0)))
-    if fcpe:
+    if crepe:
+        ctx.load_crepe(z(S.crepe_state("full", 0)))
+    elif fcpe:
         sd = S.fcpe_state(S.FCPE_CFG_FULL, 0)
         ctx.load_fcpe(W.fcpe_cfg_struct(W.fcpe_cfg_from_state(sd)), z(sd))
     else:
@@ -68,9 +70,10 @@ def load_models(ctx, zero=False, fcpe=False, also_40k=False):
     return mid48, mid40
 
 
-def make_params(seed=0, fcpe=False):
+def make_params(seed=0, fcpe=False, crepe=False):
     p = _lib.Params()
-    p.f0_method = _lib.F0_FCPE if fcpe else _lib.F0_RMVPE
+    p.f0_method = _lib.F0_CREPE if crepe else (_lib.F0_FCPE if fcpe else _lib.F0_RMVPE)
+    p.hop_length = 128
     p.pitch, p.f0_min, p.f0_max = 0.0, 50.0, 1100.0
     p.index_rate, p.protect, p.volume_envelope = 0.0, 0.33, 1.0
     p.sid = 0
@@ -270,8 +273,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2")
     ap.add_argument("--batch", type=int, default=None, help="clips per step (c3 default 64, c2 default 1)")
-    ap.add_argument("--f0-method", choices=["rmvpe+", "fcpe"], default="rmvpe+",
-                    help="F0 back-end of VC.get_f0; BASELINE's metric is quoted on rmvpe+ (fcpe: secondary line)")
+    ap.add_argument("--f0-method", choices=["rmvpe+", "fcpe", "mangio-crepe"], default="rmvpe+",
+                    help="F0 back-end of VC.get_f0; BASELINE's metric is quoted on rmvpe+ (the others: secondary lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-children", "--no-exact-fp32", dest="no_children", action="store_true",
                     help="skip the exact_fp32 and c3 child benches of the default run")
@@ -281,7 +284,8 @@ def main():
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1)
     a = ap.parse_args()
     c3, c5 = a.workload == "c3", a.workload == "c5"
-    fcpe = a.f0_method == "fcpe"
+    crepe = a.f0_method == "mangio-crepe"
+    fcpe = a.f0_method == "fcpe" or crepe            # "a secondary line": no children, no roofline object, no CPU baseline
     B = a.batch or (C3_BATCH if c3 else 1)
     if a.steps is None:
         a.steps = 3 if (c3 or c5) else 10
@@ -308,7 +312,7 @@ def main():
 
     # rank 0 parses/folds/packs the checkpoints; the folded weight regions go to the other GPUs over RCCL/xGMI
     t0 = time.perf_counter()
-    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5)
+    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5, crepe=crepe)
     mid = mids[0] if c5 else mids
     if c3:
         big = S.make_index(C3_INDEX_ROWS, 768, 0)
@@ -318,7 +322,7 @@ def main():
     nbytes = D.broadcast_weights(ctx, local, 0)
     t_bcast = time.perf_counter() - t0
 
-    params = make_params(fcpe=fcpe)
+    params = make_params(fcpe=fcpe, crepe=crepe)
     if c3:
         params.index_rate = 0.75
     # pinned host buffers: the step's H2D / D2H copies are asynchronous DMA inside the timed region
@@ -410,7 +414,7 @@ def main():
             wl = (("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
                   ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
         if fcpe:
-            wl = wl.replace("f0_method=rmvpe+", "f0_method=fcpe (secondary line: BASELINE's metric is quoted on rmvpe+)")
+            wl = wl.replace("f0_method=rmvpe+", f"f0_method={a.f0_method} (secondary line: BASELINE's metric is quoted on rmvpe+)")
         multi = len(clips) > 1
         res = {"metric": "real-time-factor (audio-sec/wall-sec) per GPU, 30s@16kHz RMVPE->48kHz",
                "value": rtf, "unit": "x real-time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
