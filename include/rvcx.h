@@ -202,9 +202,10 @@ int64_t rvcx_out_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
  * buffers of rvcx_out_len samples (host or device); out_f32[i] optional (same capacity) float
  * waveform before int16 quantisation; out_n[i] receives the number of samples produced; noise[i] optional
  * packed parity noise (see rvcx_noise_len).
- * Utterances of equal length are converted together as micro-batches (B > 1 through HuBERT, RMVPE and the
- * synthesizer; rvcx_micro_batch tells how many at a time); every utterance's result is bit-identical to
- * converting it alone.  Without parity noise utterance i draws its Gaussians from Philox(seed + i).
+ * Utterances of one length class (rvcx_bucket_length: padded lengths within RVCX_BUCKET_FRAMES 10 ms frames, default
+ * 64; clips long enough to be cut into chunks: equal lengths) are converted together as ragged micro-batches (B > 1
+ * through HuBERT, RMVPE, TextEncoder and flow with per-item lengths; rvcx_micro_batch tells how many at a time;
+ * rvcx_last_micro_batches what the last call did); every utterance's result is bit-identical to converting it alone.  Without parity noise utterance i draws its Gaussians from Philox(seed + i).
  * Batch conversion is listed as not done in the reference (TODO.md:11). */
 int rvcx_convert_batch(rvcx_ctx*, int model_id, int B, const float* const* wav16k_hd,
                        const int64_t* n, const rvcx_params* p, const float* const* noise_hd,
@@ -220,6 +221,12 @@ int rvcx_convert_batch_ex(rvcx_ctx*, int model_id, int B, const void* const* wav
                           const rvcx_utt_extra* extra, int16_t* const* out_hd, float* const* out_f32_hd, int64_t* out_n);
 /* utterances of n samples converted per launch sequence (memory-bounded; RVCX_MAX_BATCH, RVCX_ARENA_GB) */
 int rvcx_micro_batch(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
+/* The sample count whose launch geometry an n-sample utterance is converted with (>= n): utterances with equal values
+ * share micro-batches.  An uncut rmvpe clip: the longest clip of its length class; otherwise n itself. */
+int64_t rvcx_bucket_length(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
+/* Member counts of the micro-batches the last rvcx_convert_batch* call of this context formed (in launch order);
+ * returns their number (counts receives at most cap of them). */
+int rvcx_last_micro_batches(rvcx_ctx*, int32_t* counts, int cap);
 /* floats of parity noise rvcx_convert_batch consumes for one n-sample utterance: for each
  * chunk in order, z_noise (inter*T) then src_noise (T*upp) -- the draw order of the reference */
 int64_t rvcx_noise_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);

@@ -77,7 +77,7 @@ SYMBOLS = [
     "rvcx_load_rmvpe", "rvcx_index_exhaustive", "rvcx_load_crepe", "rvcx_crepe_frames", "rvcx_crepe_predict", "rvcx_op_crepe_decode", "rvcx_get_f0_crepe_x", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
     "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_weights_clone", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
     "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
-    "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_noise_len",
+    "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_bucket_length", "rvcx_last_micro_batches", "rvcx_noise_len",
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         _lib.rvcx_fp32_reruns.restype = C.c_int64
         _lib.rvcx_fp32_layers.restype = C.c_int64
         _lib.rvcx_gru_fallbacks.restype = C.c_int64
+        _lib.rvcx_bucket_length.restype = C.c_int64
         _lib.rvcx_resample_len.restype = C.c_int64
         _lib.rvcx_noise_len.restype = C.c_int64
         _lib.rvcx_crepe_frames.restype = C.c_int64
@@ -551,7 +552,7 @@ class Context:
     def convert_batch(self, model_id, wavs, params: "Params", noises=None, want_f32=False, inp_f0=None, crepe_dither=None):
         """VC.pipeline for a list of 16 kHz mono clips -> list of int16 arrays (and the pre-quantisation
         float waveforms when want_f32).  float64 clips (what the reference's load_audio returns) cross the
-        ABI as float64; anything else as float32.  Equal-length clips are converted as micro-batches."""
+        ABI as float64; anything else as float32.  Clips of one length class are converted as ragged micro-batches."""
         B = len(wavs)
         is64 = B > 0 and all(np.asarray(w).dtype == np.float64 for w in wavs)
         wavs = [np.ascontiguousarray(w, dtype=np.float64 if is64 else np.float32) for w in wavs]
@@ -616,6 +617,17 @@ class Context:
 
     def micro_batch(self, model_id, n, params) -> int:
         return int(lib().rvcx_micro_batch(self._h, model_id, C.c_int64(n), C.byref(params)))
+
+    def bucket_length(self, model_id, n, params) -> int:
+        """the length whose launch geometry an n-sample utterance runs with: equal values share micro-batches"""
+        return int(lib().rvcx_bucket_length(self._h, model_id, C.c_int64(n), C.byref(params)))
+
+    def last_micro_batches(self):
+        """member counts of the micro-batches the last convert_batch call formed"""
+        cap = 4096
+        buf = (C.c_int32 * cap)()
+        k = int(lib().rvcx_last_micro_batches(self._h, buf, cap))
+        return [int(buf[i]) for i in range(min(k, cap))]
 
     def get_f0_x(self, x, params: "Params"):
         """VC.get_f0 on the already padded + filtered signal: (coarse, f0) of 1 + n/160 frames."""

@@ -1325,6 +1325,23 @@ int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* 
   }
 }
 
+int64_t rvcx_bucket_length(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  if (!ctx || !p || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
+  try {
+    return bucket_length(n, *p, make_geometry(*p, ctx->c.synths[model_id]->cfg.sr));
+  } catch (const std::exception& e) {
+    ctx->c.last_error = e.what();
+    return -1;
+  }
+}
+
+int rvcx_last_micro_batches(rvcx_ctx* ctx, int32_t* counts, int cap) {
+  if (!ctx) return -1;
+  const auto& v = ctx->c.last_mbs;
+  for (int i = 0; i < (int)v.size() && i < cap && counts; ++i) counts[i] = v[i];
+  return (int)v.size();
+}
+
 int rvcx_get_f0(rvcx_ctx* ctx, const float* wav16k, int64_t n, const rvcx_params* p, int32_t* coarse, float* f0,
                 int64_t* p_len) {
   API_BEGIN(ctx)

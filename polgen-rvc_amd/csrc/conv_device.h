@@ -54,6 +54,7 @@ __device__ __forceinline__ void store_elem(const ConvArgs& a, int b, int cg, int
     const int ph = cg / a.sh_cout, c = cg - ph * a.sh_cout;
     const int pa = ph >> 1, pb = ph & 1;
     const int irow = nn / a.wp_in, jj = nn - irow * a.wp_in;
+    if (nn >= len_out) v = 0.f;          // rows below a shorter item's last one stay zero
     if (jj != 0 && jj != a.wp_in - 1) {
       const long rowbase = (long)b * a.y_bs + (long)c * a.y_cs + (long)(2 * irow + pa) * a.wp_out;
       a.y[rowbase + 2 * (jj - 1) + pb + 1] = v;

@@ -198,6 +198,7 @@ struct Ctx {
   bool inject_gru_timeout = false;
   int launch_seq = 0;             // launches of split-fp16 kernels since the call began (orders the layers' overflow stamps)
   float timing[9] = {0};
+  std::vector<int> last_mbs;      // member counts of the micro-batches of the last convert_batch call
   StageTimer timer;
   std::unique_ptr<HubertModel> hubert;
   std::unique_ptr<RmvpeModel> rmvpe;

@@ -22,7 +22,8 @@ template <int H>
 __global__ __launch_bounds__(3 * H) void bigru_kernel(const float* __restrict__ gi,
                                                       const float* __restrict__ whh_t,  // (2, H, 3H)
                                                       const float* __restrict__ bhh,    // (2, 3H)
-                                                      float* __restrict__ y, int T) {
+                                                      float* __restrict__ y, int T,
+                                                      const int* __restrict__ lens) {
   __shared__ float hs[H];
   __shared__ float gh[3 * H];
   const int dir = blockIdx.x, b = blockIdx.y;
@@ -31,10 +32,11 @@ __global__ __launch_bounds__(3 * H) void bigru_kernel(const float* __restrict__ 
   const float bj = bhh[dir * 3 * H + j];
   const float* gib = gi + (long)b * T * 6 * H + dir * 3 * H;
   float* yb = y + ((long)b * 2 + dir) * H * T;
+  const int Tn = lens ? lens[b] : T;      // this item's frames (rows stay T apart)
   if (j < H) hs[j] = 0.f;
   __syncthreads();
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? step : T - 1 - step;
+  for (int step = 0; step < Tn; ++step) {
+    const int t = dir == 0 ? step : Tn - 1 - step;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll 8
     for (int k = 0; k < H; k += 4) {
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
                                                                     const float* __restrict__ bhh,
                                                                     float* __restrict__ y,
                                                                     unsigned long long* xbuf,  // (B,2,2,H) granules
-                                                                    int* err, int T, int nq, int colocate) {
+                                                                    int* err, int T, int nq, int colocate,
+                                                                    const int* __restrict__ lens) {
   using G = GruGeom<NC, CPT>;
   static_assert(G::THREADS == 384, "launch bounds");
   constexpr int GATHER0 = (G::U + 63) / 64 * 64;     // first polling thread: the wave after the publishing lanes
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
   if (q >= nq) return;
   __builtin_amdgcn_s_setprio(3);   // latency-bound serial chain: issue ahead of co-resident conv waves
   const int dir = q & 1, b = q >> 1;
+  const int Tn = lens ? lens[b] : T;      // this item's frames: every workgroup of the cluster takes the same count
   const int tid = threadIdx.x;
   const int rg = tid % GRU_NRG, cs = tid / GRU_NRG;
   const float* W = whh_t + (long)dir * H * 3 * H;
@@ -164,16 +168,16 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
   __syncthreads();
   // input-projection terms of the next step are fetched one step ahead (they do not depend on h)
   float gr_n = 0.f, gz_n = 0.f, gn_n = 0.f;
-  if (tid < GRU_U && T > 0) {
-    const float* g = gib + (long)(dir == 0 ? 0 : T - 1) * 6 * H;
+  if (tid < GRU_U && Tn > 0) {
+    const float* g = gib + (long)(dir == 0 ? 0 : Tn - 1) * 6 * H;
     gr_n = g[ju];
     gz_n = g[H + ju];
     gn_n = g[2 * H + ju];
   }
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? step : T - 1 - step;
+  for (int step = 0; step < Tn; ++step) {
+    const int t = dir == 0 ? step : Tn - 1 - step;
     const float g_r = gr_n, g_z = gz_n, g_n = gn_n;
-    if (tid < GRU_U && step + 1 < T) {
+    if (tid < GRU_U && step + 1 < Tn) {
       const float* g = gib + (long)(dir == 0 ? t + 1 : t - 1) * 6 * H;
       gr_n = g[ju];
       gz_n = g[H + ju];
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
 size_t bigru_scratch_bytes(int B) { return (size_t)B * 2 * 2 * GRU_H * sizeof(unsigned long long); }
 
 void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* y, int B, int T, int H,
-                  void* scratch, int* err, hipStream_t stream) {
+                  void* scratch, int* err, hipStream_t stream, const int* lens) {
   RVCX_CHECK(H == GRU_H, "bigru: hidden size must be 256 (RMVPE)");
   // the cluster kernel needs all 2*B*NC workgroups co-resident (they spin on each other)
   static const int nc = getenv("RVCX_GRU_NC") ? atoi(getenv("RVCX_GRU_NC")) : GRU_NC;
@@ -257,12 +261,12 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
     const int grid = colocate ? 8 * nc * cdiv(nq, 8) : nc * nq;
     if (nc == 8)
       hipLaunchKernelGGL((bigru_cluster_kernel<8, 16>), dim3(grid), dim3(GruGeom<8, 16>::THREADS), 0, stream, gi, whh_t, bhh,
-                         y, xbuf, err, T, nq, colocate);
+                         y, xbuf, err, T, nq, colocate, lens);
     else
       hipLaunchKernelGGL((bigru_cluster_kernel<4, 32>), dim3(grid), dim3(GruGeom<4, 32>::THREADS), 0, stream, gi, whh_t, bhh,
-                         y, xbuf, err, T, nq, colocate);
+                         y, xbuf, err, T, nq, colocate, lens);
   } else {
-    hipLaunchKernelGGL(bigru_kernel<GRU_H>, dim3(2, B), dim3(3 * GRU_H), 0, stream, gi, whh_t, bhh, y, T);
+    hipLaunchKernelGGL(bigru_kernel<GRU_H>, dim3(2, B), dim3(3 * GRU_H), 0, stream, gi, whh_t, bhh, y, T, lens);
   }
   RVCX_HIP(hipGetLastError());
 }

@@ -84,12 +84,31 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
 }
 
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
-                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor, long wav_bs) {
+                    float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor, long wav_bs,
+                    const int* ns_host) {
   Arena& A = c.arena;
   const auto& cf = m.cfg;
   const int C = cf.conv_dim, E = cf.embed_dim;
   const int64_t t0 = (n - cf.conv_kernels[0]) / cf.conv_strides[0] + 1;
   RVCX_CHECK(t0 > 0, "hubert: input too short");
+  // ---- ragged batch: item b holds ns_host[b] <= n samples (zeros behind them).  The extractor has no padding, so an
+  // item's valid frames depend on its valid samples only; what needs the item's own length is the GroupNorm
+  // statistics, the zero padding of pos_conv and the attention's key range.
+  bool ragged = false;
+  std::vector<int> t0b(B, (int)t0), Tb(B, hubert_frames(m, n));
+  if (ns_host)
+    for (int b = 0; b < B; ++b) {
+      RVCX_CHECK(ns_host[b] <= n, "hubert: item longer than the batch geometry");
+      t0b[b] = (int)((ns_host[b] - cf.conv_kernels[0]) / cf.conv_strides[0] + 1);
+      Tb[b] = hubert_frames(m, ns_host[b]);
+      RVCX_CHECK(Tb[b] > 0, "hubert: input too short");
+      ragged |= ns_host[b] != n;
+    }
+  const int *d_t0 = nullptr, *d_T = nullptr;
+  if (ragged) {
+    d_t0 = dev_ints(A, t0b, s);
+    d_T = dev_ints(A, Tb, s);
+  }
   float* bufa = A.alloc<float>((size_t)B * C * t0);
   float* bufb = A.alloc<float>((size_t)B * C * t0);
   // ---- conv feature extractor
@@ -105,7 +124,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     c.conv_on(a, s);
     if (i == 0) {
       float* z = (y == bufa) ? bufb : bufa;
-      launch_groupnorm_gelu(y, m.gn_g, m.gn_b, z, B, C, (int)Tout, 1e-5f, s);
+      launch_groupnorm_gelu(y, m.gn_g, m.gn_b, z, B, C, (int)Tout, 1e-5f, s, d_t0);
       y = z;
     }
     x = y;
@@ -124,6 +143,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     c.conv_on(a, s);
     a = conv1d_args(m.pos_conv, h, h2, B, T, T, 1, 1, cf.pos_kernel / 2);   // SamePad: drop the last frame
     a.act = ACT_GELU;
+    a.lens_in = a.lens_out = d_T;    // zero padding behind the item's last frame
     conv_set_res(a, h, E, T);
     c.conv_on(a, s);
   }
@@ -160,9 +180,10 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
       else g.x = hf, g.ld_x = ldE;
       g.y_cf = qkv;
       g.cf_bs = (long)3 * E * T;
+      g.lens = d_T;                  // rows behind an item's last frame are stored as zeros
       c.gemm_on(g, s);
       launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T, (long)3 * E * T,
-                       (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s, c.dev_err, L.att.word,
+                       (long)E * T, scale, nullptr, nullptr, 0, d_T, nullptr, asplit, s, c.dev_err, L.att.word,
                        ++c.launch_seq, L.att.h3());
       c.flops += attention_flops(B, cf.heads, hd, T);
       launch_cf_to_tm(att, (long)E * T, o3 ? nullptr : attr, ldE, o3 ? attr : nullptr, ldEb, B, E, T, c.dev_err,
@@ -213,9 +234,10 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
   for (int l = 0; l < nl; ++l) {
     const auto& L = m.layers[l];
     ConvArgs a = conv1d_args(L.qkv, h, qkv, B, T, T);
+    a.lens_out = d_T;
     c.conv_on(a, s);
     launch_attention(qkv, qkv + (size_t)E * T, qkv + (size_t)2 * E * T, att, B, cf.heads, hd, T, T,
-                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, nullptr, nullptr, asplit, s, c.dev_err, L.att.word,
+                     (long)3 * E * T, (long)E * T, scale, nullptr, nullptr, 0, d_T, nullptr, asplit, s, c.dev_err, L.att.word,
                      ++c.launch_seq, L.att.h3());
     c.flops += attention_flops(B, cf.heads, hd, T);
     a = conv1d_args(L.o, att, h2, B, T, T);

@@ -95,9 +95,11 @@ size_t rmvpe_arena_bytes(const RmvpeModel& m, int B, int64_t n);
 // mel_out (optional): device (B, 128, frames) log-mel spectrogram (MelSpectrogram.forward, RMVPE.py:412-439)
 // `after_shallow` (optional) runs on the host once the mel front end and the first U-Net encoder levels (the long
 // launches) are enqueued: the pipeline enqueues HuBERT there, so that neither branch waits for the host
+// ns_host (optional, B ints): a ragged batch -- item b holds ns_host[b] <= n samples in its row of n; its f0 row has
+// 1 + ns_host[b]/160 valid frames and is bit-identical to what the call returns for that item alone in a row of n
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
                    float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out = nullptr,
-                   const std::function<void()>* after_shallow = nullptr);
+                   const std::function<void()>* after_shallow = nullptr, const int* ns_host = nullptr);
 
 // ------------------------------------------------------------------------------ FCPE
 struct FcpeModel {
@@ -174,9 +176,11 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n);
 // wav: device (B,n).  feats_ct: device (B, embed, T') channel-first.
 // `after_extractor` (optional) runs on the host right after the conv feature extractor has been enqueued:
 // the pipeline uses it to enqueue RMVPE's ~330 small launches while those long convs keep the GPU busy.
+// ns_host (optional, B ints): a ragged batch -- item b holds ns_host[b] <= n samples, zeros behind them; its first
+// hubert_frames(ns_host[b]) feature frames are bit-identical to what the call returns for that item alone in a row of n
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
                     float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor = nullptr,
-                    long wav_bs = 0 /* element stride between the B signals, 0 = n */);
+                    long wav_bs = 0 /* element stride between the B signals, 0 = n */, const int* ns_host = nullptr);
 
 // ------------------------------------------------------------------------------ retrieval index
 struct IndexData {

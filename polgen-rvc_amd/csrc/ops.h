@@ -21,8 +21,10 @@ double attention_flops(int B, int H, int D, int T);
 // scratch: bigru_scratch_bytes(B) of device memory for the inter-CU exchange; err: device flag set to 1 if
 // the cluster kernel timed out waiting for a partner workgroup (null scratch/err -> single-CU kernel)
 size_t bigru_scratch_bytes(int B);
+// lens (device, B ints or null): item b runs lens[b] <= T steps -- the reverse direction starts at frame lens[b] - 1 --
+// while rows stay T frames apart; y beyond an item's length is not written
 void launch_bigru(const float* gi, const float* whh, const float* bhh, float* y, int B, int T, int H,
-                  void* scratch, int* err, hipStream_t stream);
+                  void* scratch, int* err, hipStream_t stream, const int* lens = nullptr);
 
 // ---- ops.hip
 // LayerNorm over channels of (B,C,T): y = (x-mean)/sqrt(var+eps)*gamma+beta  [normalization.py:13-16]
@@ -37,8 +39,10 @@ void launch_layernorm_tm(const float* x, long ld_x, const float* gamma, const fl
 void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, long ld_ys, int B, int C, int T, int* ovf,
                      int* ovf_next, int seq, hipStream_t s);
 // per-(b,c) normalisation over time + GELU (GroupNorm(C,C) of the HuBERT extractor)
+// lens (device, B ints or null): statistics over the item's first lens[b] frames only (rows stay T apart); frames
+// beyond are stored as zeros
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
-                           float eps, hipStream_t s);
+                           float eps, hipStream_t s, const int* lens = nullptr);
 // (B,R,Cc) -> (B,Cc,R)
 void launch_transpose(const float* x, float* y, int B, int R, int Cc, hipStream_t s);
 // x[c][t] = lrelu((x[c][t] + emb[pitch[t]][c]) * scale, slope) * (t<len)     [encoders.py:116-123]
@@ -70,12 +74,22 @@ void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStrea
 
 // ---- RMVPE helpers
 // reflect-pad 1-D signals: x (B,n) -> y (B,n+2p) written with batch stride y_bs
-void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s);
+// ns (device, B ints or null): item b holds ns[b] <= n samples (rows of x stay x_bs = n apart unless given); its padded
+// signal is ns[b] + 2p long and the rest of the row (up to n + 2p) is written as zeros
+void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s, const int* ns = nullptr,
+                        long x_bs = 0);
+// small int arrays for the kernels' per-item length arguments: written by a kernel from by-value arguments (no host
+// buffer has to outlive the call, no DMA in the launch sequence)
+int* dev_ints(Arena& A, const int* v, int n, hipStream_t s);
+void set_dev_ints(int* dst, const int* v, int n, hipStream_t s);      // the same into memory the caller owns
+inline int* dev_ints(Arena& A, const std::vector<int>& v, hipStream_t s) { return dev_ints(A, v.data(), (int)v.size(), s); }
 // |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F) = sqrt(re^2 + im^2 + eps)   (eps: FCPE.py:147)
 void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s, float eps = 0.f);
 // log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp
+// fs / tps (device, B ints each, or null): item b has fs[b] <= F frames reflect-padded to tps[b] <= Tp rows; rows beyond
+// tps[b] are zero
 void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, const float* bn,
-                     hipStream_t s);
+                     hipStream_t s, const int* fs = nullptr, const int* tps = nullptr);
 // y = log(max(x, floor))
 void launch_log_clamp(const float* x, float* y, long n, float floor, hipStream_t s);
 // 2x2 average pool on row-padded maps: (B*C, H, Wp) -> (B*C, H/2, W/2+2)
@@ -112,7 +126,9 @@ void launch_resample_f32(const ResampleFilter& f, const float* x, long n, float*
 
 // ---- pipeline glue
 // feats (C,T) -> x2 nearest upsample, protect mix; writes phone (C, 2T') cropped to p_len  [pipeline.py:252-270]
+// ld_in / ld_out (0 = Th / p_len): row strides of feats / out when the item sits in a wider batch row
 void launch_upsample_protect(const float* feats, const float* feats0, const float* pitchf, float* out, int C,
-                             int Th, int p_len, float protect, int use_protect, hipStream_t s);
+                             int Th, int p_len, float protect, int use_protect, hipStream_t s, int ld_in = 0,
+                             int ld_out = 0);
 
 }  // namespace rvcx

@@ -203,11 +203,12 @@ void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, l
 __global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
-                                                             int C, int T, float eps) {
+                                                             int C, int Trow, float eps, const int* __restrict__ lens) {
   __shared__ double red[2][8];
   const int c = blockIdx.x, b = blockIdx.y;
-  const float* xr = x + ((long)b * C + c) * T;
-  float* yr = y + ((long)b * C + c) * T;
+  const float* xr = x + ((long)b * C + c) * Trow;
+  float* yr = y + ((long)b * C + c) * Trow;
+  const int T = lens ? lens[b] : Trow;        // the item's own frame count: sums, and their order, are those of its single run
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s = 0.0, q = 0.0;
   int t = tid;
@@ -251,11 +252,12 @@ __global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __rest
     yr[t + 1536] = gelu_erf((v3 - mean) * rstd * g + bb);
   }
   for (; t < T; t += 512) yr[t] = gelu_erf((xr[t] - mean) * rstd * g + bb);
+  for (t = T + tid; t < Trow; t += 512) yr[t] = 0.f;
 }
 
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
-                           float eps, hipStream_t s) {
-  hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3(C, B), dim3(512), 0, s, x, gamma, beta, y, C, T, eps);
+                           float eps, hipStream_t s, const int* lens) {
+  hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3(C, B), dim3(512), 0, s, x, gamma, beta, y, C, T, eps, lens);
 }
 
 // ------------------------------------------------------------------ batched transpose
@@ -522,20 +524,44 @@ void launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStrea
 }
 
 // ------------------------------------------------------------------ RMVPE helpers
-__global__ void reflect_pad_kernel(const float* x, float* y, int n, int p, long y_bs, long total) {
+__global__ void reflect_pad_kernel(const float* x, float* y, int n, int p, long y_bs, long total, const int* ns,
+                                   long x_bs) {
   const int np2 = n + 2 * p;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long b = idx / np2;
     const long o = idx - b * np2;
+    const int nb = ns ? ns[b] : n;
     int j = (int)o - p;
     if (j < 0) j = -j;
-    if (j >= n) j = 2 * (n - 1) - j;
-    y[b * y_bs + o] = x[b * n + j];
+    if (j >= nb) j = 2 * (nb - 1) - j;
+    y[b * y_bs + o] = o < nb + 2 * p ? x[b * x_bs + j] : 0.f;
   }
 }
-void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s) {
+void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs, hipStream_t s, const int* ns, long x_bs) {
   long tot = (long)B * (n + 2 * p);
-  hipLaunchKernelGGL(reflect_pad_kernel, EW_GRID(tot), 0, s, x, y, n, p, y_bs, tot);
+  hipLaunchKernelGGL(reflect_pad_kernel, EW_GRID(tot), 0, s, x, y, n, p, y_bs, tot, ns, x_bs > 0 ? x_bs : (long)n);
+}
+
+namespace {
+struct IntPack {
+  int v[32];
+};
+__global__ void set_ints_kernel(int* dst, IntPack pk, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = pk.v[threadIdx.x];
+}
+}  // namespace
+void set_dev_ints(int* d, const int* v, int n, hipStream_t s) {
+  for (int o = 0; o < n; o += 32) {
+    IntPack pk;
+    const int m = std::min(32, n - o);
+    for (int i = 0; i < 32; ++i) pk.v[i] = i < m ? v[o + i] : 0;
+    hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(32), 0, s, d + o, pk, m);
+  }
+}
+int* dev_ints(Arena& A, const int* v, int n, hipStream_t s) {
+  int* d = A.alloc<int>((size_t)std::max(n, 1));
+  set_dev_ints(d, v, n, s);
+  return d;
 }
 
 __global__ void magnitude_kernel(const float* ft, float* mag, int nb, int F, long total, float eps) {
@@ -552,7 +578,7 @@ void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStre
 }
 
 __global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, int Tp, const float* bn,
-                                long total) {
+                                long total, const int* fs, const int* tps) {
   const int Wp = nmel + 2;
   const float sc = bn[0], sh = bn[1];
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -560,9 +586,10 @@ __global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, i
     const long bt = idx / Wp;
     const int t = bt % Tp;
     const long b = bt / Tp;
+    const int Fb = fs ? fs[b] : F, Tb = tps ? tps[b] : Tp;
     float v = 0.f;
-    if (col > 0 && col < Wp - 1) {
-      const int src = t < F ? t : 2 * F - 2 - t;   // F.pad(mel, (0,pad), "reflect"), RMVPE.py:465
+    if (col > 0 && col < Wp - 1 && t < Tb) {
+      const int src = t < Fb ? t : 2 * Fb - 2 - t;   // F.pad(mel, (0,pad), "reflect"), RMVPE.py:465
       const float mv = mel[(b * nmel + (col - 1)) * F + src];
       v = logf(fmaxf(mv, 1e-5f)) * sc + sh;
     }
@@ -570,9 +597,9 @@ __global__ void mel_post_kernel(const float* mel, float* out, int nmel, int F, i
   }
 }
 void launch_mel_post(const float* mel, float* out, int B, int nmel, int F, int Tp, const float* bn,
-                     hipStream_t s) {
+                     hipStream_t s, const int* fs, const int* tps) {
   long tot = (long)B * Tp * (nmel + 2);
-  hipLaunchKernelGGL(mel_post_kernel, EW_GRID(tot), 0, s, mel, out, nmel, F, Tp, bn, tot);
+  hipLaunchKernelGGL(mel_post_kernel, EW_GRID(tot), 0, s, mel, out, nmel, F, Tp, bn, tot, fs, tps);
 }
 
 __global__ void log_clamp_kernel(const float* x, float* y, long n, float floor) {
@@ -756,7 +783,7 @@ std::vector<double> f0_file_track(const float* tbl, int rows) {
 }
 
 __global__ void upsample_protect_kernel(const float* feats, const float* feats0, const float* pitchf, float* out,
-                                        int Th, int p_len, float protect, int use_protect, long total) {
+                                        int Th, int p_len, float protect, int use_protect, long total, int ld_out) {
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int t = idx % p_len;
     const long c = idx / p_len;
@@ -766,14 +793,14 @@ __global__ void upsample_protect_kernel(const float* feats, const float* feats0,
       const float ff = pitchf[t] < 1.f ? protect : 1.f;
       v = v * ff + feats0[c * Th + src] * (1.f - ff);
     }
-    out[idx] = v;
+    out[c * ld_out + t] = v;
   }
 }
 void launch_upsample_protect(const float* feats, const float* feats0, const float* pitchf, float* out, int C,
-                             int Th, int p_len, float protect, int use_protect, hipStream_t s) {
+                             int Th, int p_len, float protect, int use_protect, hipStream_t s, int ld_in, int ld_out) {
   long tot = (long)C * p_len;
-  hipLaunchKernelGGL(upsample_protect_kernel, EW_GRID(tot), 0, s, feats, feats0, pitchf, out, Th, p_len, protect,
-                     use_protect, tot);
+  hipLaunchKernelGGL(upsample_protect_kernel, EW_GRID(tot), 0, s, feats, feats0, pitchf, out, ld_in > 0 ? ld_in : Th, p_len,
+                     protect, use_protect, tot, ld_out > 0 ? ld_out : p_len);
 }
 
 }  // namespace rvcx

@@ -19,9 +19,10 @@ long out_capacity(const SynthModel& m, long n, const rvcx_params& p);
 long noise_len_for(const Ctx& c, const SynthModel& m, long n, const rvcx_params& p);
 
 size_t highpass_ext_doubles(long n);   // scratch per signal the caller provides as `ext`
-// B equal-length signals (element stride xs, 0 = n); y64 / y32 are written densely (B, n)
+// B signals (element stride xs, 0 = n); y64 / y32 are written densely (B, n).  ns (device, B ints or null): item b holds
+// ns[b] <= n samples -- it is filtered as a signal of exactly that length, the rest of its output row is zero
 void launch_highpass(const float* x32, const double* x64, double* ext, double* y64, float* y32, long n,
-                     hipStream_t s, int B = 1, long xs = 0);
+                     hipStream_t s, int B = 1, long xs = 0, const int* ns = nullptr);
 
 // one utterance of a rvcx_convert_batch call.  wav / wav64 / noise / out / out_f32 may be host or device memory.
 struct UttIO {
@@ -55,8 +56,11 @@ int crepe_hop(const rvcx_params& p);
 void crepe_f0_device(Ctx& c, const float* x, long n, const rvcx_params& p, long p_len, const F0Extra* ex, float* f0raw,
                      hipStream_t s);   // VC.get_f0_crepe for one padded signal on the device          // "mangio-crepe" frame step: params.hop_length, 128 when unset
 // VC.get_f0 on device for B equal-length reflect-padded signals: coarse/f0 rows of out_stride elements
+// ns_host (optional, B ints, rmvpe only): ragged batch -- item b holds ns_host[b] <= n_pad padded samples in its row
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
                    hipStream_t s, int B = 1, long out_stride = 0, const std::function<void()>* mid = nullptr,
-                   const F0Extra* extra = nullptr);
+                   const F0Extra* extra = nullptr, const int* ns_host = nullptr);
+int bucket_frames();                                                   // class width of the ragged micro-batches (frames)
+long bucket_length(long n, const rvcx_params& p, const Geometry& g);   // length whose geometry an n-sample utterance runs with
 
 }  // namespace rvcx

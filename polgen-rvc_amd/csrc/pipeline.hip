@@ -61,9 +61,10 @@ constexpr int IIR_WARM = 3072;   // slice error vs the full recursion: 2.7e-8 at
 // scipy filtfilt(method="pad", padtype="odd"): odd extension by PADLEN samples on both sides.
 // All highpass kernels take a batch of equal-length signals: blockIdx.y = item, element strides xs / es / ys.
 __global__ void odd_ext_kernel(const float* __restrict__ x32, const double* __restrict__ x64, double* ext, long n,
-                               long xs, long es) {
-  const long m = n + 2 * PADLEN;
+                               long xs, long es, const int* __restrict__ ns) {
   const long b = blockIdx.y;
+  if (ns) n = ns[b];                       // ragged micro-batch: the item's own length (rows stay xs / es apart)
+  const long m = n + 2 * PADLEN;
   ext += b * es;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
     auto X = [&](long j) -> double { return x64 ? x64[b * xs + j] : (double)x32[b * xs + j]; };
@@ -88,9 +89,10 @@ __device__ __forceinline__ double iir_step(const IirCoef& cf, double (&z)[5], do
 
 // one lane per slice; `rev` walks the buffers backwards (filtfilt's second, time-reversed pass)
 __global__ void iir_slice_kernel(const double* __restrict__ in, double* __restrict__ out, long m, int rev,
-                                 long es, IirCoef cf) {
+                                 long es, IirCoef cf, const int* __restrict__ ns) {
   const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long s = p * IIR_CHUNK;
+  if (ns) m = ns[blockIdx.y] + 2 * PADLEN;
   if (s >= m) return;
   in += blockIdx.y * es;
   out += blockIdx.y * es;
@@ -120,11 +122,13 @@ __global__ void iir_slice_kernel(const double* __restrict__ in, double* __restri
   for (; i < e; ++i) out[rev ? m - 1 - i : i] = iir_step(cf, z, in[rev ? m - 1 - i : i]);
 }
 
-__global__ void crop_ext_kernel(const double* ext, double* y64, float* y32, long n, long es, long ys) {
+__global__ void crop_ext_kernel(const double* ext, double* y64, float* y32, long n, long es, long ys,
+                                const int* __restrict__ ns) {
   const long b = blockIdx.y;
   ext += b * es;
+  const long nb = ns ? ns[b] : n;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const double v = ext[PADLEN + i];
+    const double v = i < nb ? ext[PADLEN + i] : 0.0;    // beyond the item's length the row is zero
     if (y64) y64[b * ys + i] = v;
     if (y32) y32[b * ys + i] = (float)v;
   }
@@ -146,7 +150,7 @@ static const IirCoef& iir_coef() {
 
 // B equal-length signals (element stride xs in, n out); ext: B * highpass_ext_doubles(n) doubles of scratch
 void launch_highpass(const float* x32, const double* x64, double* ext, double* y64, float* y32, long n,
-                     hipStream_t s, int B, long xs) {
+                     hipStream_t s, int B, long xs, const int* ns) {
   RVCX_CHECK(n > PADLEN, "highpass: input shorter than filtfilt's pad length");
   const IirCoef& cf = iir_coef();
   if (xs == 0) xs = n;
@@ -155,10 +159,10 @@ void launch_highpass(const float* x32, const double* x64, double* ext, double* y
   double* tmp = ext + m;
   const unsigned g = (unsigned)std::min<long>(cdiv64(m, 256), 65535);
   const int nslices = (int)cdiv64(m, IIR_CHUNK);
-  hipLaunchKernelGGL(odd_ext_kernel, dim3(g, B), dim3(256), 0, s, x32, x64, ext, n, xs, es);
-  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, ext, tmp, m, 0, es, cf);
-  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, tmp, ext, m, 1, es, cf);
-  hipLaunchKernelGGL(crop_ext_kernel, dim3(g, B), dim3(256), 0, s, ext, y64, y32, n, es, n);
+  hipLaunchKernelGGL(odd_ext_kernel, dim3(g, B), dim3(256), 0, s, x32, x64, ext, n, xs, es, ns);
+  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, ext, tmp, m, 0, es, cf, ns);
+  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, tmp, ext, m, 1, es, cf, ns);
+  hipLaunchKernelGGL(crop_ext_kernel, dim3(g, B), dim3(256), 0, s, ext, y64, y32, n, es, n, ns);
 }
 
 size_t highpass_ext_doubles(long n) { return 2 * ((size_t)n + 2 * PADLEN) + 16; }
@@ -405,6 +409,32 @@ size_t convert_call_bytes(Ctx& c, int model_id, long n, const rvcx_params& p, bo
   return b;
 }
 
+// ---- length classes (ragged micro-batches)
+// Uncut utterances whose padded length falls into the same class of `bucket_frames()` 10 ms frames share a micro-batch:
+// every network up to the decoder is launched with the class's geometry (the longest length of the class: tiles,
+// split-K factors, key splits -- everything that shapes an fp32 summation order) and per-item length arrays carry
+// each utterance's own arithmetic (filter ends, reflect padding, frame counts, statistics, masks, recurrence
+// length).  A single utterance takes exactly the same path with B = 1, so a batch item is bit-identical to its single
+// run whatever shares the batch with it; the NSF decoder runs every utterance at its own length.
+// RVCX_BUCKET_FRAMES: class width in frames (a multiple of 32, the F0 U-Net's row granularity); 0 = equal lengths only.
+int bucket_frames() {
+  static const int v = [] {
+    const char* e = getenv("RVCX_BUCKET_FRAMES");
+    int f = e ? atoi(e) : 64;
+    if (f <= 0) return 0;
+    return std::max(32, (f + 31) / 32 * 32);
+  }();
+  return v;
+}
+
+// the sample count whose geometry an n-sample utterance is run with (>= n)
+long bucket_length(long n, const rvcx_params& p, const Geometry& g) {
+  const int cf = bucket_frames();
+  if (cf == 0 || p.f0_method != RVCX_F0_RMVPE || n + 160 > g.t_max) return n;   // cut clips keep their own geometry
+  const long k = ((n + 2 * g.t_pad) / 160) / cf;
+  return (k + 1) * cf * 160 - 1 - 2 * g.t_pad;          // the longest clip whose padded frame count is (k + 1) cf - 1
+}
+
 int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p) {
   static const int env_max = getenv("RVCX_MAX_BATCH") ? std::max(1, atoi(getenv("RVCX_MAX_BATCH"))) : 8;
   static const size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 64) << 30;
@@ -461,10 +491,12 @@ void crepe_f0_device(Ctx& c, const float* x, long n, const rvcx_params& p, long 
 }
 
 long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, int* coarse, float* f0,
-                   hipStream_t s, int B, long out_stride, const std::function<void()>* mid, const F0Extra* extra) {
+                   hipStream_t s, int B, long out_stride, const std::function<void()>* mid, const F0Extra* extra,
+                   const int* ns_host) {
   // VC.get_f0 (pipeline.py:132-201) on already reflect-padded signals (B, n_pad); coarse / f0 rows of out_stride
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
   check_f0_backend(c, p);
+  RVCX_CHECK(!ns_host || p.f0_method == RVCX_F0_RMVPE, "get_f0: ragged batches are an rmvpe feature");
   float* f0raw = c.arena.alloc<float>((size_t)B * F);
   if (p.f0_method == RVCX_F0_CREPE) {   // pipeline.py:151-152: get_f0_crepe(x, f0_min, f0_max, p_len, hop_length)
     if (mid) (*mid)();
@@ -482,10 +514,10 @@ long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, 
     fcpe_post_coarse(c, f0raw, B, (int)F, (int)p_len, f0, coarse, out_stride, p.pitch, p.f0_min, p.f0_max, s);
     return p_len;
   }
-  rmvpe_forward(c, *c.rmvpe, B, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s, nullptr, mid);
+  rmvpe_forward(c, *c.rmvpe, B, apad, n_pad, 0.03f, p.f0_min, p.f0_max, f0raw, nullptr, s, nullptr, mid, ns_host);
   for (int b = 0; b < B; ++b)
-    launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)p_len,
-                     p.pitch, p.f0_min, p.f0_max, s);
+    launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride,
+                     (int)(ns_host ? ns_host[b] / 160 : p_len), p.pitch, p.f0_min, p.f0_max, s);
   return p_len;
 }
 
@@ -515,12 +547,15 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   Arena& A = c.arena;
   StageClock clk(stage_ms != nullptr);
 
-  // ---- micro-batches: utterances sorted by length (stable), equal lengths grouped, at most `mb_max` per group
+  // ---- micro-batches: utterances sorted by length (stable); utterances of one length class (bucket_length: the same
+  // launch geometry `nd`) are grouped, at most `mb_max` per group.  `ragged`: the members differ from nd.
   std::vector<int> order(NB);
   for (int i = 0; i < NB; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ios[a].n < ios[b].n; });
   struct MB {
     int first, count;
+    long nd;        // the length whose geometry every launch of the micro-batch takes (>= every member's length)
+    bool ragged;
   };
   std::vector<MB> mbs;
   long n_max = 0;
@@ -528,12 +563,19 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   for (int i = 0; i < NB;) {
     const long n = ios[order[i]].n;
     RVCX_CHECK(n > g.t_pad, "convert: clip shorter than the reflect padding");
-    const int cap = convert_micro_batch(c, model_id, n, p);
+    const long nd = bucket_length(n, p, g);
+    const int cap = convert_micro_batch(c, model_id, nd, p);
     int j = i;
-    while (j < NB && ios[order[j]].n == n && j - i < cap) ++j;
-    mbs.push_back({i, j - i});
+    bool ragged = false;
+    while (j < NB && bucket_length(ios[order[j]].n, p, g) == nd && j - i < cap) {
+      ragged |= ios[order[j]].n != nd;
+      ++j;
+    }
+    mbs.push_back({i, j - i, nd, ragged});
     i = j;
   }
+  c.last_mbs.clear();
+  for (const auto& mb : mbs) c.last_mbs.push_back(mb.count);
   size_t call_bytes = 0, mb_bytes = 0, f0_bytes = 0, hub_bytes = 0;
   for (const auto& u : ios) {
     any_f64 |= u.wav64 != nullptr;
@@ -544,7 +586,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     if (u.inp_f0) call_bytes += (size_t)65536 * sizeof(double) + 256;      // delta_t is an int16
   }
   for (const auto& mb : mbs) {
-    const long n = ios[order[mb.first]].n;
+    const long n = mb.nd;
     mb_bytes = std::max(mb_bytes, (size_t)mb.count * convert_item_bytes(c, model_id, n, p));
     f0_bytes = std::max(f0_bytes, f0_arena_bytes(c, p, mb.count, n + 2 * g.t_pad));
     const long n_pad = n + 2 * g.t_pad;
@@ -601,13 +643,14 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     long* cuts = nullptr;
     float* feats = nullptr;     // HuBERT features of every chunk of the micro-batch, group after group
     size_t feats_cap = 0;
+    int* ns = nullptr;          // device: the members' sample counts (ragged micro-batches)
   } fr[2];
   size_t front_items = 0;
   for (const auto& mb : mbs) front_items = std::max(front_items, (size_t)mb.count);
   {
     size_t wmax = 0, emax = 0, nmax = 0, pmax = 0, fmax = 0, cmax = 0, hmax = 0;
     for (const auto& mb : mbs) {
-      const long n = ios[order[mb.first]].n;
+      const long n = mb.nd;
       const size_t k = (size_t)mb.count;
       wmax = std::max(wmax, k * (size_t)n * 8);
       emax = std::max(emax, k * highpass_ext_doubles(n));
@@ -629,6 +672,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       f.cuts = A.alloc<long>(cmax);
       f.feats = A.alloc<float>(hmax);
       f.feats_cap = hmax;
+      f.ns = A.alloc<int>(front_items);
     }
   }
   // resample_sr (pipeline.py:453-454): librosa.resample(audio_opt, orig_sr=tgt_sr, target_sr=resample_sr) ahead of the peak
@@ -654,7 +698,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   auto front = [&](int k) {
     const MB& mb = mbs[k];
     Front& f = fr[k & 1];
-    const long n = ios[order[mb.first]].n, n_pad = n + 2 * g.t_pad;
+    const long n = mb.nd, n_pad = n + 2 * g.t_pad;      // the micro-batch's geometry; a member holds ios[].n <= n samples
     const int Bm = mb.count;
     if (sf != s && k >= 2) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_done[k & 1], 0));   // set k&1 was micro-batch k-2's
     if (sf != s && k >= 1 && front_delay) RVCX_HIP(hipStreamWaitEvent(sf, c.ev_syn[(k - 1) & 1], 0));
@@ -663,15 +707,23 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     for (int b = 0; b < Bm; ++b) {
       const UttIO& io = ios[order[mb.first + b]];
       RVCX_CHECK((io.wav64 != nullptr) == f64, "convert: float32 and float64 inputs mixed in one call");
-      if (f64) RVCX_HIP(hipMemcpyAsync(static_cast<double*>(f.wav) + (size_t)b * n, io.wav64, (size_t)n * 8, hipMemcpyDefault, sf));
-      else RVCX_HIP(hipMemcpyAsync(static_cast<float*>(f.wav) + (size_t)b * n, io.wav, (size_t)n * 4, hipMemcpyDefault, sf));
+      if (f64) RVCX_HIP(hipMemcpyAsync(static_cast<double*>(f.wav) + (size_t)b * n, io.wav64, (size_t)io.n * 8, hipMemcpyDefault, sf));
+      else RVCX_HIP(hipMemcpyAsync(static_cast<float*>(f.wav) + (size_t)b * n, io.wav, (size_t)io.n * 4, hipMemcpyDefault, sf));
       Utt& u = utts[order[mb.first + b]];
       if (io.noise) RVCX_HIP(hipMemcpyAsync(const_cast<float*>(u.noise), io.noise, (size_t)u.noise_cap * 4, hipMemcpyDefault, sf));
     }
+    const int* d_ns = nullptr;
+    if (mb.ragged) {
+      std::vector<int> nsv(Bm);
+      for (int b = 0; b < Bm; ++b) nsv[b] = (int)ios[order[mb.first + b]].n;
+      set_dev_ints(f.ns, nsv.data(), Bm, sf);
+      d_ns = f.ns;
+    }
     launch_highpass(f64 ? nullptr : static_cast<const float*>(f.wav), f64 ? static_cast<const double*>(f.wav) : nullptr,
-                    f.ext, f.a64, f.a32, n, sf, Bm, n);
+                    f.ext, f.a64, f.a32, n, sf, Bm, n, d_ns);
     // chunk cut points (pipeline.py:330-344): only clips longer than t_max are cut
-    const long ncut = cut_count(n, g);
+    const long ncut = cut_count(ios[order[mb.first]].n, g);     // cut clips are never ragged: n is their own length
+    RVCX_CHECK(ncut == 0 || !mb.ragged, "internal: a cut clip in a ragged micro-batch");
     std::vector<long> cuts((size_t)Bm * ncut);
     if (ncut > 0) {
       for (int b = 0; b < Bm; ++b) {
@@ -687,7 +739,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       }
       RVCX_HIP(hipMemcpyAsync(cuts.data(), f.cuts, cuts.size() * sizeof(long), hipMemcpyDeviceToHost, sf));
     }
-    launch_reflect_pad(f.a32, f.apad, Bm, (int)n, (int)g.t_pad, n_pad, sf);
+    launch_reflect_pad(f.a32, f.apad, Bm, (int)n, (int)g.t_pad, n_pad, sf, d_ns);   // zeros behind a shorter member
     if (sf != s) RVCX_HIP(hipEventRecord(c.ev_front[k & 1], sf));
     spans.push_back({h0, clk.mark(sf), &t_hp});
     if (ncut > 0) RVCX_HIP(hipStreamSynchronize(sf));
@@ -699,7 +751,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       u.coarse = f.coarse + (size_t)b * stride;
       u.f0 = f.f0 + (size_t)b * stride;
       std::vector<long> opt(cuts.begin() + (size_t)b * ncut, cuts.begin() + (size_t)(b + 1) * ncut);
-      u.plan = plan_chunks(n, opt, g);
+      u.plan = plan_chunks(u.n, opt, g);
     }
   };
 
@@ -708,7 +760,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   auto enqueue_f0 = [&](int k, const std::function<void()>* mid) {
     const MB& mb = mbs[k];
     Front& f = fr[k & 1];
-    const long n_pad = ios[order[mb.first]].n + 2 * g.t_pad;
+    const long n_pad = mb.nd + 2 * g.t_pad;
     f0_ev0[k] = clk.mark(sf);
     c.arena_f0.reset();
     c.arena.swap(c.arena_f0);
@@ -720,7 +772,10 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         fx[b].dither_n = io.crepe_dither_n;
         fx[b].seed_offset = io.seed_offset;
       }
-      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8, mid, fx.data());
+      std::vector<int> nsp(mb.count);
+      for (int b = 0; b < mb.count; ++b) nsp[b] = (int)utts[order[mb.first + b]].n_pad;
+      get_f0_device(c, f.apad, n_pad, p, f.coarse, f.f0, sf, mb.count, n_pad / 160 + 8, mid, fx.data(),
+                    mb.ragged ? nsp.data() : nullptr);
     } catch (...) {
       c.arena.swap(c.arena_f0);
       throw;
@@ -731,7 +786,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       const long stride = n_pad / 160 + 8;
       if (u.rep)
         launch_f0_override(u.rep, u.rep_n, (int)(g.t_pad / 160), f.f0 + (size_t)b * stride, f.coarse + (size_t)b * stride,
-                           (int)(n_pad / 160), p.f0_min, p.f0_max, sf);
+                           (int)(u.n_pad / 160), p.f0_min, p.f0_max, sf);
     }
     f0_ev1[k] = clk.mark(sf);
     if (sf != s) RVCX_HIP(hipEventRecord(c.ev_join, sf));
@@ -747,9 +802,15 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
 
   // ---- chunk jobs of a micro-batch, grouped by chunk length (order of first appearance); group gi's HuBERT
   // features live at fr[k & 1].feats + feats_off[gi]
+  struct Grp {
+    std::vector<int> jobs;
+    long ns = 0;        // launch geometry of the group: chunk samples, HuBERT frames, synthesizer frames ...
+    int Th = 0, T = 0;
+    bool ragged = false;   // ... which a member's own (Job::e - s, Th, T) may fall short of
+  };
   struct Plan {
     std::vector<Job> jobs;
-    std::vector<std::vector<int>> groups;
+    std::vector<Grp> groups;
     std::vector<size_t> feats_off;
   } plans[2];
   auto plan_jobs = [&](int k) {
@@ -778,17 +839,34 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       RVCX_CHECK(!u.noise || noise_off <= u.noise_cap, "convert: parity noise buffer shorter than the chunk plan needs");
       u.out_n = out_off;
     }
-    for (int j = 0; j < (int)P.jobs.size(); ++j) {
-      size_t gi = 0;
-      for (; gi < P.groups.size(); ++gi)
-        if (P.jobs[P.groups[gi][0]].e - P.jobs[P.groups[gi][0]].s == P.jobs[j].e - P.jobs[j].s) break;
-      if (gi == P.groups.size()) P.groups.emplace_back();
-      P.groups[gi].push_back(j);
+    if (mb.ragged) {
+      // one job per member (uncut clips), one group with the class's geometry
+      Grp G;
+      G.ns = mb.nd + 2 * g.t_pad;
+      G.Th = hubert_frames(*c.hubert, G.ns);
+      G.T = (int)std::min<long>(G.ns / 160, 2L * G.Th);
+      G.ragged = true;
+      RVCX_CHECK((int)P.jobs.size() == mb.count, "internal: a ragged micro-batch holds uncut clips only");
+      for (int j = 0; j < (int)P.jobs.size(); ++j) G.jobs.push_back(j);
+      P.groups.push_back(std::move(G));
+    } else {
+      for (int j = 0; j < (int)P.jobs.size(); ++j) {
+        size_t gi = 0;
+        for (; gi < P.groups.size(); ++gi)
+          if (P.groups[gi].ns == P.jobs[j].e - P.jobs[j].s) break;
+        if (gi == P.groups.size()) {
+          P.groups.emplace_back();
+          P.groups[gi].ns = P.jobs[j].e - P.jobs[j].s;
+          P.groups[gi].Th = P.jobs[j].Th;
+          P.groups[gi].T = P.jobs[j].T;
+        }
+        P.groups[gi].jobs.push_back(j);
+      }
     }
     size_t off = 0;
     for (const auto& grp : P.groups) {
       P.feats_off.push_back(off);
-      off += (size_t)grp.size() * E * P.jobs[grp[0]].Th;
+      off += (size_t)grp.jobs.size() * E * grp.Th;
     }
     RVCX_CHECK(off <= fr[k & 1].feats_cap, "internal: HuBERT feature buffer smaller than the chunk plan");
   };
@@ -804,10 +882,12 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     hub_ev0[k] = clk.mark(sh);
     c.arena_hub.reset();
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
-      const auto& grp = P.groups[gi];
+      const auto& grp = P.groups[gi].jobs;
       const int G = (int)grp.size();
       const Job& j0 = P.jobs[grp[0]];
-      const long ns = j0.e - j0.s;
+      const long ns = P.groups[gi].ns;
+      std::vector<int> nsv(G);
+      for (int q = 0; q < G; ++q) nsv[q] = (int)(P.jobs[grp[q]].e - P.jobs[grp[q]].s);
       c.arena.swap(c.arena_hub);       // allocations below come from HuBERT's arena (stream-ordered on `sh`)
       try {
         const size_t mk = c.arena.mark();
@@ -816,7 +896,9 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         long wav_bs = ns;
         bool uniform = true;
         for (int q = 1; q < G; ++q) uniform &= P.jobs[grp[q]].s == j0.s && P.jobs[grp[q]].u == j0.u + q;
-        if (G > 1 && uniform) {
+        if (P.groups[gi].ragged) {
+          wav_bs = mb.nd + 2 * g.t_pad;      // the members' rows of the front set's apad (zeros behind each member)
+        } else if (G > 1 && uniform) {
           wav_bs = utts[order[mb.first + j0.u]].n_pad;
         } else if (G > 1) {
           float* wg = c.arena.alloc<float>((size_t)G * ns);
@@ -825,7 +907,8 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
                                     (size_t)ns * 4, hipMemcpyDeviceToDevice, sh));
           wav = wg;
         }
-        hubert_forward(c, *c.hubert, G, wav, ns, 12, f.feats + P.feats_off[gi], sh, nullptr, wav_bs);
+        hubert_forward(c, *c.hubert, G, wav, ns, 12, f.feats + P.feats_off[gi], sh, nullptr, wav_bs,
+                       P.groups[gi].ragged ? nsv.data() : nullptr);
         c.arena.reset(mk);
       } catch (...) {
         c.arena.swap(c.arena_hub);
@@ -874,11 +957,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     spans.push_back({w0, w1, &t_wait_hub});
     bool joined = false;
     for (size_t gi = 0; gi < P.groups.size(); ++gi) {
-      const auto& grp = P.groups[gi];
+      const auto& grp = P.groups[gi].jobs;
+      const bool ragged = P.groups[gi].ragged;
       const size_t mk = A.mark();
       const int G = (int)grp.size();
-      const Job& j0 = jobs[grp[0]];
-      const int Th = j0.Th, T = j0.T;
+      const int Th = P.groups[gi].Th, T = P.groups[gi].T;      // the group's geometry; a member's own: Job::Th, Job::T
       const size_t nz = (size_t)inter * T, nsrc = (size_t)T * M.upp;
       const int h1 = clk.mark(s);
       float* feats = fr[k & 1].feats + P.feats_off[gi];
@@ -891,7 +974,16 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         }
         for (int q = 0; q < G; ++q) {
           const size_t mk2 = A.mark();
-          index_blend(c, *c.index, feats + (size_t)q * E * Th, Th, p.index_rate, nullptr, nullptr, s);
+          const int Thq = jobs[grp[q]].Th;
+          float* fq = feats + (size_t)q * E * Th;
+          if (Thq == Th) {
+            index_blend(c, *c.index, fq, Th, p.index_rate, nullptr, nullptr, s);
+          } else {       // a shorter member of a ragged group: searched as the (E, Thq) matrix of its single run
+            float* cq = A.alloc<float>((size_t)E * Thq);
+            RVCX_HIP(hipMemcpy2DAsync(cq, (size_t)Thq * 4, fq, (size_t)Th * 4, (size_t)Thq * 4, E, hipMemcpyDeviceToDevice, s));
+            index_blend(c, *c.index, cq, Thq, p.index_rate, nullptr, nullptr, s);
+            RVCX_HIP(hipMemcpy2DAsync(fq, (size_t)Th * 4, cq, (size_t)Thq * 4, (size_t)Thq * 4, E, hipMemcpyDeviceToDevice, s));
+          }
           A.reset(mk2);
         }
       }
@@ -909,19 +1001,28 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       float* pitchf = A.alloc<float>((size_t)G * T);
       float* zn = A.alloc<float>((size_t)G * nz);
       float* sn = A.alloc<float>((size_t)G * nsrc);
-      std::vector<int> sids(G, p.sid);
+      std::vector<int> sids(G, p.sid), lens_q(G);
+      if (ragged) {      // frames behind a shorter member: zero phone / pitch rows (masked in the networks anyway)
+        RVCX_HIP(hipMemsetAsync(phone, 0, (size_t)G * E * T * sizeof(float), s));
+        RVCX_HIP(hipMemsetAsync(pitch, 0, (size_t)G * T * sizeof(int), s));
+        RVCX_HIP(hipMemsetAsync(pitchf, 0, (size_t)G * T * sizeof(float), s));
+      }
       for (int q = 0; q < G; ++q) {
         const Job& j = jobs[grp[q]];
         const Utt& u = utts[order[mb.first + j.u]];
+        const int Tq = j.T;
+        lens_q[q] = Tq;
         launch_upsample_protect(feats + (size_t)q * E * Th, feats0 + (size_t)q * E * Th, u.f0 + j.f0_off,
-                                phone + (size_t)q * E * T, E, Th, T, p.protect, use_protect ? 1 : 0, s);
-        RVCX_HIP(hipMemcpyAsync(pitch + (size_t)q * T, u.coarse + j.f0_off, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
-        RVCX_HIP(hipMemcpyAsync(pitchf + (size_t)q * T, u.f0 + j.f0_off, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
-        // noise: parity = packed [z (inter*T) | src (T*upp)] per chunk in draw order; else Philox with the
-        // utterance's own stream (seed + position in the call) so that a batch item equals its single run
+                                phone + (size_t)q * E * T, E, j.Th, Tq, p.protect, use_protect ? 1 : 0, s, Th, T);
+        RVCX_HIP(hipMemcpyAsync(pitch + (size_t)q * T, u.coarse + j.f0_off, (size_t)Tq * 4, hipMemcpyDeviceToDevice, s));
+        RVCX_HIP(hipMemcpyAsync(pitchf + (size_t)q * T, u.f0 + j.f0_off, (size_t)Tq * 4, hipMemcpyDeviceToDevice, s));
+        // noise: parity = packed [z (inter*T) | src (T*upp)] per chunk in draw order (the member's own T); else Philox
+        // with the utterance's own stream (seed + position in the call) so that a batch item equals its single run
         if (u.noise) {
-          RVCX_HIP(hipMemcpyAsync(zn + (size_t)q * nz, u.noise + j.noise_off, nz * 4, hipMemcpyDeviceToDevice, s));
-          RVCX_HIP(hipMemcpyAsync(sn + (size_t)q * nsrc, u.noise + j.noise_off + nz, nsrc * 4, hipMemcpyDeviceToDevice, s));
+          const size_t nzq = (size_t)inter * Tq, nsq = (size_t)Tq * M.upp;
+          RVCX_HIP(hipMemcpy2DAsync(zn + (size_t)q * nz, (size_t)T * 4, u.noise + j.noise_off, (size_t)Tq * 4, (size_t)Tq * 4,
+                                    inter, hipMemcpyDeviceToDevice, s));
+          RVCX_HIP(hipMemcpyAsync(sn + (size_t)q * nsrc, u.noise + j.noise_off + nzq, nsq * 4, hipMemcpyDeviceToDevice, s));
         } else {
           const uint64_t seed = p.seed + (uint64_t)ios[u.io].seed_offset;
           const uint64_t off = (uint64_t)j.ci << 36;
@@ -935,6 +1036,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       if (gi == 0 && sf != s && front_delay == 2) io.ev_decoder = c.ev_syn[k & 1];
       io.B = G;
       io.T = T;
+      io.lens_host = ragged ? lens_q.data() : nullptr;
       io.phone_ct = phone;
       io.pitch = pitch;
       io.pitchf = pitchf;
@@ -949,10 +1051,10 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       ht("pre-synth", k);
       synth_forward(c, M, io, stage_ms ? syn_ev.back().data() : nullptr);
       ht("synth", k);
-      const long keep_n = (long)nsrc - 2 * g.t_pad_tgt;
       for (int q = 0; q < G; ++q) {
         const Job& j = jobs[grp[q]];
         const Utt& u = utts[order[mb.first + j.u]];
+        const long keep_n = (long)j.T * M.upp - 2 * g.t_pad_tgt;
         if (keep_n > 0)
           RVCX_HIP(hipMemcpyAsync(u.outf + j.out_off, wavout + (size_t)q * nsrc + g.t_pad_tgt,
                                   (size_t)keep_n * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -209,15 +209,19 @@ struct Map2 {
 };
 
 // ConvBlockRes (RMVPE.py:140-175): relu(bn(conv2(relu(bn(conv1(x)))))) + shortcut(x)
+// lens (device, B ints or null): valid flat positions (rows * Wp) per item on this level -- reads beyond see zeros, stores
+// beyond are zeros: the zero padding a shorter item's single run sees below its last row
 void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y, float* tmp1, float* tmp2, int B,
-               hipStream_t s) {
+               hipStream_t s, const int* lens) {
   const int H = x.H, Wp = x.Wp;
   ConvArgs a = conv2d_args(b.c1, x.p, tmp1, B, H, Wp);
   a.x_bs = x.bs;
   a.act = ACT_RELU;
+  a.lens_in = a.lens_out = lens;
   // conv1 -> conv2 hand-off in split fp16 form on the large (shallow) levels; the deep levels keep fp32 because
   // their launches rely on split-K, which the split store does not go through
   ConvArgs a2 = conv2d_args(b.c2, tmp1, y.p, B, H, Wp);
+  a2.lens_in = a2.lens_out = lens;
   const bool split = (long)H * Wp >= 20000 && conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
   if (split) {
     a.y_split = tmp1;
@@ -229,6 +233,7 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
   if (b.has_sc) {
     a = conv2d_args(b.sc, x.p, tmp2, B, H, Wp);
     a.x_bs = x.bs;
+    a.lens_in = a.lens_out = lens;
     c.conv_on(a, s);
     res = tmp2;
     res_bs = (long)b.cout * H * Wp;
@@ -246,17 +251,42 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
 
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
                    float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out,
-                   const std::function<void()>* after_shallow) {
+                   const std::function<void()>* after_shallow, const int* ns_host) {
   Arena& A = c.arena;
   const int F = (int)(1 + n / HOP), Tp = padded_frames(F);
   const int nenc = m.cfg.en_de_layers;
   RVCX_CHECK(Tp % (1 << nenc) == 0, "rmvpe: clip too short for the U-Net depth");
   const int nb = N_FFT / 2 + 1;
+  // ---- ragged batch: item b holds ns_host[b] <= n samples.  The launch geometry is that of n for every item; the
+  // arithmetic of item b is that of a clip of ns_host[b] samples (its own frame count, reflect padding, zero rows
+  // below its last U-Net row, recurrence length) -- per-item length arrays do the rest.
+  bool ragged = false;
+  std::vector<int> Fb(B, F), Tb(B, Tp);
+  if (ns_host)
+    for (int b = 0; b < B; ++b) {
+      RVCX_CHECK(ns_host[b] > N_FFT / 2 && ns_host[b] <= n, "rmvpe: item length outside (512, n]");
+      Fb[b] = 1 + ns_host[b] / HOP;
+      Tb[b] = padded_frames(Fb[b]);
+      RVCX_CHECK(Tb[b] <= Tp && Tb[b] % (1 << nenc) == 0, "rmvpe: item frames exceed the batch geometry");
+      ragged |= ns_host[b] != n;
+    }
+  const int *d_ns = nullptr, *d_F = nullptr, *d_T = nullptr;
+  std::vector<const int*> d_lv(nenc + 1, nullptr);     // valid flat positions per U-Net level
+  if (ragged) {
+    d_ns = dev_ints(A, ns_host, B, s);
+    d_F = dev_ints(A, Fb, s);
+    d_T = dev_ints(A, Tb, s);
+    for (int l = 0; l <= nenc; ++l) {
+      std::vector<int> v(B);
+      for (int b = 0; b < B; ++b) v[b] = (Tb[b] >> l) * ((N_MELS >> l) + 2);
+      d_lv[l] = dev_ints(A, v, s);
+    }
+  }
   // ---- mel
   const int Mh = cdiv((int)n + N_FFT, HOP);     // hops covering the reflect-padded signal
   float* apad = A.alloc<float>((size_t)B * Mh * HOP);
   RVCX_HIP(hipMemsetAsync(apad, 0, (size_t)B * Mh * HOP * sizeof(float), s));
-  launch_reflect_pad(audio, apad, B, (int)n, N_FFT / 2, (long)Mh * HOP, s);
+  launch_reflect_pad(audio, apad, B, (int)n, N_FFT / 2, (long)Mh * HOP, s, d_ns);
   float* x2 = A.alloc<float>((size_t)B * Mh * HOP);
   launch_transpose(apad, x2, B, Mh, HOP, s);    // (B, Mh, 160) -> (B, 160, Mh)
   float* ft = A.alloc<float>((size_t)B * 2 * nb * F);
@@ -294,7 +324,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   float* w3 = A.alloc<float>(big);
   Map2 x{w0, (long)Hs[0] * Ws[0], 1, Hs[0], Ws[0]};
   if (mel_out) launch_log_clamp(mel, mel_out, (long)B * N_MELS * F, 1e-5f, s);   // log(clamp(mel, 1e-5)), RMVPE.py:438
-  launch_mel_post(mel, x.p, B, N_MELS, F, Tp, m.bn0, s);
+  launch_mel_post(mel, x.p, B, N_MELS, F, Tp, m.bn0, s, d_F, d_T);
   for (int l = 0; l < nenc; ++l) {
     const int nblk = (int)m.enc[l].size();
     for (int b = 0; b < nblk; ++b) {
@@ -309,7 +339,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
         y.p = (x.p == w0) ? w3 : w0;
         y.bs = (long)Cs[l] * Hs[l] * Ws[l];
       }
-      run_block(c, m.enc[l][b], x, y, w1, w2, B, s);
+      run_block(c, m.enc[l][b], x, y, w1, w2, B, s, d_lv[l]);
       x = y;
     }
     // 2x2 average pool (RMVPE.py:195)
@@ -327,7 +357,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   for (const auto& layer : m.inter)
     for (const auto& blk : layer) {
       Map2 y{(x.p == w0) ? w3 : w0, (long)blk.cout * Hs[nenc] * Ws[nenc], blk.cout, Hs[nenc], Ws[nenc]};
-      run_block(c, blk, x, y, w1, w2, B, s);
+      run_block(c, blk, x, y, w1, w2, B, s, d_lv[nenc]);
       x = y;
     }
   for (int l = 0; l < nenc; ++l) {
@@ -337,11 +367,13 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
     a.x_bs = x.bs;
     a.y_bs = cat[lv].bs;
     a.act = ACT_RELU;
+    a.lens_in = d_lv[lv + 1];        // the polyphase conv runs on the low-resolution grid: an item's rows there
+    a.lens_out = d_lv[lv + 1];
     c.conv_on(a, s);
     x = cat[lv];
     for (const auto& blk : D.blocks) {
       Map2 y{(x.p == w0) ? w3 : w0, (long)blk.cout * Hs[lv] * Ws[lv], blk.cout, Hs[lv], Ws[lv]};
-      run_block(c, blk, x, y, w1, w2, B, s);
+      run_block(c, blk, x, y, w1, w2, B, s, d_lv[lv]);
       x = y;
     }
   }
@@ -350,6 +382,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   {
     ConvArgs a = conv2d_args(m.cnn, x.p, cnn, B, Hs[0], Ws[0]);
     a.x_bs = x.bs;
+    a.lens_in = a.lens_out = d_lv[0];
     c.conv_on(a, s);
   }
   const int I = 3 * N_MELS, H = 256;
@@ -365,10 +398,11 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   }
   float* gy = A.alloc<float>((size_t)B * 2 * H * Tp);
   void* gscr = A.alloc<unsigned long long>(bigru_scratch_bytes(B) / 8);
-  launch_bigru(gi, m.whh_t, m.bhh, gy, B, Tp, H, gscr, c.dev_err, s);
+  launch_bigru(gi, m.whh_t, m.bhh, gy, B, Tp, H, gscr, c.dev_err, s, d_T);
   float* sal = A.alloc<float>((size_t)B * Tp * 360);
   {
     ConvArgs a = conv1d_args(m.fc, gy, sal, B, Tp, Tp);
+    a.lens_in = d_T;                 // the recurrence left frames beyond an item's length unwritten
     a.act = ACT_SIGMOID;
     a.out_mode = OUT_TRANSPOSED;
     a.y_bs = (long)Tp * 360;
@@ -378,10 +412,10 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   // hidden[:, :F] -> decode
   if (hidden) launch_copy_strided(sal, hidden, B, (long)F * 360, (long)Tp * 360, (long)F * 360, s);
   if (B == 1) {
-    launch_decode_f0(sal, f0, 1, F, 360, thred, f0_min, f0_max, s);
+    launch_decode_f0(sal, f0, 1, Fb[0], 360, thred, f0_min, f0_max, s);
   } else {
     for (int b = 0; b < B; ++b)
-      launch_decode_f0(sal + (size_t)b * Tp * 360, f0 + (size_t)b * F, 1, F, 360, thred, f0_min, f0_max, s);
+      launch_decode_f0(sal + (size_t)b * Tp * 360, f0 + (size_t)b * F, 1, Fb[b], 360, thred, f0_min, f0_max, s);
   }
   RVCX_HIP(hipGetLastError());
 }

@@ -341,20 +341,27 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   for (int b0 = 0; b0 < B; b0 += dec_batch) {
     const int db = std::min(dec_batch, B - b0);
     A.reset(dec_mark);
-    float* cur = A.alloc<float>((size_t)db * C0 * T);
+    // One utterance at a time runs at ITS OWN length Td (rows of the batched tensors stay T apart): no masks, no work on
+    // padding, and every launch decision (tile, split-K) is the one the utterance's single run takes.
+    const bool own = db == 1 && io.lens_host != nullptr;
+    const int Td = own ? io.lens_host[b0] : T;
+    RVCX_CHECK(Td > 0 && Td <= T, "synth: item length outside (0, T]");
+    float* cur = A.alloc<float>((size_t)db * C0 * Td);
     {
-      ConvArgs a = conv1d_args(m.conv_pre, z + (size_t)b0 * inter * T, cur, db, T, T, 1, 1, 3);
-      a.lens_in = lens ? lens + b0 : nullptr;
+      ConvArgs a = conv1d_args(m.conv_pre, z + (size_t)b0 * inter * T, cur, db, Td, Td, 1, 1, 3);
+      a.x_bs = (long)inter * T;
+      a.x_cs = T;
+      a.lens_in = (lens && !own) ? lens + b0 : nullptr;
       c.conv(a);
       float* gcond = A.alloc<float>((size_t)db * C0);
       a = conv1d_args(m.cond, g + (size_t)b0 * gin, gcond, db, 1, 1);
       c.conv(a);
-      launch_add_channel_bias(cur, gcond, db, C0, T, s);
+      launch_add_channel_bias(cur, gcond, db, C0, Td, s);
     }
-    long Tin = T;
+    long Tin = Td, Tin_c = T;
     for (size_t i = 0; i < m.stages.size(); ++i) {
       const auto& S = m.stages[i];
-      const long Tout = Tin * cf.up_rates[i];
+      const long Tout = Tin * cf.up_rates[i], Tout_c = Tin_c * cf.up_rates[i];
       const size_t n = (size_t)db * S.ch * Tout;
       float* xs = A.alloc<float>(n);      // survives the stage (next stage's input)
       const size_t stage_mark = A.mark();
@@ -366,14 +373,14 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
         xcb[j] = A.alloc<float>(n);
         xtb[j] = A.alloc<float>(n);
       }
-      const int* lin = lens_stage[i] ? lens_stage[i] + b0 : nullptr;
-      const int* lout = lens_stage[i + 1] ? lens_stage[i + 1] + b0 : nullptr;
+      const int* lin = (lens_stage[i] && !own) ? lens_stage[i] + b0 : nullptr;
+      const int* lout = (lens_stage[i + 1] && !own) ? lens_stage[i + 1] + b0 : nullptr;
       ConvArgs a = convT1d_args(S.up, cur, xu, db, (int)Tin, (int)Tout);
       a.pre_act = ACT_LRELU;
       a.pre_slope = 0.1f;
       a.lens_in = lin;
       a.lens_out = lout;
-      conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout, S.ch, (int)Tout);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
+      conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout_c, S.ch, (int)Tout_c);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
       c.conv(a);
       // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
       // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases
@@ -468,6 +475,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       if (rs[nk - 1] != s) RVCX_HIP(hipStreamWaitEvent(s, c.ev_aux[nk], 0));   // join before the next stage
       cur = xs;
       Tin = Tout;
+      Tin_c = Tout_c;
       A.reset(stage_mark);
     }
     {
@@ -476,9 +484,11 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       a.pre_act = ACT_LRELU;
       a.pre_slope = 0.01f;
       a.act = ACT_TANH;
-      a.lens_in = lens_stage[m.stages.size()] ? lens_stage[m.stages.size()] + b0 : nullptr;
+      a.lens_in = (lens_stage[m.stages.size()] && !own) ? lens_stage[m.stages.size()] + b0 : nullptr;
       a.lens_out = a.lens_in;
       c.conv(a);
+      if (own && Td < T)               // the rest of the item's output row reads as silence
+        RVCX_HIP(hipMemsetAsync(io.out + (size_t)b0 * Tupp + (size_t)Td * m.upp, 0, (size_t)(T - Td) * m.upp * sizeof(float), s));
     }
   }
   tm.mark(3);
