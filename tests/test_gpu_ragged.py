@@ -56,7 +56,7 @@ def test_ragged_micro_batch_equals_single_runs(ctx):
     float waveform equal, bit for bit, what the clip gives alone (Philox noise, protect, RMS envelope)."""
     mid = _load(ctx, 3)
     p = _params(volume_envelope=0.25)
-    lens = [27200, 27360, 27999, 30001, 33333, 36000, 36160, 40800, 41000]
+    lens = [27200, 27360, 27999, 30001, 33333, 36160, 40800, 41000, 50000]
     clips = [_clip(100 + i, n) for i, n in enumerate(lens)]
     classes = {}
     for n in lens:
