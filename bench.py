@@ -13,10 +13,11 @@ model, rmvpe+ F0, contentvec-shaped HuBERT-base, index_rate 0, fp32, chunk geome
 synthetic clip + synthetic weights in the real checkpoint layouts (no real weights exist offline).
 Workload c3 (--workload c3, BASELINE.json configs[2]): a batch of 64 x 30 s clips per step, index_rate 0.75 with
 a 65 536 x 768 retrieval matrix resident in HBM.  The default (c2, N = 1) run also carries a "c3" object measured by
-a child process of the same run, like "exact_fp32".
+a child process of the same run, like "exact_fp32".  With --gpus 8 this is BASELINE.json configs[3] (C4: 512 clips, 64 per rank).
 Workload c5 (--workload c5, BASELINE.json configs[4]): 256 utterances of U(3, 15) s per step for the whole job, a
 40 k and a 48 k voice model resident beside one HuBERT and one RMVPE; the utterances are sharded over the ranks by
-length (dist.shard), odd ones go to the 48 k model, even ones to the 40 k model.
+length (dist.shard), odd ones go to the 48 k model, even ones to the 40 k model; mixed lengths are converted as ragged
+micro-batches (length classes).  The default run carries a "c5" object too (child process).
 A step = VC.pipeline on the step's clip(s) as SURVEY.md 8(d) defines the metric: H2D of the float PCM (pinned
 host memory), every kernel, D2H of the int16 PCM -- all inside the timed region.
 Weak scaling (c2 / c3): every rank converts its own clip(s) per step; value = all ranks' audio seconds / max-rank wall
@@ -48,13 +49,21 @@ CLIP_SECONDS = 30.0
 C3_BATCH = 64
 C3_INDEX_ROWS = 65536
 C5_UTTERANCES = 256
-CPU_SAMPLE_SECONDS = 8.0
-PMC_FILES = ("pmc_traffic_r03.json", "pmc_traffic_r02.json")     # newest first
+CPU_SAMPLE_SECONDS = 30.0    # the clip the metric is quoted on (attention is O(T^2): a shorter sample would flatter the CPU)
+PMC_FILES = ("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json")     # newest first
+WORKER_DEADLINE_S = 3600.0   # launch_workers: the whole multi-rank run
+PEAK_FILE = "mfma_peak_r04.json"   # profiles/: measured split-fp16 ceiling on random operands (tools/mfma_peak.hip)
 
 
 def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False):
+    """zero: this rank receives rank 0's folded weights by broadcast -- it loads shape-only placeholders (zeros, no
+    random numbers drawn: the region layout depends on shapes only)."""
+    if zero:
+        with S.shapes_only():
+            return load_models(ctx, False, fcpe, also_40k, crepe)
+
     def z(state):
-        return {k: np.zeros_like(v) for k, v in state.items()} if zero else state
+        return state
     ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0)))
     if crepe:
         ctx.load_crepe(z(S.crepe_state("full", 0)))
@@ -68,6 +77,11 @@ def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False):
         return mid48
     mid40 = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_40K, 768), z(S.synth_state(S.SYNTH_CFG_40K, 1)))
     return mid48, mid40
+
+
+def ctx_bucket_frames():
+    v = os.environ.get("RVCX_BUCKET_FRAMES")
+    return int(v) if v else 128
 
 
 def make_params(seed=0, fcpe=False, crepe=False):
@@ -158,11 +172,13 @@ def pmc_traffic(tile_name):
     return None, None
 
 
-def child_bench(extra_args, env_extra, label):
+def child_bench(extra_args, env_extra, label, roofline=True):
     """One more bench of this run in a FRESH child process, started before this process touches the GPU and run to
     completion (never an exec of a GPU-initialised process, never two benches sharing the device)."""
     env = dict(os.environ, **env_extra)
-    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args + ["--no-cpu-baseline", "--no-children", "--no-roofline"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args + ["--no-cpu-baseline", "--no-children"]
+    if not roofline:
+        cmd.append("--no-roofline")
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -170,6 +186,9 @@ def child_bench(extra_args, env_extra, label):
         out = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                "warmup": d["warmup"], "how": "child process of this bench run (started before the parent touched the GPU)"}
         out.update(label)
+        if d.get("roofline"):
+            out["roofline"] = d["roofline"]
+        out["stage_ms"] = d.get("stage_ms")
         return out, d
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}, None
@@ -190,6 +209,20 @@ def c3_child():
     if d is not None:
         out["clips_per_step"] = d["config"]["clips_per_step"]
         out["micro_batch"] = d["config"]["micro_batch"]
+        out["ms_per_clip"] = d["ms_per_step"] / d["config"]["clips_per_step"]
+        out["stage_ms_note"] = d.get("stage_ms_note")
+    return out
+
+
+def c5_child():
+    """BASELINE configs[4] on one GPU: 256 utterances of U(3, 15) s per step, a 40 k and a 48 k voice model resident
+    beside one HuBERT and one RMVPE; mixed lengths run as ragged micro-batches (length classes)."""
+    out, d = child_bench(["--workload", "c5", "--steps", "3", "--warmup", "1"], {},
+                         {"workload": "c5: 256 utterances of U(3,15) s per step, 40 k + 48 k voice models resident, "
+                                      "ragged micro-batches by length class"})
+    if d is not None:
+        out["clips_per_step"] = d["config"]["clips_per_step"]
+        out["micro_batches"] = d["config"].get("micro_batches")
         out["ms_per_clip"] = d["ms_per_step"] / d["config"]["clips_per_step"]
         out["stage_ms_note"] = d.get("stage_ms_note")
     return out
@@ -218,12 +251,20 @@ def launch_workers(n, argv):
     buf = []
     reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    t_start, t_term = time.monotonic(), None
     while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):   # a rank died: the others would wait in a collective forever
-            time.sleep(2.0)
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()                           # exactly the processes started above, by handle
+        late = time.monotonic() - t_start > WORKER_DEADLINE_S
+        if late or any(p.poll() not in (None, 0) for p in procs):   # a rank died: the others would wait in a collective forever
+            if t_term is None:
+                time.sleep(2.0)
+                t_term = time.monotonic()
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()                       # exactly the processes started above, by handle
+            elif time.monotonic() - t_term > 20.0:          # a rank stuck in a GPU wait ignores SIGTERM
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
         time.sleep(0.05)
     reader.join(10)
     codes = [p.returncode for p in procs]
@@ -301,10 +342,12 @@ def main():
         raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
     if a.dry_run:
         return dry_run(a, rank, world)
-    fp32 = c3_obj = None
+    fp32 = c3_obj = c5_obj = None
     if world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe:
-        fp32 = exact_fp32_child(a.steps, a.warmup)       # both before the first GPU call of this process
+        fp32 = exact_fp32_child(a.steps, a.warmup)       # all before the first GPU call of this process
         c3_obj = c3_child()
+        c5_obj = c5_child()
+        time.sleep(5.0)                                  # the children left the chip warm: let it idle before the headline loop
     rank, local, world = D.init("nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -366,13 +409,17 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     rtf = a.steps * audio_seconds_per_step / dt
     stage = ctx.last_timing()
+    mbs_per_step = None
+    if c5 or len(clips) > 1:
+        # micro-batches the LAST call of a step formed (c5: one call per voice model)
+        mbs_per_step = ctx.last_micro_batches()
 
     # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv): one extra, untimed step in SERIAL mode
     # (every launch on the library's one stream, so a launch's duration is its own) with a HIP event pair around
     # every conv launch.  `rocprofv3 --kernel-trace --stats` of `RVCX_SERIAL=1 python bench.py ...` gives the same
     # per-kernel averages (profiles/rocprof_r03_*).
     roofline, prof = None, None
-    if not a.no_roofline and not c5:
+    if not a.no_roofline:
         ctx.flop_counter(reset=True)
         ctx.conv_profile_begin()
         step()
@@ -406,10 +453,14 @@ def main():
         if c5:
             wl = (f"{C5_UTTERANCES} utterances of U(3,15) s per step for the whole job ({len(clips)} on this rank, sharded by "
                   "length), a 40 k and a 48 k RVC v2 voice model resident beside one HuBERT-base and one RMVPE, "
-                  "f0_method=rmvpe+, index_rate=0, geometry (1,6,38,41)")
+                  "f0_method=rmvpe+, index_rate=0, geometry (1,6,38,41); mixed lengths run as ragged micro-batches "
+                  f"(length classes of {ctx_bucket_frames()} frames)")
         elif c3:
             wl = (f"batch of {B} x 30 s 16 kHz clips per GPU per step, RVC v2 48k, f0_method=rmvpe+, HuBERT-base, "
                   f"index_rate=0.75 over a resident {C3_INDEX_ROWS} x 768 index, geometry (1,6,38,41)")
+            if world > 1:
+                wl = (f"C4 (BASELINE configs[3]): {world * B} x 30 s clips sharded {world} ways ({B} per rank), weights "
+                      "broadcast from rank 0 over RCCL/xGMI, no collective in the hot loop; per rank: ") + wl
         else:
             wl = (("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
                   ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
@@ -427,6 +478,7 @@ def main():
                "value_is": "whole-job aggregate over n_gpus (driver contract); value_per_gpu = value / n_gpus",
                "config": {"workload": wl + "; timed region = H2D of float PCM (pinned host) + all kernels + D2H of int16",
                           "clips_per_step": len(clips), "micro_batch": ctx.micro_batch(mid, n, params),
+                          "micro_batches": mbs_per_step,
                           "out_samples": got[0] if len(got) == 1 else sum(got), "weights_bcast_bytes": nbytes,
                           "weights_bcast_s": t_bcast, "load_s": t_load},
                "stage_ms": stage,
@@ -438,6 +490,10 @@ def main():
             res["exact_fp32"] = fp32
         if c3_obj is not None:
             res["c3"] = c3_obj
+        if c5_obj is not None:
+            res["c5"] = c5_obj
+        if fp32 is not None or c3_obj is not None:
+            res["order"] = "children (exact_fp32, c3, c5) ran first, each to completion; 5 s idle; then this process's warm-up and timed loop"
         if not a.no_cpu_baseline and world == 1 and not fcpe:
             res["cpu_baseline"] = cpu_baseline()
         else:

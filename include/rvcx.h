@@ -203,7 +203,7 @@ int64_t rvcx_out_len(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
  * waveform before int16 quantisation; out_n[i] receives the number of samples produced; noise[i] optional
  * packed parity noise (see rvcx_noise_len).
  * Utterances of one length class (rvcx_bucket_length: padded lengths within RVCX_BUCKET_FRAMES 10 ms frames, default
- * 64; clips long enough to be cut into chunks: equal lengths) are converted together as ragged micro-batches (B > 1
+ * 128; clips long enough to be cut into chunks: equal lengths) are converted together as ragged micro-batches (B > 1
  * through HuBERT, RMVPE, TextEncoder and flow with per-item lengths; rvcx_micro_batch tells how many at a time;
  * rvcx_last_micro_batches what the last call did); every utterance's result is bit-identical to converting it alone.  Without parity noise utterance i draws its Gaussians from Philox(seed + i).
  * Batch conversion is listed as not done in the reference (TODO.md:11). */

@@ -139,7 +139,11 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
   // this split's chunk range, and the stage structure: LIN -> stages of KKT chunks; else (chunk, tap-group)
   const int cb0 = ks * nchunk / a.splitk, cb1 = (ks + 1) * nchunk / a.splitk;
   const int nkk = LIN ? 1 : (a.ksize + KKT - 1) / KKT;
-  const int nst = LIN ? (cb1 - cb0 + KKT - 1) / KKT : (cb1 - cb0) * nkk;
+  // ragged batches: a tile that lies entirely behind its item's last valid output has nothing to compute -- no stages,
+  // and the epilogue stores the zeros it stores for every position beyond lens_out (workgroup-uniform)
+  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
+  const bool dead = (a.out_mode == OUT_SHUF1D ? n0 * a.sh_s - a.sh_pad : n0) >= len_out;
+  const int nst = dead ? 0 : (LIN ? (cb1 - cb0 + KKT - 1) / KKT : (cb1 - cb0) * nkk);
 
   uint4 ra[NA];
   float rb[NBT][8];
@@ -293,7 +297,6 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] *= inv;
 
-  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const int co_w = co0 + wr * (WM * 32) + 4 * h, nn_w = n0 + wc * (WN * 32) + i;
   if (H3_DBG(a, 8)) return;
   if (a.splitk > 1) {

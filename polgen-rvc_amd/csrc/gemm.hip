@@ -190,14 +190,24 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
     lds_barrier();
   };
 
-  fetch(0, ra[0], rb[0]);
-  fetch(1, ra[1], rb[1]);
-  commit(0, ra[0], rb[0]);
-  fetch(2, ra[0], rb[0]);
-  lds_barrier();
-  for (int st = 0; st < nst; st += 2) {
-    iter(st, ra[1], rb[1]);
-    iter(st + 1, ra[0], rb[0]);        // st + 1 == nst on an odd stage count: nothing to multiply, see iter
+  // ragged batches: a tile whose rows all lie behind one item's last frame has nothing to multiply -- its outputs are
+  // the zeros gemm_store_tile writes for dead rows (workgroup-uniform: no barrier is skipped by a part of the group)
+  bool dead = false;
+  if (a.lens) {
+    const long last = (n0 + BN <= a.rows ? n0 + BN : a.rows) - 1;
+    const long b0 = n0 / a.T;
+    dead = last / a.T == b0 && (int)(n0 - b0 * a.T) >= a.lens[b0];
+  }
+  if (!dead) {
+    fetch(0, ra[0], rb[0]);
+    fetch(1, ra[1], rb[1]);
+    commit(0, ra[0], rb[0]);
+    fetch(2, ra[0], rb[0]);
+    lds_barrier();
+    for (int st = 0; st < nst; st += 2) {
+      iter(st, ra[1], rb[1]);
+      iter(st + 1, ra[0], rb[0]);        // st + 1 == nst on an odd stage count: nothing to multiply, see iter
+    }
   }
 
   constexpr float inv = 1.f / kH3Scale;

@@ -105,9 +105,16 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
       ragged |= ns_host[b] != n;
     }
   const int *d_t0 = nullptr, *d_T = nullptr;
+  std::vector<const int*> d_tl(cf.n_conv, nullptr);     // valid frames behind extractor layer i
   if (ragged) {
     d_t0 = dev_ints(A, t0b, s);
     d_T = dev_ints(A, Tb, s);
+    std::vector<int> tl(t0b);
+    d_tl[0] = d_t0;
+    for (int i = 1; i < cf.n_conv; ++i) {
+      for (auto& t : tl) t = (t - cf.conv_kernels[i]) / cf.conv_strides[i] + 1;
+      d_tl[i] = dev_ints(A, tl, s);
+    }
   }
   float* bufa = A.alloc<float>((size_t)B * C * t0);
   float* bufb = A.alloc<float>((size_t)B * C * t0);
@@ -121,6 +128,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     ConvArgs a = conv1d_args(m.convs[i], x, y, B, (int)Tin, (int)Tout, cf.conv_strides[i], 1, 0);
     if (i == 0 && wav_bs > 0) a.x_bs = wav_bs;      // the B signals are slices of longer rows
     if (i > 0) a.act = ACT_GELU;
+    a.lens_out = d_tl[i];       // frames behind an item's last one: zeros, and tiles that hold nothing else are skipped
     c.conv_on(a, s);
     if (i == 0) {
       float* z = (y == bufa) ? bufb : bufa;
@@ -140,6 +148,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
   float* h2 = A.alloc<float>((size_t)B * E * T);
   {
     ConvArgs a = conv1d_args(m.proj, ln, h, B, T, T);
+    a.lens_out = d_T;
     c.conv_on(a, s);
     a = conv1d_args(m.pos_conv, h, h2, B, T, T, 1, 1, cf.pos_kernel / 2);   // SamePad: drop the last frame
     a.act = ACT_GELU;
@@ -189,6 +198,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
       launch_cf_to_tm(att, (long)E * T, o3 ? nullptr : attr, ldE, o3 ? attr : nullptr, ldEb, B, E, T, c.dev_err,
                       L.o.ovf_word, ++c.launch_seq, s);
       g = gemm_args(L.o, R, T);
+      g.lens = d_T;
       if (o3) g.xs = attr, g.ld_xs = ldEb;
       else g.x = attr, g.ld_x = ldE;
       g.res = hf;
@@ -199,6 +209,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
       launch_layernorm_tm(tmp, ldE, L.ln1_g, L.ln1_b, hf, ldE, f13 ? hs : nullptr, ldEb, R, E, 1e-5f, c.dev_err,
                           L.fc1.ovf_word, ++c.launch_seq, s);
       g = gemm_args(L.fc1, R, T);
+      g.lens = d_T;
       if (f13) g.xs = hs, g.ld_xs = ldEb;
       else g.x = hf, g.ld_x = ldE;
       g.act = ACT_GELU;
@@ -206,6 +217,7 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
       else g.y = ff, g.ld_y = F;
       c.gemm_on(g, s);
       g = gemm_args(L.fc2, R, T);
+      g.lens = d_T;
       if (f23) g.xs = ff, g.ld_xs = ldFb;
       else g.x = ff, g.ld_x = F;
       g.res = hf;

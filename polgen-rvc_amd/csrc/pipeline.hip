@@ -416,11 +416,13 @@ size_t convert_call_bytes(Ctx& c, int model_id, long n, const rvcx_params& p, bo
 // each utterance's own arithmetic (filter ends, reflect padding, frame counts, statistics, masks, recurrence
 // length).  A single utterance takes exactly the same path with B = 1, so a batch item is bit-identical to its single
 // run whatever shares the batch with it; the NSF decoder runs every utterance at its own length.
-// RVCX_BUCKET_FRAMES: class width in frames (a multiple of 32, the F0 U-Net's row granularity); 0 = equal lengths only.
+// RVCX_BUCKET_FRAMES: class width in frames (a multiple of 32, the F0 U-Net's row granularity; default 128 = 1.28 s);
+// 0 = equal lengths only.  Tiles that lie entirely behind an item's length are skipped (conv_h3, gemm_h3), so the
+// padding of a class costs little.
 int bucket_frames() {
   static const int v = [] {
     const char* e = getenv("RVCX_BUCKET_FRAMES");
-    int f = e ? atoi(e) : 64;
+    int f = e ? atoi(e) : 128;      // measured on C5 (tools/sweep_bucket.sh): 64 / 128 / 256 within noise of each other, 32 slower
     if (f <= 0) return 0;
     return std::max(32, (f + 31) / 32 * 32);
   }();
@@ -436,7 +438,8 @@ long bucket_length(long n, const rvcx_params& p, const Geometry& g) {
 }
 
 int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p) {
-  static const int env_max = getenv("RVCX_MAX_BATCH") ? std::max(1, atoi(getenv("RVCX_MAX_BATCH"))) : 8;
+  // 16: the BiGRU cluster kernel's co-residency bound (2 directions x 16 items x 4 workgroups = 128); C5 +3 %, C3 +1 % over 8
+  static const int env_max = getenv("RVCX_MAX_BATCH") ? std::max(1, atoi(getenv("RVCX_MAX_BATCH"))) : 16;
   static const size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 64) << 30;
   const size_t per = convert_item_bytes(c, model_id, n, p) + f0_arena_bytes(c, p, 1, n + 32000L * p.x_pad);
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)env_max, budget / std::max<size_t>(per, 1)));

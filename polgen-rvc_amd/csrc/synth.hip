@@ -238,6 +238,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   float* x = A.alloc<float>((size_t)B * hid * T);
   {
     ConvArgs a = conv1d_args(m.emb_phone, io.phone_ct, x, B, T, T);
+    a.lens_out = lens;      // (everything behind an item's last frame is masked below anyway: its tiles are skipped)
     c.conv(a);
     launch_embed_pitch(x, m.emb_pitch, io.pitch, B, hid, T, std::sqrt((float)hid), 0.1f, lens, s);
   }
@@ -250,12 +251,14 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   const float scale = 1.f / std::sqrt((float)kc);
   for (const auto& L : m.enc) {
     ConvArgs a = conv1d_args(L.qkv, x, qkv, B, T, T);
+    a.lens_out = lens;
     c.conv(a);
     launch_attention(qkv, qkv + (size_t)hid * T, qkv + (size_t)2 * hid * T, att, B, heads, kc, T, T,
                      (long)3 * hid * T, (long)hid * T, scale, L.rel_k, L.rel_v, 10, lens, scratch, asplit, s, c.dev_err, L.att.word,
                      ++c.launch_seq, L.att.h3());
     c.flops += attention_flops(B, heads, kc, T);
     a = conv1d_args(L.o, att, tmp, B, T, T);
+    a.lens_out = lens;
     conv_set_res(a, x, hid, T);
     c.conv(a);
     launch_layernorm_c(tmp, L.g1, L.b1, x, B, hid, T, 1e-5f, nullptr, s);
@@ -268,6 +271,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     c.conv(a);
     a = conv1d_args(L.ffn2, hbuf, tmp, B, T, T, 1, 1, pl);
     a.lens_in = lens;
+    a.lens_out = lens;
     conv_set_res(a, x, hid, T);      // x + y; positions beyond len are never read by valid frames
     c.conv(a);
     launch_layernorm_c(tmp, L.g2, L.b2, x, B, hid, T, 1e-5f, nullptr, s);
@@ -312,9 +316,11 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       for (int i = 0; i < 3; ++i) {
         a = conv1d_args(F.in_l[i], h, xin, B, T, T, 1, 1, (F.in_l[i].k - 1) / 2);
         a.lens_in = lens;
+        a.lens_out = lens;
         c.conv(a);
         launch_wn_gate(xin, gc, i * 2 * hid, 6 * hid, acts, B, hid, T, s);
         a = conv1d_args(F.rs_l[i], acts, rs, B, T, T);
+        a.lens_out = lens;
         c.conv(a);
         launch_wn_res_skip(h, wout, rs, B, hid, T, i == 2, i == 0, lens, s);
       }

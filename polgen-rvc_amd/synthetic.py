@@ -58,7 +58,25 @@ def _rng(name: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=key))
 
 
+# shape-only mode: ranks that receive rank 0's folded weights by broadcast (dist.broadcast_weights) only need tensors of
+# the right SHAPES to build the same region layout -- zeros, no random numbers drawn (bench.py, ranks != 0)
+_SHAPES_ONLY = False
+
+
+class shapes_only:
+    """with S.shapes_only(): S.hubert_state(...) -> same keys and shapes, all zeros, at a fraction of the host time."""
+    def __enter__(self):
+        global _SHAPES_ONLY
+        self._prev, _SHAPES_ONLY = _SHAPES_ONLY, True
+
+    def __exit__(self, *exc):
+        global _SHAPES_ONLY
+        _SHAPES_ONLY = self._prev
+
+
 def _normal(name: str, shape, std: float, seed: int, mean: float = 0.0) -> np.ndarray:
+    if _SHAPES_ONLY:
+        return np.zeros(tuple(shape), np.float32)
     x = _rng(name, seed).standard_normal(size=tuple(shape), dtype=np.float32)
     return (x * np.float32(std) + np.float32(mean)).astype(np.float32)
 

@@ -266,3 +266,71 @@ def test_c3_item_with_retrieval_blend_vs_reference(ctx, full):
         assert rms(f0_[0] - f32[0]) > 3 * e
     finally:
         ctx.load_index(None)
+
+
+def test_c5_256_mixed_length_utterances_two_models_ragged_batches():
+    """BASELINE configs[4] at its stated size on one GPU: the 256 utterances of U(3, 15) s bench.py's c5 workload
+    converts (even -> 40 k, odd -> 48 k voice model, one call per model as app code would issue them), PLUS the three
+    utterances of the reference fixture pipeline_c5_two_models riding in the same calls with their own noise.
+    * the calls really batch: mixed lengths form ragged micro-batches (length classes), mean size >= 4;
+    * 16 sampled utterances (8 per model; shortest, longest and members of full micro-batches among them) are
+      bit-equal to their single runs;
+    * the three fixture utterances, converted inside those 131- / 128-utterance calls, still match the REFERENCE's own
+      VC.pipeline output within 1e-4 RMS (float) / 8 LSB (PCM)."""
+    import json
+    from bench import c5_lengths
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_c5_two_models.npz"))
+    seed = int(d["seed"])
+    hcfg, rcfg = json.loads(str(d["hcfg"])), json.loads(str(d["rcfg"]))
+    ctx = _lib.Context(0)
+    try:
+        ctx.load_hubert(W.hubert_cfg_struct(hcfg), S.hubert_state(hcfg, seed))
+        ctx.load_rmvpe(W.rmvpe_cfg_struct(rcfg), S.rmvpe_state(rcfg, seed))
+        mids, fix = {}, []
+        for u in range(int(d["n_utts"])):
+            pre = f"u{u}_"
+            scfg = json.loads(str(d[pre + "scfg"]))
+            key = (scfg[-1], int(d[pre + "synth_seed"]))
+            if key not in mids:
+                mids[key] = ctx.load_synth(W.synth_cfg_struct(scfg, 768), S.synth_state(scfg, key[1]))
+            noise = _fixture_noise(scfg, int(d[pre + "chunk_lens"][0]), scfg[-1], d[pre + "noise_seed"])
+            fix.append((pre, scfg[-1], mids[key], S.make_clip(int(d[pre + "clip"]), float(d[pre + "seconds"])), noise))
+        by_rate = {k[0]: m for k, m in mids.items()}
+        assert set(by_rate) == {40000, 48000}
+        lengths = c5_lengths()
+        assert len(lengths) == 256 and min(lengths) >= 3 * 16000 and max(lengths) <= 15 * 16000
+        p = _params()
+        checked = 0
+        for rate, parity in ((40000, 0), (48000, 1)):
+            mid = by_rate[rate]
+            sel = [i for i in range(256) if i % 2 == parity]
+            clips = [S.make_clip(5000 + i, lengths[i] / 16000.0) for i in sel]
+            noises = [None] * len(clips)
+            mine = [f for f in fix if f[1] == rate]
+            for f in mine:                      # the reference's utterances ride along, with the reference's noise
+                clips.append(f[3])
+                noises.append(f[4])
+            pcm, f32 = ctx.convert_batch(mid, clips, p, noises=noises, want_f32=True)
+            mbs = ctx.last_micro_batches()
+            assert sum(mbs) == len(clips)
+            print(f"{rate} Hz: {len(clips)} utterances in {len(mbs)} micro-batches (mean {np.mean(mbs):.1f}, max {max(mbs)})")
+            assert np.mean(mbs) >= 4.0 and max(mbs) >= 8
+            # single runs of 8 sampled utterances: extremes of the length range + evenly spread ones
+            order = np.argsort([len(c) for c in clips[:len(sel)]])
+            pick = sorted({int(order[0]), int(order[-1])} | {int(order[k]) for k in np.linspace(5, len(sel) - 6, 6).astype(int)})
+            assert len(pick) == 8
+            for j in pick:                      # utterance j of a call draws from Philox(seed + j)
+                alone, alone32 = ctx.convert_batch(mid, [clips[j]], _params(seed=5 + j), want_f32=True)
+                assert np.array_equal(alone32[0], f32[j]), (rate, j)
+                assert np.array_equal(alone[0], pcm[j]), (rate, j)
+                checked += 1
+            for k, f in enumerate(mine):
+                j = len(sel) + k
+                e, dmax, frac, blocks = _check_vs_fixture(d, f[0], pcm[j], f32[j], rate)
+                print(f"  fixture {f[0]} inside the call: float rms err {e:.3e}, pcm max diff {dmax} LSB, {blocks} blocks")
+                assert e < 1e-4 and dmax <= 8 and frac < 0.02 and blocks > 20
+        assert checked == 16
+        assert ctx.fp32_reruns() == 0
+    finally:
+        ctx.close()

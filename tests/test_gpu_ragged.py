@@ -43,7 +43,7 @@ def test_length_classes_partition_the_lengths(ctx):
         nd = ctx.bucket_length(mid, n, p)
         assert nd >= n and ctx.bucket_length(mid, nd, p) == nd and nd >= prev
         assert (nd + 32000 + 1) % (160 * 32) == 0          # the class ends one sample short of a 32-frame boundary
-        assert nd - n < 160 * 64
+        assert nd - n < 160 * 128
         prev = nd
         seen.add(nd)
     assert len(seen) > 10
@@ -56,7 +56,7 @@ def test_ragged_micro_batch_equals_single_runs(ctx):
     float waveform equal, bit for bit, what the clip gives alone (Philox noise, protect, RMS envelope)."""
     mid = _load(ctx, 3)
     p = _params(volume_envelope=0.25)
-    lens = [27200, 27360, 27999, 30001, 33333, 36160, 40800, 41000, 50000]
+    lens = [27200, 27360, 27999, 30001, 33333, 36160, 50000, 52000, 71000]
     clips = [_clip(100 + i, n) for i, n in enumerate(lens)]
     classes = {}
     for n in lens:
