@@ -569,12 +569,15 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     const long nd = bucket_length(n, p, g);
     const int cap = convert_micro_batch(c, model_id, nd, p);
     int j = i;
-    bool ragged = false;
-    while (j < NB && bucket_length(ios[order[j]].n, p, g) == nd && j - i < cap) {
-      ragged |= ios[order[j]].n != nd;
-      ++j;
+    while (j < NB && bucket_length(ios[order[j]].n, p, g) == nd) ++j;
+    // the class's members in ceil(m / cap) micro-batches of (almost) equal size: 17 members are 9 + 8, not 16 + 1
+    const int m = j - i, parts = (m + cap - 1) / cap;
+    for (int q = 0; q < parts; ++q) {
+      const int a = i + (int)((long)m * q / parts), b = i + (int)((long)m * (q + 1) / parts);
+      bool ragged = false;
+      for (int t = a; t < b; ++t) ragged |= ios[order[t]].n != nd;
+      mbs.push_back({a, b - a, nd, ragged});
     }
-    mbs.push_back({i, j - i, nd, ragged});
     i = j;
   }
   c.last_mbs.clear();

@@ -46,7 +46,7 @@ def test_length_classes_partition_the_lengths(ctx):
         assert nd - n < 160 * 128
         prev = nd
         seen.add(nd)
-    assert len(seen) > 10
+    assert len(seen) >= 6
     # a clip long enough to be cut (x_max = 3 s here) keeps its own geometry
     assert ctx.bucket_length(mid, 16000 * 5, _params(geo=(1, 1, 2, 3))) == 16000 * 5
 
