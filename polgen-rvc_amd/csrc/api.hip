@@ -442,6 +442,25 @@ int rvcx_bench_resblock_pair(rvcx_ctx* ctx, int B, int Cc, int T, int K, int dil
   };
   if (fused && !resblock_pair_ok(pa)) fail("resblock pair: shape not supported by the fused kernel");
   once();
+  if (fused && getenv("RVCX_PAIR_TRACE")) {     // one traced launch: per-workgroup phase stamps -> CSV (tools/pair_trace.py)
+    const size_t cap = (size_t)B * (T / 32 + 64) * 8;
+    long long* tr = C->arena.alloc<long long>(cap);
+    RVCX_HIP(hipMemsetAsync(tr, 0, cap * 8, C->stream));
+    pa.trace = tr;
+    once();
+    pa.trace = nullptr;
+    std::vector<long long> h(cap);
+    RVCX_HIP(hipMemcpyAsync(h.data(), tr, cap * 8, hipMemcpyDeviceToHost, C->stream));
+    RVCX_HIP(hipStreamSynchronize(C->stream));
+    if (FILE* f = fopen(getenv("RVCX_PAIR_TRACE"), "a")) {
+      fprintf(f, "# C %d T %d K %d dil %d\n", Cc, T, K, dil);
+      for (size_t w = 0; w * 8 < cap; ++w)
+        if (h[w * 8]) {
+          for (int k = 0; k < 8; ++k) fprintf(f, "%lld%c", h[w * 8 + k], k == 7 ? '\n' : ',');
+        }
+      fclose(f);
+    }
+  }
   hipEvent_t e0, e1;
   RVCX_HIP(hipEventCreate(&e0));
   RVCX_HIP(hipEventCreate(&e1));

@@ -93,6 +93,7 @@ struct PairArgs {
   int* ovf = nullptr;            // as ConvArgs::ovf
   int* ovf_layer = nullptr;      // as ConvArgs::ovf_layer (the pair reports as its first conv)
   int seq = 0;
+  long long* trace = nullptr;    // profiling (rvcx_bench_resblock_pair, RVCX_PAIR_TRACE): 8 s_memrealtime stamps per workgroup
 };
 // fp16 hi/lo split kernels hold activations as fp16 halves: |x| >= 65504 (attention K / V: >= 255) would become
 // inf.  Every split kernel checks what it converts, raises bit 1 of the context's device error word and stamps its

@@ -34,6 +34,14 @@ __device__ __forceinline__ uint4 h3_load4(const H3Rsrc& b, int off) {
   return make_uint4(0, 0, 0, 0);
 #endif
 }
+// per-lane offset + wave-uniform offset (an SGPR: no vector address arithmetic per load)
+__device__ __forceinline__ uint4 h3_load4s(const H3Rsrc& b, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0));
+#else
+  return make_uint4(0, 0, 0, 0);
+#endif
+}
 __device__ __forceinline__ f32x16 h3_mfma(half8 a, half8 b, f32x16 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);

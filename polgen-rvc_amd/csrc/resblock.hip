@@ -33,6 +33,10 @@ constexpr int kPairPadY = 16;    // c2 reads up to k - 1 <= 10 columns past N1 (
 #define RVCX_PAIR_SCHED_FENCE 0
 #endif
 constexpr bool kSchedFence = RVCX_PAIR_SCHED_FENCE != 0;
+#ifndef RVCX_PAIR_PIPE
+#define RVCX_PAIR_PIPE 1
+#endif
+constexpr bool kPipe = RVCX_PAIR_PIPE != 0;      // pin the fragment-read / MFMA interleave (sched_group_barrier); 0: A/B builds
 // Timing ablations (tools/ablate_pair.sh builds one library per value; results are garbage, only the clock counts):
 //   1 c2: no weight commit, no barriers      2 c2 epilogue: no residual loads / stores      4 no fragment reads, no MFMAs
 //   8 c1: no input conversion at commit     16 c1: no weight commit, one barrier per chunk
@@ -56,7 +60,12 @@ constexpr int pair_pady(int K, bool trim) { return trim ? K - 1 : kPairPadY; }
 // tile of its wave and comes back transposed, a lane then owns 4 consecutive positions of one channel: residual loads and
 // output stores are 16 bytes per lane, a quarter of the memory instructions (the dword stores were store-ISSUE bound).
 // Needs 16-byte aligned rows (cs, T multiples of 4); the tile keeps a multiple of 4 output positions.
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool TRIM = false, int RESPF = 0>
+// OVL: the c1 input tile Bs OVERLAYS the Y1 region (Y1 is written only by the c1 epilogue, when nobody reads Bs any more
+// -- one extra barrier per tile): the LDS then holds max(Y1, Bs) + As, which is what lets a 256-position tile of all 128
+// channels fit, i.e. 8 waves of 64 x 64 (WM = WN = 2: eight fragment reads per twelve MFMAs instead of six per six).
+// Round 4 (tools/mfma_peak.hip): ds_read_b128 delivers ~115 B/clk/CU, so at one fragment read per MFMA the LDS, not the
+// matrix pipe, bounds the k-loop (measured: 1.9 us per stage against 1.2 us of MFMA time).
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool TRIM = false, int RESPF = 0, bool OVL = false>
 __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairArgs a) {
   constexpr int THREADS = 64 * WR * WC;
   constexpr int N1 = 32 * NT, N1P = N1 + pair_pady(K, TRIM), WROW = N1 + pair_halo(K, TRIM);
@@ -71,9 +80,10 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   static_assert(NCS == 1 || KKT == K, "several chunks per stage only with all taps resident");
   static_assert(NCHUNK % NCS == 0, "chunk sets must tile the channels");
   extern __shared__ uint4 lds[];
+  constexpr int Y1_ELEMS = NCHUNK * 4 * N1P, BS_ELEMS = NCS * 4 * WROW;
   uint4* Y1 = lds;                              // [chunk][op][h][N1P]
-  uint4* As = Y1 + NCHUNK * 4 * N1P;            // [slot][op][h][C]
-  uint4* Bs = As + A_ELEMS;                     // [cl][op][h][WROW]
+  uint4* As = Y1 + (OVL && BS_ELEMS > Y1_ELEMS ? BS_ELEMS : Y1_ELEMS);   // [slot][op][h][C]
+  uint4* Bs = OVL ? Y1 : As + A_ELEMS;          // [cl][op][h][WROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
@@ -100,6 +110,20 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   const int xrow = a.cs * 4;
   constexpr int slab = 4 * C * 16;              // bytes of one (tap, chunk) weight slab
 
+  // phase stamps of this workgroup (100 MHz real-time counter): 0 start, 1 first stage committed (inputs arrived),
+  // 2 c1 loop done, 3 Y1 written, 4 c2 loop done, 5 end; 6 = tile, 7 = XCC id
+  auto stamp = [&](int k) {
+    if (a.trace && tid == 0) a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + k] = (long long)wall_clock64();
+  };
+  stamp(0);
+  if (a.trace && tid == 0) {
+    a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + 6] = tile;
+    unsigned xcc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#endif
+    a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + 7] = xcc & 0xf;
+  }
   f32x16 acc[WM][WN];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -210,9 +234,6 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
     for (int s = 0; s < NS; ++s) {
       const int cur = s & 1;
       if (s + 1 < NS) load(cur ^ 1, s + 1);
-      // -DRVCX_PAIR_SCHED_FENCE=1 pins the reads of slot s+1 AHEAD of the MFMAs of slot s (left alone, the scheduler
-      // sinks every ds_read next to its first use, lgkmcnt(0) in front of each MFMA).  Measured neutral: with three
-      // waves per SIMD the other waves' MFMAs cover the latency, and the kernel is power-limited.
       if (kSchedFence) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < WM; ++m) {
@@ -226,37 +247,54 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
       }
       if (kSchedFence) __builtin_amdgcn_sched_barrier(0);
     }
+    // The software pipeline above, PINNED (round 4).  Left alone the scheduler sinks every ds_read next to its first use
+    // -- the ISA was {ds_read, s_waitcnt lgkmcnt(0), v_mfma} per MFMA: each wave pays the LDS latency per matrix
+    // instruction, the matrix pipe idled more than half of the k-loop.  The groups below order the block as: the first
+    // slot's fragment reads, then per slot one MFMA / one read of the NEXT slot alternating; the compiler's counted
+    // lgkmcnt waits then find the data already there.  Same instructions, same arithmetic order per accumulator.
+    if (kPipe) {
+      constexpr int R = 2 * WM + 2 * WN, M = 3 * WM * WN;
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (s + 1 < NS && j < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (s + 1 < NS && R > M) __builtin_amdgcn_sched_group_barrier(0x100, R - M, 0);
+      }
+    }
   };
   using Full = std::integral_constant<int, KKT>;
   using Last = std::integral_constant<int, K - (NG - 1) * KKT>;
-  constexpr int nst = (NCHUNK / NCS) * NG;
   constexpr float inv = 1.f / kH3Scale;
 
   // ================================================================ phase 1: Y1 = lrelu(c1(lrelu(x)) + b1)
   zero_acc();
   fetch_b(0);
   fetch_a(w1r, 0, 0);
-  {
-    int chunk = 0, g = 0;
-    for (int st = 0; st < nst; ++st) {
+  // The tap groups of a chunk set are unrolled at compile time: one loop body holds the Full and the Last form of the
+  // k-steps, so the accumulators keep their registers across the loop (as a runtime choice inside one loop the two forms
+  // were joined by 32 v_mov_b64 per stage behind an s_nop that drained the matrix pipe).
+  for (int chunk = 0; chunk < NCHUNK; chunk += NCS) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const bool last_stage = chunk + NCS >= NCHUNK && g == NG - 1;
       if (!(kAbl & 16) || g == 0) __syncthreads();
       if (g == 0) commit_b();
       if (!(kAbl & 16)) commit_a();
       if (!(kAbl & 16) || g == 0) __syncthreads();
-      int g1 = g + 1, chunk1 = chunk;
-      if (g1 == NG) {
-        g1 = 0;
-        chunk1 += NCS;
-      }
-      if (st + 1 < nst) fetch_a(w1r, chunk1, g1 * KKT);
+      if (chunk == 0 && g == 0) stamp(1);
+      if (!last_stage) fetch_a(w1r, g + 1 == NG ? chunk + NCS : chunk, g + 1 == NG ? 0 : (g + 1) * KKT);
       else fetch_a(w2r, 0, 0);                       // first weights of c2 fly during the c1 epilogue
       if (g == 0 && chunk + NCS < NCHUNK) fetch_b(chunk + NCS);
       if (NG > 1 && g == NG - 1) compute(Last{}, Bs, WROW, 4 * WROW, g * KKT, a.dil);
       else compute(Full{}, Bs, WROW, 4 * WROW, g * KKT, a.dil);
-      g = g1;
-      chunk = chunk1;
     }
   }
+  stamp(2);
+  if (OVL) __syncthreads();                      // Y1 overlays the input tile: every wave is done reading Bs
   // c1 epilogue: bias, leaky_relu (the one ahead of c2), zero outside the sequence, split, into LDS
 #pragma unroll
   for (int m = 0; m < WM; ++m)
@@ -324,27 +362,23 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
   };
   if (RESPF == 2 && !(kAbl & 2)) load_res();
   zero_acc();
-  {
-    int chunk = 0, g = 0;
-    if (kAbl & 1) __syncthreads();
-    for (int st = 0; st < nst; ++st) {
+  stamp(3);
+  if (kAbl & 1) __syncthreads();
+  for (int chunk = 0; chunk < NCHUNK; chunk += NCS) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const bool last_stage = chunk + NCS >= NCHUNK && g == NG - 1;
       if (!(kAbl & 1)) {
         __syncthreads();
         commit_a();
         __syncthreads();
       }
-      int g1 = g + 1, chunk1 = chunk;
-      if (g1 == NG) {
-        g1 = 0;
-        chunk1 += NCS;
-      }
-      if (st + 1 < nst && !(kAbl & 1)) fetch_a(w2r, chunk1, g1 * KKT);
+      if (!last_stage && !(kAbl & 1)) fetch_a(w2r, g + 1 == NG ? chunk + NCS : chunk, g + 1 == NG ? 0 : (g + 1) * KKT);
       if (NG > 1 && g == NG - 1) compute(Last{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
       else compute(Full{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
-      g = g1;
-      chunk = chunk1;
     }
   }
+  stamp(4);
   if constexpr (RESPF == 3) {
     constexpr int P = 36;                              // floats per staged row: 16-byte aligned, rows 4 banks apart
     static_assert(THREADS / 64 * 32 * P * 4 <= NCHUNK * 4 * N1P * 16, "staging tiles must fit the Y1 region");
@@ -394,6 +428,7 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
           }
         }
       }
+    stamp(5);
     return;
   }
   // c2 epilogue: bias, residual (x itself: L2-hot, this workgroup staged it a moment ago), length mask, store
@@ -442,18 +477,355 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_kernel(const PairA
     }
 }
 
+
+// ====================================================================================================================
+// Round 4: the A-DIRECT form of the fused step.
+//
+// Per-workgroup phase stamps of the kernel above (tools/pair_trace.py) showed the two k-loops are 91 % of a tile's
+// life and run at ~60 % matrix-pipe duty: every stage pays two workgroup barriers around the weight commit (drain,
+// commit, refill: ~0.6 us of a 1.9 us stage), and with one fragment read per MFMA the LDS (~115 B/clk/CU for
+// ds_read_b128, tools/mfma_peak.hip) is the second bound right behind it.  Here the weight fragments never touch the
+// LDS: the fp16 hi/lo weight image is already stored in MFMA A-fragment order (16 bytes per lane, 512 contiguous
+// bytes per half wave), so every wave loads ITS fragments straight from L2 into registers, one tap group ahead
+// (double-buffered register sets, ~1 us of prefetch distance).  What is left in LDS is the activation side:
+//   * phase 2 (c2 over Y1) has NO barrier at all -- Y1 is read-only, waves run free;
+//   * phase 1 (c1) keeps one barrier per 16-channel chunk: the converted input tile is double-buffered, the
+//     conversion of chunk c + 1 happens in the shadow of chunk c's MFMAs;
+//   * LDS reads per MFMA: 4 per 6 (32 x 64 wave tiles) or 4 per 12 (64 x 64) instead of 6 per 6.
+// Same split, same k-order (chunks ascending, taps ascending, three MFMAs per block): bit-identical to the kernel
+// above and to the two conv_h3 launches.
+// G: taps per A register set.  OVL: the input tiles overlay Y1 (see above).
+template <int G0, int NGRP, typename F>
+__device__ __forceinline__ void for_each_group(F&& f) {      // f(integral_constant<int, g>) for g = G0 .. NGRP - 1, unrolled
+  if constexpr (G0 < NGRP) {
+    f(std::integral_constant<int, G0>{});
+    for_each_group<G0 + 1, NGRP>(f);
+  }
+}
+
+template <int C, int NT, int WR, int WC, int K, int G, bool OVL>
+__global__ __launch_bounds__(64 * WR * WC) void resblock_pair_adir_kernel(const PairArgs a) {
+  constexpr int THREADS = 64 * WR * WC;
+  constexpr int N1 = 32 * NT, N1P = N1 + kPairPadY, WROW = N1 + kPairHalo;
+  constexpr int WM = (C / 32) / WR, WN = NT / WC;
+  constexpr int NCHUNK = C / 16, NG = (K + G - 1) / G;
+  constexpr int B_TASKS = 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
+  constexpr int BN_OUT = (N1 - (K - 1)) & ~3, H2 = (K - 1) / 2;
+  constexpr int Y1_ELEMS = NCHUNK * 4 * N1P, BS_ELEMS = 4 * WROW;
+  static_assert(WM >= 1 && WN >= 1 && WM * WR * 32 == C && WN * WC == NT, "bad tile");
+  static_assert(NCHUNK % 2 == 0, "chunks are processed in pairs");
+  static_assert(!OVL || 2 * BS_ELEMS <= Y1_ELEMS, "the two input tiles must fit the Y1 region");
+  extern __shared__ uint4 lds[];
+  uint4* Y1 = lds;                                  // [chunk][op][h][N1P]
+  uint4* Bs = OVL ? Y1 : Y1 + Y1_ELEMS;             // [buf][op][h][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int pad1 = (K - 1) * a.dil / 2;
+  int tile = blockIdx.x;
+  if (a.xcd_order) {
+    const int nt = gridDim.x, xcd = tile & 7, idx = tile >> 3, q = nt >> 3, r = nt & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n0 = tile * BN_OUT;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int wuse = N1 + (K - 1) * a.dil;
+  const int in_base = n0 - H2 - pad1;
+  const float slope = a.slope;
+  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.bs, C * a.cs * 4);
+  const H3Rsrc w1r = h3_rsrc(a.w1, K * NCHUNK * 4 * C * 16);
+  const H3Rsrc w2r = h3_rsrc(a.w2, K * NCHUNK * 4 * C * 16);
+  const int xrow = a.cs * 4;
+  constexpr int slab = 4 * C * 16;
+  constexpr float inv = 1.f / kH3Scale;
+  auto stamp = [&](int k) {
+    if (a.trace && tid == 0) a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + k] = (long long)wall_clock64();
+  };
+  stamp(0);
+  if (a.trace && tid == 0) a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + 6] = tile;
+
+  f32x16 acc[WM][WN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  // ---- input tile staging: task t -> (h, p): 8 channels of one position (fp32 -> split fp16 at commit)
+  int b_off[NBT], b_row[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) {
+    const int t = tid + THREADS * j;
+    const int hh = t / WROW, p = t - hh * WROW;
+    const int pos = in_base + p;
+    b_row[j] = hh * 8;
+    b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len) ? pos * 4 : kH3Oob;
+  }
+  float rb[NBT][8];
+  bool ovf = false;
+  auto fetch_b = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int row0 = (chunk * 16 + b_row[j]) * xrow;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
+    }
+  };
+  auto commit_b = [&](int buf) {
+    uint4* Bd = Bs + buf * BS_ELEMS;
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + THREADS * j;
+      if (NBT * THREADS == B_TASKS || t < B_TASKS) {
+        half8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v = rb[j][q];
+          v = v > 0.f ? v : v * slope;                 // leaky_relu ahead of c1
+          ovf |= !(fabsf(v) < kH3ActLimit);
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        const int hh = t / WROW, p = t - hh * WROW;
+        Bd[(0 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
+        Bd[(1 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+      }
+    }
+  };
+
+  // ---- weight fragments: two register sets of G taps x {S wh, S wl} x WM row blocks, loaded straight from the image
+  half8 aq[2][G][2][WM];
+  const int a_lane = (h * C + wr * (WM * 32) + i) * 16;
+  auto taps_of = [](int g) { return (NG > 1 && g == NG - 1) ? K - (NG - 1) * G : G; };
+  auto load_aset = [&](auto set_tag, const H3Rsrc& wres, int chunk, int g) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int kk0 = g * G;
+#pragma unroll
+    for (int kkl = 0; kkl < G; ++kkl)
+      if (kkl < taps_of(g)) {
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+            aq[SET][kkl][op][m] = __builtin_bit_cast(
+                half8, h3_load4s(wres, a_lane, ((kk0 + kkl) * NCHUNK + chunk) * slab + op * 2 * C * 16 + m * 512));
+      }
+  };
+  // the k-steps of one stage: TAPS taps of one chunk, A from register set SET, B from LDS one slot ahead
+  auto compute = [&](auto set_tag, auto taps_tag, const uint4* Bt, int pitch, int kk0, int tap_step) {
+    constexpr int SET = decltype(set_tag)::value, TAPS = decltype(taps_tag)::value;
+    half8 bf[2][2][WN];
+    auto loadb = [&](int buf, int s) {
+      const int tp = (kk0 + s) * tap_step;
+#pragma unroll
+      for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          bf[buf][op][n] = __builtin_bit_cast(half8, Bt[(op * 2 + h) * pitch + wc * (WN * 32) + n * 32 + i + tp]);
+    };
+    loadb(0, 0);
+#pragma unroll
+    for (int s = 0; s < TAPS; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < TAPS) loadb(cur ^ 1, s + 1);
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        const half8 wh = aq[SET][s][0][m] * (_Float16)(1.f / kH3Scale);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          acc[m][n] = h3_mfma(aq[SET][s][0][m], bf[cur][0][n], acc[m][n]);   // (S wh) xh
+          acc[m][n] = h3_mfma(wh, bf[cur][1][n], acc[m][n]);                  // wh (S xl)
+          acc[m][n] = h3_mfma(aq[SET][s][1][m], bf[cur][0][n], acc[m][n]);   // (S wl) xh
+        }
+      }
+    }
+    if (kPipe) {      // pin the software pipeline: first slot's reads, then MFMAs / next slot's reads alternating
+      constexpr int R = 2 * WN, M = 3 * WM * WN;
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+#pragma unroll
+      for (int s = 0; s < TAPS; ++s) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (s + 1 < TAPS && j < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // one stage of a phase: prefetch the next stage's weights into the other register set, then multiply
+  auto stage = [&](auto cc_tag, auto g_tag, int chunk, const H3Rsrc& wres, bool have_next_chunk, const H3Rsrc* wres_after,
+                   const uint4* Bt, int pitch, int tap_step) {
+    constexpr int CC = decltype(cc_tag)::value, GG = decltype(g_tag)::value;
+    constexpr int P = (CC * NG + GG) & 1;
+    using Cur = std::integral_constant<int, P>;
+    using Nxt = std::integral_constant<int, P ^ 1>;
+    if constexpr (GG + 1 < NG) {
+      load_aset(Nxt{}, wres, chunk, GG + 1);
+    } else {
+      if (have_next_chunk) load_aset(Nxt{}, wres, chunk + 1, 0);
+      else if (wres_after) load_aset(Nxt{}, *wres_after, 0, 0);
+    }
+    constexpr int TAPS = (NG > 1 && GG == NG - 1) ? K - (NG - 1) * G : G;
+    compute(Cur{}, std::integral_constant<int, TAPS>{}, Bt, pitch, GG * G, tap_step);
+  };
+  // compile-time loop over the tap groups of a chunk
+  auto for_groups = [&](auto&& f) { for_each_group<0, NG>(f); };
+
+  // ================================================================ phase 1: Y1 = lrelu(c1(lrelu(x)) + b1)
+  zero_acc();
+  fetch_b(0);
+  load_aset(S0{}, w1r, 0, 0);
+  commit_b(0);
+  __syncthreads();
+  stamp(1);
+  if (NCHUNK > 1) fetch_b(1);
+  for (int cp = 0; cp < NCHUNK; cp += 2) {
+    // chunk cp (input tile buffer 0) then chunk cp + 1 (buffer 1)
+    for_groups([&](auto g_tag) {
+      constexpr int GG = decltype(g_tag)::value;
+      stage(S0{}, g_tag, cp, w1r, true, nullptr, Bs, WROW, a.dil);
+      if constexpr (GG == 0) {             // chunk cp + 1 into the other buffer, in the shadow of this chunk's MFMAs
+        commit_b(1);
+        if (cp + 2 < NCHUNK) fetch_b(cp + 2);
+      }
+    });
+    __syncthreads();      // buffer 1 is complete; everyone is done with buffer 0
+    for_groups([&](auto g_tag) {
+      constexpr int GG = decltype(g_tag)::value;
+      stage(S1{}, g_tag, cp + 1, w1r, cp + 2 < NCHUNK, &w2r, Bs + BS_ELEMS, WROW, a.dil);
+      if constexpr (GG == 0) {
+        if (cp + 2 < NCHUNK) {
+          commit_b(0);
+          if (cp + 3 < NCHUNK) fetch_b(cp + 3);
+        }
+      }
+    });
+    if (cp + 2 < NCHUNK) __syncthreads();
+  }
+  stamp(2);
+  if (OVL) __syncthreads();                // Y1 overlays the input tiles: every wave is done reading them
+  // c1 epilogue: bias, leaky_relu (the one ahead of c2), zero outside the sequence, split, into LDS
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      const int c_t = wr * (WM * 32) + m * 32;
+      const int j = wc * (WN * 32) + n * 32 + i;
+      const int pos1 = n0 - H2 + j;
+      const bool live = pos1 >= 0 && pos1 < len;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const int cg = c_t + 8 * g;
+        half4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[m][n][4 * g + q] * inv + (a.b1 ? a.b1[cg + 4 * h + q] : 0.f);
+          v = fmaxf(v, v * slope);
+          v = live ? v : 0.f;
+          ovf |= !(fabsf(v) < kH3ActLimit);
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        char* e_hi = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 0) * 2 + (g & 1)) * N1P + j) + 8 * h;
+        char* e_lo = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 1) * 2 + (g & 1)) * N1P + j) + 8 * h;
+        *reinterpret_cast<half4*>(e_hi) = hi;
+        *reinterpret_cast<half4*>(e_lo) = lo;
+      }
+    }
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
+  zero_acc();
+  __syncthreads();                          // Y1 is complete
+  stamp(3);
+
+  // ================================================================ phase 2: y = c2(Y1) + b2 + x  -- no barrier in the loop
+  for (int cp = 0; cp < NCHUNK; cp += 2) {
+    for_groups([&](auto g_tag) { stage(S0{}, g_tag, cp, w2r, true, nullptr, Y1 + cp * 4 * N1P, N1P, 1); });
+    for_groups([&](auto g_tag) { stage(S1{}, g_tag, cp + 1, w2r, cp + 2 < NCHUNK, nullptr, Y1 + (cp + 1) * 4 * N1P, N1P, 1); });
+  }
+  stamp(4);
+  // ---- wide epilogue (as above): 32 x 32 tiles transposed through a per-wave LDS tile, 16 bytes per lane
+  {
+    constexpr int P = 36;
+    static_assert(THREADS / 64 * 32 * P * 4 <= Y1_ELEMS * 16, "staging tiles must fit the Y1 region");
+    __syncthreads();                                   // every wave is done reading Y1: the staging tiles overlay it
+    float* stg = reinterpret_cast<float*>(lds) + wave * (32 * P);
+    const int lr = lane >> 3, lc = (lane & 7) * 4;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * P + i] = acc[m][n][r] * inv;
+        __builtin_amdgcn_wave_barrier();
+        const int col0 = wc * (WN * 32) + n * 32 + lc;
+        const int pos0 = n0 + col0;
+        const bool ok = col0 < BN_OUT && pos0 < a.T;
+        float4 v[4], rv[4], pv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+          const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+          v[p] = *reinterpret_cast<const float4*>(stg + (lr + 8 * p) * P + lc);
+          rv[p] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          pv[p] = (ok && a.acc2_mode != ACC2_NONE && a.acc2_mode != ACC2_SET) ? *reinterpret_cast<const float4*>(a.y2 + off)
+                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+            const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+            const float bb = a.b2 ? a.b2[co] : 0.f;
+            float o[4] = {v[p].x + bb + rv[p].x, v[p].y + bb + rv[p].y, v[p].z + bb + rv[p].z, v[p].w + bb + rv[p].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pos0 + q < len ? o[q] : 0.f;
+            if (a.y) *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.acc2_mode != ACC2_NONE) {
+              const float pp[4] = {pv[p].x, pv[p].y, pv[p].z, pv[p].w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (a.acc2_mode == ACC2_ADD) o[q] = pp[q] + o[q];
+                else if (a.acc2_mode == ACC2_ADD_DIV) o[q] = (pp[q] + o[q]) / a.acc2_div;
+              }
+              *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+          }
+        }
+      }
+  }
+  stamp(5);
+}
+
 struct PairCfg {
   int C, K, n1, threads, variant, bn_out;
   bool wide;                     // wide epilogue: rows must be 16-byte aligned
   size_t lds;
   void (*kern)(const PairArgs);
 };
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false, int RESPF = 0>
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false, int RESPF = 0, bool OVL = false>
 constexpr PairCfg make_cfg() {
+  constexpr size_t y1 = (size_t)(C / 16) * 4 * (32 * NT + pair_pady(K, TRIM)), as = (size_t)NCS * KKT * 4 * C,
+                   bs = (size_t)NCS * 4 * (32 * NT + pair_halo(K, TRIM));
   return {C, K, 32 * NT, 64 * WR * WC, V, RESPF == 3 ? ((32 * NT - (K - 1)) & ~3) : 32 * NT - (K - 1), RESPF == 3,
-          (size_t)((C / 16) * 4 * (32 * NT + pair_pady(K, TRIM)) + NCS * KKT * 4 * C +
-                   NCS * 4 * (32 * NT + pair_halo(K, TRIM))) * 16,
-          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM, RESPF>};
+          (OVL ? (y1 > bs ? y1 : bs) + as : y1 + as + bs) * 16,
+          resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM, RESPF, OVL>};
+}
+template <int C, int NT, int WR, int WC, int K, int G, int V, bool OVL = false>
+constexpr PairCfg make_adir() {
+  constexpr size_t y1 = (size_t)(C / 16) * 4 * (32 * NT + kPairPadY), bs = (size_t)2 * 4 * (32 * NT + kPairHalo);
+  return {C, K, 32 * NT, 64 * WR * WC, V, (32 * NT - (K - 1)) & ~3, true, (OVL ? y1 : y1 + bs) * 16,
+          resblock_pair_adir_kernel<C, NT, WR, WC, K, G, OVL>};
 }
 // (C, K) instantiations of the RVC v2 decoders (resblock kernels 3 / 7 / 11): 512 threads, one workgroup per CU
 const PairCfg kPair[] = {
@@ -479,6 +851,18 @@ const PairCfg kPair[] = {
     make_cfg<64, 8, 2, 4, 3, 3, 2, 4, false, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 4, false, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 4, false, 3>(),
     make_cfg<128, 6, 4, 3, 3, 3, 1, 4, false, 3>(),  make_cfg<128, 4, 4, 2, 7, 7, 1, 4, false, 3>(),  make_cfg<128, 6, 4, 3, 11, 4, 1, 4, false, 3>(),
     make_cfg<256, 3, 4, 3, 3, 2, 1, 4, false, 3>(),  make_cfg<256, 3, 4, 3, 7, 2, 1, 4, false, 3>(),  make_cfg<256, 3, 4, 3, 11, 2, 1, 4, false, 3>(),
+    // variant 5 (round 4): 8 waves of 64 x 64 (C >= 64) / 32 x 128 (C = 32) on twice as wide tiles, input tile overlaid on Y1
+    make_cfg<32, 32, 1, 8, 3, 3, 2, 5, false, 3, true>(),  make_cfg<32, 32, 1, 8, 7, 7, 1, 5, false, 3, true>(),  make_cfg<32, 32, 1, 8, 11, 11, 1, 5, false, 3, true>(),
+    make_cfg<64, 16, 1, 8, 3, 3, 2, 5, false, 3, true>(),  make_cfg<64, 16, 1, 8, 7, 3, 1, 5, false, 3, true>(),  make_cfg<64, 16, 1, 8, 11, 4, 1, 5, false, 3, true>(),
+    make_cfg<128, 8, 2, 4, 3, 3, 1, 5, false, 3, true>(),  make_cfg<128, 8, 2, 4, 7, 3, 1, 5, false, 3, true>(),  make_cfg<128, 8, 2, 4, 11, 3, 1, 5, false, 3, true>(),
+    // variant 6 (round 4): A-direct (weights from L2 into registers, barrier-free c2 loop), the same wave tiles as variant 4
+    make_adir<32, 16, 1, 8, 3, 3, 6>(),  make_adir<32, 16, 1, 8, 7, 4, 6>(),  make_adir<32, 16, 1, 8, 11, 4, 6>(),
+    make_adir<64, 8, 2, 4, 3, 3, 6>(),   make_adir<64, 8, 2, 4, 7, 4, 6>(),   make_adir<64, 8, 2, 4, 11, 4, 6>(),
+    make_adir<128, 6, 4, 3, 3, 3, 6>(),  make_adir<128, 6, 4, 3, 7, 2, 6>(),  make_adir<128, 6, 4, 3, 11, 2, 6>(),
+    // variant 7: A-direct on 8 waves of 64 x 64 (C >= 64) / 32 x 128 (C = 32), input tiles overlaid on Y1 where needed
+    make_adir<32, 16, 1, 8, 3, 3, 7>(),  make_adir<32, 16, 1, 8, 7, 4, 7>(),  make_adir<32, 16, 1, 8, 11, 4, 7>(),
+    make_adir<64, 16, 1, 8, 3, 2, 7, true>(),  make_adir<64, 16, 1, 8, 7, 2, 7, true>(),  make_adir<64, 16, 1, 8, 11, 2, 7, true>(),
+    make_adir<128, 8, 2, 4, 3, 2, 7, true>(),  make_adir<128, 8, 2, 4, 7, 2, 7, true>(),  make_adir<128, 8, 2, 4, 11, 2, 7, true>(),
     // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
     make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
     make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),

@@ -5,6 +5,7 @@
 //           consecutive MFMAs see different operands (data toggling = the power a real GEMM draws)
 //   f16 L : the same MFMAs fed from LDS, one ds_read_b128 per MFMA (the diet of the fused ResBlock step: six fragment
 //           reads for six MFMAs, resblock.hip)
+//   f16 L2: both operands from LDS, two ds_read_b128 per MFMA (is the LDS 128 or 256 B/clk/CU for 16-byte reads?)
 //   f16 Z : all-zero operands (no toggling: the power floor; what the all-zero-input experiment of round 2 measured)
 // at 1, 2 and 3 waves per SIMD.  Per launch: wall time (HIP events) -> TFLOP/s, and the shader clock the chip held
 // (s_memtime cycles / s_memrealtime 100 MHz ticks, read by wave 0 of every workgroup).  The split-fp16 kernels form
@@ -45,7 +46,7 @@ struct Clocks {
   unsigned long long cyc, ticks;
 };
 
-// MODE 0: registers, random; 1: LDS-fed, random; 2: registers, zeros
+// MODE 0: registers, random; 1: LDS-fed (one read per MFMA), random; 2: registers, zeros; 3: LDS-fed, TWO reads per MFMA
 template <int MODE, int NACC>
 __global__ __launch_bounds__(256) void spin_f16(float* out, Clocks* clk, int iters) {
   __shared__ half8 lds[4 * 2 * 64 * 4];            // [wave][a|b][lane][4 fragments]: 16 B elements, conflict-free per wave
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void spin_f16(float* out, Clocks* clk, int ite
       a[q][e] = MODE == 2 ? (_Float16)0.f : rnd_half(seed);
       b[q][e] = MODE == 2 ? (_Float16)0.f : rnd_half(seed);
     }
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 3) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       lds[((wave * 2 + 0) * 4 + q) * 64 + lane] = a[q];
@@ -79,7 +80,11 @@ __global__ __launch_bounds__(256) void spin_f16(float* out, Clocks* clk, int ite
 #pragma unroll
       for (int i = 0; i < NACC; ++i) {
         half8 av, bv;
-        if (MODE == 1) {
+        if (MODE == 3) {                            // both operands from LDS: what the LDS can feed at most
+          av = lds[((wave * 2 + 0) * 4 + ((i + it) & 3)) * 64 + lane];
+          bv = lds[((wave * 2 + 1) * 4 + ((i >> 1) & 3)) * 64 + lane];
+          asm volatile("" ::: "memory");
+        } else if (MODE == 1) {
           // one 16-byte LDS read per MFMA: A and B fragments alternate (the other operand stays in its register)
           if (i & 1) {
             av = lds[((wave * 2 + 0) * 4 + ((i >> 1) & 3)) * 64 + lane];
@@ -192,6 +197,7 @@ int main() {
     const int it16 = 600000 / wps, it32 = 300000 / wps;
     run("f16 R (registers, random)", spin_f16<0, 8>, wps, it16, 8, F16);
     run("f16 L (1 ds_read_b128/MFMA)", spin_f16<1, 8>, wps, it16, 8, F16);
+    run("f16 L2 (2 ds_read_b128/MFMA)", spin_f16<3, 8>, wps, it16 / 2, 8, F16);
     run("f16 Z (registers, zeros)", spin_f16<2, 8>, wps, it16, 8, F16);
     run("f32   (registers, random)", spin_f32<8>, wps, it32, 8, F32);
   }
