@@ -96,8 +96,14 @@ __device__ __forceinline__ void lds_barrier() {
 // to read the PREVIOUS step's value in one dword q of the 16-byte stores of 16 consecutive lanes -- after s_waitcnt
 // lgkmcnt(0) + s_barrier, a few times per ten thousand steps, never without the co-resident kernel (round 3;
 // tools/check_gru_under_load.py reproduces it: 4-7 distinct results of 24 with b128, 1 of 24 with b32).
+// -DRVCX_GRU_B128=1 rebuilds the round-3 form (natural layout, the four stores merged into one ds_write_b128) so that the
+// reproducer stays alive (tools/check_gru_under_load.py); =2: the same with the array declared aligned(16); 3-6: the
+// round-4 experiments that narrowed it down.
+#ifndef RVCX_GRU_B128
+#define RVCX_GRU_B128 0
+#endif
 template <int NRG>
-__device__ __forceinline__ int part_at(int row) { return (row & 3) * NRG + (row >> 2); }
+__device__ __forceinline__ int part_at(int row) { return RVCX_GRU_B128 ? row : (row & 3) * NRG + (row >> 2); }
 
 union Granule {
   unsigned long long u;
@@ -122,7 +128,11 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
   constexpr int H = GRU_H, GRU_U = G::U, GRU_ROWS = G::ROWS, GRU_RPT = G::RPT, GRU_CPT = CPT, GRU_NCS = G::NCS,
                 GRU_NRG = G::NRG, GRU_THREADS = G::THREADS, GRU_NC = NC;
   __shared__ __attribute__((aligned(16))) float hs[H];
+#if RVCX_GRU_B128 == 2
+  __shared__ __attribute__((aligned(16))) float part[GRU_NCS][GRU_ROWS];
+#else
   __shared__ float part[GRU_NCS][GRU_ROWS];
+#endif
   __shared__ int sfail;
   // workgroup -> (cluster q = dir + 2 b, member c).  Workgroups are dealt round-robin to the 8 XCDs, so with
   // `colocate` the NC members of a cluster are the ids congruent mod 8: they share one XCD and its L2.
@@ -197,17 +207,45 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
         acc[q] = fmaf(w[q][4 * k + 3], hv.w, acc[q]);
       }
     }
+#if RVCX_GRU_B128 == 3          // experiment: natural layout, but four separate ds_write_b32 (the merge into b128 is prevented)
 #pragma unroll
-    for (int q = 0; q < GRU_RPT; ++q) part[cs][q * GRU_NRG + rg] = acc[q];   // four 4-byte stores (see part_at)
+    for (int q = 0; q < GRU_RPT; ++q)
+      asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)&part[cs][rg * GRU_RPT + q]), "v"(acc[q]) : "memory");
+#else
+#pragma unroll
+    for (int q = 0; q < GRU_RPT; ++q) part[cs][part_at<GRU_NRG>(rg * GRU_RPT + q)] = acc[q];   // four 4-byte stores (see part_at)
+#endif
+#if RVCX_GRU_B128 == 5          // experiment: ~64 idle cycles between the counter reaching zero and the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_sleep 1" ::: "memory");
+#endif
+#if RVCX_GRU_B128 == 6          // experiment: the barrier twice
+    lds_barrier();
+#endif
     lds_barrier();
     // ---- gates for the owned units, publish h_t[ju] as a {value, step+1} granule
     if (tid < GRU_U) {
       float sr = 0.f, sz = 0.f, sn = 0.f;
 #pragma unroll
       for (int p = 0; p < GRU_NCS; ++p) {
+#if RVCX_GRU_B128 == 4          // experiment: b128 stores, but every sum read by its own ds_read_b32 (no read2st64 pairs)
+        float pr, pz, pn;
+        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(pr), "=&v"(pz), "=&v"(pn)
+                     : "v"((unsigned)(size_t)&part[p][tid]), "v"((unsigned)(size_t)&part[p][GRU_U + tid]),
+                       "v"((unsigned)(size_t)&part[p][2 * GRU_U + tid])
+                     : "memory");
+        sr += pr;
+        sz += pz;
+        sn += pn;
+#elif RVCX_GRU_B128 == 7        // experiment: b128 stores, compiler-scheduled reads that cannot be paired (volatile)
+        sr += *(volatile float*)&part[p][tid];
+        sz += *(volatile float*)&part[p][GRU_U + tid];
+        sn += *(volatile float*)&part[p][2 * GRU_U + tid];
+#else
         sr += part[p][part_at<GRU_NRG>(tid)];
         sz += part[p][part_at<GRU_NRG>(GRU_U + tid)];
         sn += part[p][part_at<GRU_NRG>(2 * GRU_U + tid)];
+#endif
       }
       const float ghr = sr + bh_r, ghz = sz + bh_z, ghn = sn + bh_n;
       // hardware exp2 / rcp (1-2 ulp): the gate chain is on the serial critical path of every step
