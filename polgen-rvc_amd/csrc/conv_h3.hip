@@ -367,6 +367,14 @@ const H3Cfg kH3[] = {
     // wide 3x3 tiles for the shallow U-Net levels (C = 16/32): the 2*Wp+2 halo is amortised over more outputs
     {32, 256, 320, 1, false, 22.f, 1.10f, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 256, 1, 4, 4, 320, 1, false, true>},
     {32, 512, 320, 1, false, 22.f, 1.15f, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 512, 1, 4, 4, 320, 1, false, true>},
+    // Round 4 measured four more forms of the small-channel 3x3 tile (tools/sweep_unet.py, U-Net levels 0 / 1, B = 1 and 8)
+    // and kept none: 32 x 512 on EIGHT waves (the 2 Wp + 2 halo staged once per 512 outputs instead of once per 128: 51 / 317
+    // us against 41 / 290 for 32 x 128), 32 x 128 with min-waves 4 (the tile already runs four workgroups per CU: 104 VGPRs,
+    // 37 KB of LDS), all nine taps of a chunk in one stage on 4 and on 8 waves (two barriers instead of six: slower than
+    // both), and the 64 x 64 tile forced on the deep levels (faster in the isolated sweep at S = 1, nothing in the model,
+    // where the per-item split-K factor stands).  These launches are bound by the latency chain of a workgroup (load ->
+    // convert -> LDS -> 27 MFMAs -> store, ~10 us of life for 128 outputs), not by staging volume, occupancy or the matrix
+    // pipe: what would help is a persistent kernel that prefetches tile t + 1 under tile t, or a fused ConvBlockRes.
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 }  // namespace
