@@ -423,6 +423,9 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     rtf = a.steps * audio_seconds_per_step / dt
     stage = ctx.last_timing()
+    # retrieval: queries whose neighbours the split-fp16 pre-filter could not certify and that were searched exhaustively
+    # (the slow path: one workgroup reads the whole matrix per query) during warm-up + timed steps; 0 on this workload
+    idx_exhaustive = ctx.index_exhaustive() if c3 else None
     mbs_per_step = None
     if c5 or len(clips) > 1:
         # micro-batches the LAST call of a step formed (c5: one call per voice model)
@@ -500,7 +503,7 @@ def main():
                "value_is": "whole-job aggregate over n_gpus (driver contract); value_per_gpu = value / n_gpus",
                "config": {"workload": wl + "; timed region = H2D of float PCM (pinned host) + all kernels + D2H of int16",
                           "clips_per_step": len(clips), "micro_batch": ctx.micro_batch(mid, n, params),
-                          "micro_batches": mbs_per_step,
+                          "micro_batches": mbs_per_step, "index_exhaustive_queries": idx_exhaustive,
                           "out_samples": got[0] if len(got) == 1 else sum(got), "weights_bcast_bytes": nbytes,
                           "weights_bcast_s": t_bcast, "load_s": t_load},
                "stage_ms": stage,

@@ -174,6 +174,7 @@ int rvcx_create(int device, rvcx_ctx** out) {
     }
     conv_init();
     resblock_pair_init();
+    gemm_init();
     h->c.resblock_streams = !getenv("RVCX_RESBLOCK_STREAMS") || atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
     // RVCX_SERIAL=1: every launch on the one main stream (rocprofv3 kernel durations are then each launch's own)
     h->c.serial_env = getenv("RVCX_SERIAL") && atoi(getenv("RVCX_SERIAL")) != 0;

@@ -315,17 +315,19 @@ double crepe_quantile999(std::vector<float>& a) {
 }
 
 size_t crepe_arena_bytes(const CrepeModel& m, int64_t n, int hop) {
+  // exactly what crepe_forward allocates: per batch of 2 * hop frames the framed input and EVERY layer's conv and pooled
+  // buffers (they stay live until the batch's reset), each rounded up to the arena's 256-byte granule
+  auto al = [](size_t floats) { return (floats * sizeof(float) + 255) & ~size_t(255); };
   const size_t F = (size_t)crepe_frames(n, hop), fb = (size_t)std::min<size_t>(2 * (size_t)hop, F);
-  size_t per_frame = (size_t)CR_PH * CR_TP + (size_t)m.filters[0] * (CR_T1 + CR_T1 / 2);
-  int T = CR_T1 / 2;
-  size_t mx = 0;
-  for (int i = 1; i < 6; ++i) {
-    mx = std::max(mx, (size_t)m.filters[i] * (T + T / 2));
+  size_t batch = al(fb * CR_PH * CR_TP);
+  int T = CR_T1;
+  for (int i = 0; i < 6; ++i) {
+    batch += al(fb * (size_t)m.filters[i] * T);
+    if (i < 5) batch += al(fb * (size_t)m.filters[i] * (T / 2));
     T /= 2;
   }
-  per_frame += 2 * mx;
-  return (fb * per_frame + F * ((size_t)m.in_features + 2 * CR_BINS + 8) + (size_t)n) * sizeof(float) +
-         F * CR_BINS * sizeof(unsigned short) + ((size_t)64 << 20);
+  return batch + al((size_t)m.in_features * F) + 2 * al((size_t)CR_BINS * F) + 3 * al(F) + al((size_t)n) +
+         ((F * CR_BINS * sizeof(unsigned short) + 255) & ~size_t(255)) + ((size_t)16 << 20);
 }
 
 // x: device, n samples of the (already normalised-by-`scale`) signal; writes `pitch` (F frames, Hz) and optionally the

@@ -17,6 +17,7 @@
 // gemm_f32_kernel: the exact-fp32 form (v_mfma_f32_32x32x2_f32) for layers pinned after an fp16-range overflow.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "conv.h"
 #include "conv_device.h"
@@ -301,14 +302,17 @@ void gemm_describe(ConvProfile* p) {
   p->halo[kGemmF32Slot] = 600001;
 }
 
-void gemm_init() {
-  static const bool init = [] {
-    for (const auto& c : kGemm)
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)c.lds));
-    return true;
-  }();
-  (void)init;
+void gemm_init() {      // per DEVICE: a second-GPU context of the same process needs the >64 KB dynamic-LDS attribute too
+  static std::mutex mu;
+  static uint64_t done = 0;
+  int dev = 0;
+  RVCX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  if ((done >> (dev & 63)) & 1) return;
+  for (const auto& c : kGemm)
+    RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)c.lds));
+  done |= 1ull << (dev & 63);
 }
 
 // returns the profile slot of the kernel that ran

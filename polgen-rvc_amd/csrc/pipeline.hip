@@ -480,7 +480,13 @@ void crepe_f0_device(Ctx& c, const float* x, long n, const rvcx_params& p, long 
   RVCX_HIP(hipMemcpyAsync(h.data(), x, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
   RVCX_HIP(hipStreamSynchronize(s));
   const float scale = (float)crepe_quantile999(h);
-  RVCX_CHECK(scale > 0.f && std::isfinite(scale), "crepe: the signal is silent (its 99.9 % quantile is 0)");
+  RVCX_CHECK(std::isfinite(scale), "crepe: non-finite samples in the signal");
+  if (!(scale > 0.f)) {
+    // a silent clip: the reference divides by 0, every frame turns NaN and get_f0_crepe's nan_to_num leaves an all-zero
+    // track (pipeline.py:91,111-118) -- this item's f0 is zero, the rest of the batch goes on
+    RVCX_HIP(hipMemsetAsync(f0raw, 0, (size_t)p_len * sizeof(float), s));
+    return;
+  }
   float* dith = c.arena.alloc<float>((size_t)F);
   if (ex && ex->dither) {
     RVCX_CHECK(ex->dither_n >= F, "crepe: the dither array is shorter than the frame count");

@@ -17,6 +17,7 @@
 // Bs[op][h][N1 + 64], 16-byte elements (8 halves = the k-slice one lane feeds to one MFMA).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "conv.h"
@@ -916,14 +917,17 @@ void resblock_pair_describe(ConvProfile* p) {
   }
 }
 
-void resblock_pair_init() {
-  static const bool init = [] {       // once per process, also when several contexts start on different threads
-    for (const auto& c : kPair)
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)c.lds));
-    return true;
-  }();
-  (void)init;
+void resblock_pair_init() {      // once per device, also when several contexts start on different threads
+  static std::mutex mu;
+  static uint64_t done = 0;
+  int dev = 0;
+  RVCX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  if ((done >> (dev & 63)) & 1) return;
+  for (const auto& c : kPair)
+    RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)c.lds));
+  done |= 1ull << (dev & 63);
 }
 
 void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {

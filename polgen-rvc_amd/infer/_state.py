@@ -29,9 +29,17 @@ def dev_index(device) -> int:
     return device if isinstance(device, int) else 0
 
 
-def context(device) -> "_lib.Context":
+def default_device() -> int:
+    """The GPU of calls that name no device (load_audio): the one this process already serves -- its resident context,
+    else a torchrun-style LOCAL_RANK, else 0.  A rank on cuda:N must not build a second full context on GPU 0."""
+    if _CTX:
+        return next(iter(_CTX))
+    return int(os.environ.get("LOCAL_RANK", "0") or 0)
+
+
+def context(device=None) -> "_lib.Context":
     """One rvcx context per GPU, created on first use."""
-    idx = dev_index(device)
+    idx = default_device() if device is None else dev_index(device)
     if idx not in _CTX:
         _CTX[idx] = _lib.Context(idx)
     return _CTX[idx]

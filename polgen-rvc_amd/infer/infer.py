@@ -185,8 +185,8 @@ def get_vc(device, is_half, config, model_path, cpt=None):
     return cpt, version, net_g, tgt_sr, vc
 
 
-def load_audio(file, sample_rate):
-    """rvc/lib/my_utils.py:5-16: read -> mono mean -> resample -> flatten (float64).  Decoding: infer/audio.py
+def load_audio(file, sample_rate, *, device=None):
+    """rvc/lib/my_utils.py:5-16 (`device`: keyword-only extra, default = the GPU this process already serves): read -> mono mean -> resample -> flatten (float64).  Decoding: infer/audio.py
     (soundfile when installed, RIFF/WAVE otherwise).  The mono mix and the rate conversion run on the GPU in one pass
     (``rvcx_resample_f64``): resampy's "kaiser_best" band-limited interpolation; librosa's current default, soxr_hq, is
     not published as a formula, so this edge stays "parity unpinned" (oracle/audio.py restates what is computed)."""
@@ -195,7 +195,7 @@ def load_audio(file, sample_rate):
         from .audio import read_audio
         audio, sr = read_audio(file)
         if sr != sample_rate:
-            audio = _context("cuda:0").resample(audio, sr, sample_rate)
+            audio = _context(device).resample(audio, sr, sample_rate)
         elif len(audio.shape) > 1:
             audio = np.asarray(audio, np.float64).mean(axis=1)        # librosa.to_mono(audio.T)
     except Exception as error:

@@ -153,3 +153,27 @@ def test_crepe_batch_equals_single_runs(ctx):
         alone = ctx.convert_batch(mid, [c], pi, crepe_dither=[dith[i]])[0]
         assert np.array_equal(alone, together[i]), i
     _lib.lib().rvcx_unload_synth(ctx._h, mid)
+
+
+def test_a_silent_clip_gets_an_all_zero_track_and_the_batch_goes_on(ctx):
+    """np.quantile(|x|, 0.999) of a silent clip is 0 -- the reference divides by it, every frame turns NaN and
+    get_f0_crepe's nan_to_num leaves an all-zero f0 (pipeline.py:91,111-118).  Here the silent item gets exactly that
+    (f0 = 0, coarse = 1) instead of failing the call, and the other item of the batch equals its single run."""
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    seed = 4
+    cfgs = (S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY)
+    ctx.load_hubert(W.hubert_cfg_struct(cfgs[0]), S.hubert_state(cfgs[0], seed))
+    ctx.load_crepe(S.crepe_state("tiny", seed))
+    mid = ctx.load_synth(W.synth_cfg_struct(cfgs[2], cfgs[0]["embed_dim"]), S.synth_state(cfgs[2], seed, input_dim=cfgs[0]["embed_dim"]))
+    try:
+        p = _lib.Params(1.0, 50.0, 1100.0, 0.0, 0.33, 1.0, 0, 1, 6, 38, 41, 9, _lib.F0_CREPE, 0, 128, 0)
+        voiced, silent = S.make_clip(44, 2.0), np.zeros(32000, np.float32)
+        dith = [_dither(ctx.crepe_frames(32000 + 32000, 128), i) for i in range(2)]
+        both = ctx.convert_batch(mid, [voiced, silent], p, crepe_dither=dith)
+        alone = ctx.convert_batch(mid, [voiced], p, crepe_dither=[dith[0]])[0]
+        assert np.array_equal(alone, both[0])
+        assert len(both[1]) > 0 and np.isfinite(both[1].astype(np.float64)).all()
+        coarse, f0 = ctx.get_f0_crepe_x(np.zeros(64000, np.float32), 400, p, dither=dith[1])
+        assert np.all(f0 == 0.0) and np.all(coarse == 1)
+    finally:
+        _lib.lib().rvcx_unload_synth(ctx._h, mid)

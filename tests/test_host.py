@@ -419,3 +419,38 @@ def test_broadcast_refuses_device_regions_on_a_cpu_backend():
             D.broadcast_weights(Ctx(), 0, 0, force=True)
     finally:
         dist.destroy_process_group()
+
+
+def test_calls_that_name_no_device_use_the_gpu_this_process_serves(monkeypatch):
+    """load_audio resampled on a hard-wired "cuda:0" -- a rank serving cuda:N would have built a second full
+    context on GPU 0.  The default device is the resident context's, else LOCAL_RANK, else 0."""
+    import polgen_rvc_amd  # noqa: F401
+    from polgen_rvc_amd.infer import _state
+    monkeypatch.setattr(_state, "_CTX", {})
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert _state.default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert _state.default_device() == 5
+    monkeypatch.setattr(_state, "_CTX", {3: object()})
+    assert _state.default_device() == 3
+    import inspect
+    from polgen_rvc_amd.infer import infer
+    sig = inspect.signature(infer.load_audio)
+    assert list(sig.parameters)[:2] == ["file", "sample_rate"]
+    assert sig.parameters["device"].kind is inspect.Parameter.KEYWORD_ONLY
+
+
+def test_shape_only_placeholders_match_the_real_layouts():
+    """bench.py's ranks != 0 load zeros of the right shapes without drawing random numbers (synthetic.shapes_only)."""
+    import numpy as np
+    from polgen_rvc_amd import synthetic as S
+    real = S.rmvpe_state(S.RMVPE_CFG_TINY, 3)
+    with S.shapes_only():
+        ph = S.rmvpe_state(S.RMVPE_CFG_TINY, 3)
+        ph_s = S.synth_state(S.SYNTH_CFG_TINY, 3, input_dim=128)
+    again = S.rmvpe_state(S.RMVPE_CFG_TINY, 3)
+    assert set(ph) == set(real) and all(ph[k].shape == real[k].shape and ph[k].dtype == real[k].dtype for k in real)
+    assert all(not np.any(v) for k, v in ph.items() if "running_var" not in k and k.endswith(".weight") and v.ndim > 1)
+    assert all(np.array_equal(real[k], again[k]) for k in real)          # the mode does not leak out of the with-block
+    real_s = S.synth_state(S.SYNTH_CFG_TINY, 3, input_dim=128)
+    assert set(ph_s) == set(real_s) and all(ph_s[k].shape == real_s[k].shape for k in real_s)
