@@ -123,14 +123,16 @@ def practical_peak():
     """Measured ceiling of the split-fp16 arithmetic: v_mfma_f32_32x32x16_f16 on RANDOM operands sustains less than the
     dense peak (the chip lowers its clock under the matrix pipes' power draw); profiles/mfma_peak_r04.json is the
     output of tools/mfma_peak.hip on this pool (register-fed and LDS-fed loops, 1-3 waves per SIMD).  Returns
-    (TFLOP/s of three-MFMA products with register-fed operands, the same with one ds_read_b128 per MFMA, source)."""
+    (TFLOP/s of three-MFMA products with register-fed operands, the same with one ds_read_b128 per MFMA, the same for the
+    kernels' own k-step -- two accumulators x three dependent MFMAs, six fragment reads, the wh rebuild -- , source)."""
     path = os.path.join(ROOT, "profiles", PEAK_FILE)
     if not os.path.exists(path):
-        return None, None, None
+        return None, None, None, None
     res = json.load(open(path))["results"]
     reg = max(r["tflops"] for r in res if r["kernel"].startswith("f16 R"))
-    lds = max(r["tflops"] for r in res if r["kernel"].startswith("f16 L"))
-    return reg / 3.0, lds / 3.0, "profiles/" + PEAK_FILE
+    lds = max(r["tflops"] for r in res if r["kernel"].startswith("f16 L ("))
+    kstep = max([r["tflops"] for r in res if r["kernel"].startswith("h3 step")] or [lds])
+    return reg / 3.0, lds / 3.0, kstep / 3.0, "profiles/" + PEAK_FILE
 
 
 def pmc_traffic(tile_name):
@@ -453,16 +455,20 @@ def main():
         traffic, traffic_src = pmc_traffic(dom["tile"])
         h3 = dom["tile"].startswith(("conv_h3", "resblock_pair", "gemm_h3"))
         peak = PEAK_H3_TFLOPS if h3 else PEAK_F32_TFLOPS
-        pp_reg, pp_lds, pp_src = practical_peak() if h3 else (None, None, None)
+        pp_reg, pp_lds, pp_kstep, pp_src = practical_peak() if h3 else (None, None, None, None)
         roofline = {"bound": "mfma", "kernel": dom["tile"], "achieved": achieved,
                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                     "practical_peak": pp_reg, "frac_practical": (achieved / pp_reg) if pp_reg else None,
-                    "practical_peak_lds_fed": pp_lds,
+                    "practical_peak_lds_fed": pp_lds, "practical_peak_kstep": pp_kstep,
+                    "frac_kstep": (achieved / pp_kstep) if pp_kstep else None,
                     "practical_peak_note": (None if not pp_reg else
                                             f"{pp_src}: v_mfma_f32_32x32x16_f16 on random fp16 operands sustains "
                                             f"{3 * pp_reg:.0f} TFLOP/s register-fed ({3 * pp_lds:.0f} with one ds_read_b128 per "
                                             "MFMA) at ~1.6 GHz -- the chip lowers its clock under the matrix pipes' power "
-                                            "draw; a third of that is the ceiling of three-MFMA products on real data"),
+                                            "draw; a third of that is the ceiling of three-MFMA products on real data; "
+                                            f"the kernels' own k-step pattern (six fragment reads + six MFMAs, three of "
+                                            f"them dependent per accumulator) sustains {3 * pp_kstep:.0f} at ~1.43 GHz "
+                                            "(practical_peak_kstep)"),
                     "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (each fp32 product block = 3 fp16 MFMAs of a "
                                   "hi/lo split); 'achieved' counts algorithmic 2*M*N*K conv FLOPs" if h3 else
                                   "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),

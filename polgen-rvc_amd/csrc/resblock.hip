@@ -808,6 +808,348 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_adir_kernel(const 
   stamp(5);
 }
 
+
+// ====================================================================================================================
+// Round 4, third form: SPLIT-PHASE staging.  The weights stay LDS-staged (shared by the waves of the CU: the A-direct
+// form showed the L2 cannot feed every wave separately) but the two s_barriers per stage are gone from the k-loops.
+// The weight tile is a ring of two stage buffers; a wave commits its share of stage s + 1 in the MIDDLE of its own
+// stage s and signals through two monotonic LDS counters:
+//     ready : + 1 per wave when its share of a stage is in LDS      (a stage is readable at  ready >= W * (index + 1))
+//     done  : + 1 per wave when it has issued the last MFMA of a stage (a buffer is writable at done >= W * index)
+// What a wave waits for happened about half a stage ago, so waves drift apart by up to half a stage instead of meeting
+// at a barrier twice per stage: while one converts or commits, the others keep the matrix pipe fed.  The c1 input tile
+// is double-buffered in the (not yet written) Y1 region and follows the same counters.  Same arithmetic order.
+template <int C, int NT, int WR, int WC, int K, int G>
+__global__ __launch_bounds__(64 * WR * WC) void resblock_pair_sp_kernel(const PairArgs a) {
+  constexpr int THREADS = 64 * WR * WC, NW = WR * WC;
+  constexpr int N1 = 32 * NT, N1P = N1 + kPairPadY, WROW = N1 + kPairHalo;
+  constexpr int WM = (C / 32) / WR, WN = NT / WC;
+  constexpr int NCHUNK = C / 16, NG = (K + G - 1) / G, NS = NCHUNK * NG;
+  constexpr int A_ELEMS = G * 4 * C, NA = (A_ELEMS + THREADS - 1) / THREADS;
+  constexpr int B_TASKS = 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
+  constexpr int BN_OUT = (N1 - (K - 1)) & ~3, H2 = (K - 1) / 2;
+  constexpr int Y1_ELEMS = NCHUNK * 4 * N1P, BS_ELEMS = 4 * WROW;
+  static_assert(WM >= 1 && WN >= 1 && WM * WR * 32 == C && WN * WC == NT, "bad tile");
+  constexpr int R0_ELEMS = Y1_ELEMS > 2 * BS_ELEMS ? Y1_ELEMS : 2 * BS_ELEMS;
+  static_assert(G >= 2, "the commit sits behind the first tap of a stage");
+  extern __shared__ uint4 lds[];
+  uint4* Y1 = lds;                                  // [chunk][op][h][N1P]; phase 1: the two input tiles [buf][op][h][WROW]
+  uint4* Bs = Y1;
+  uint4* As = Y1 + R0_ELEMS;                        // [buf][tap][op][h][C]
+  unsigned* cnt = reinterpret_cast<unsigned*>(As + 2 * A_ELEMS);   // {ready, done}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int pad1 = (K - 1) * a.dil / 2;
+  int tile = blockIdx.x;
+  if (a.xcd_order) {
+    const int nt = gridDim.x, xcd = tile & 7, idx = tile >> 3, q = nt >> 3, r = nt & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n0 = tile * BN_OUT;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int wuse = N1 + (K - 1) * a.dil;
+  const int in_base = n0 - H2 - pad1;
+  const float slope = a.slope;
+  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.bs, C * a.cs * 4);
+  const H3Rsrc w1r = h3_rsrc(a.w1, K * NCHUNK * 4 * C * 16);
+  const H3Rsrc w2r = h3_rsrc(a.w2, K * NCHUNK * 4 * C * 16);
+  const int xrow = a.cs * 4;
+  constexpr int slab = 4 * C * 16;
+  constexpr float inv = 1.f / kH3Scale;
+  auto stamp = [&](int k) {
+    if (a.trace && tid == 0) a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + k] = (long long)wall_clock64();
+  };
+  stamp(0);
+  if (a.trace && tid == 0) a.trace[((long)b * gridDim.x + blockIdx.x) * 8 + 6] = tile;
+
+  // ---- the two counters: one lane per wave adds, every wave polls (a broadcast LDS read)
+  auto arrive = [&](int which) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS stores / fragment reads are performed
+#endif
+    if (lane == 0) __hip_atomic_fetch_add(&cnt[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_for = [&](int which, unsigned target) {
+    unsigned spins = 0;           // bounded: a protocol bug must end in wrong numbers (the tests see them), not in a hung GPU
+    while (__hip_atomic_load(&cnt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1u << 20))
+      __builtin_amdgcn_s_sleep(1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+  };
+
+  f32x16 acc[WM][WN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  // ---- weight staging: element e = tid + THREADS j -> (tap kkl, op, h, co) of one stage
+  int a_kkl[NA], a_off[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int e = tid + THREADS * j;
+    const int co = e % C, rest = e / C;              // rest = (kkl*2 + op)*2 + h
+    a_kkl[j] = rest / 4;
+    a_off[j] = e < A_ELEMS ? ((rest % 4) * C + co) * 16 : kH3Oob;
+  }
+  uint4 ra[NA];
+  auto fetch_a = [&](const H3Rsrc& wres, int chunk, int g) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int kk = g * G + a_kkl[j];
+      const bool ok = a_off[j] != kH3Oob && kk < K;
+      ra[j] = h3_load4(wres, ok ? (kk * NCHUNK + chunk) * slab + a_off[j] : kH3Oob);
+    }
+  };
+  auto commit_a = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (NA * THREADS == A_ELEMS || tid + THREADS * j < A_ELEMS) As[buf * A_ELEMS + tid + THREADS * j] = ra[j];
+  };
+  // ---- input tile staging (phase 1)
+  int b_off[NBT], b_row[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) {
+    const int t = tid + THREADS * j;
+    const int hh = t / WROW, p = t - hh * WROW;
+    const int pos = in_base + p;
+    b_row[j] = hh * 8;
+    b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len) ? pos * 4 : kH3Oob;
+  }
+  float rb[NBT][8];
+  bool ovf = false;
+  auto fetch_b = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int row0 = (chunk * 16 + b_row[j]) * xrow;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
+    }
+  };
+  auto commit_b = [&](int buf) {
+    uint4* Bd = Bs + buf * BS_ELEMS;
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + THREADS * j;
+      if (NBT * THREADS == B_TASKS || t < B_TASKS) {
+        half8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v = rb[j][q];
+          v = v > 0.f ? v : v * slope;
+          ovf |= !(fabsf(v) < kH3ActLimit);
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        const int hh = t / WROW, p = t - hh * WROW;
+        Bd[(0 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
+        Bd[(1 * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+      }
+    }
+  };
+
+  // the k-steps of one stage: TAPS taps; `mid` runs behind the MFMAs of the first tap (the commit of the next stage)
+  auto compute = [&](auto taps_tag, const uint4* Ab, const uint4* Bt, int pitch, int kk0, int tap_step, auto&& mid) {
+    constexpr int TAPS = decltype(taps_tag)::value;
+    half8 af[2][2][WM], bf[2][2][WN];
+    auto load = [&](int buf, int s) {
+      const int tp = (kk0 + s) * tap_step;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        af[buf][0][m] = __builtin_bit_cast(half8, Ab[((s * 2 + 0) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+        af[buf][1][m] = __builtin_bit_cast(half8, Ab[((s * 2 + 1) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+      }
+#pragma unroll
+      for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          bf[buf][op][n] = __builtin_bit_cast(half8, Bt[(op * 2 + h) * pitch + wc * (WN * 32) + n * 32 + i + tp]);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int s = 0; s < TAPS; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < TAPS) load(cur ^ 1, s + 1);
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        const half8 wh = af[cur][0][m] * (_Float16)(1.f / kH3Scale);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          acc[m][n] = h3_mfma(af[cur][0][m], bf[cur][0][n], acc[m][n]);
+          acc[m][n] = h3_mfma(wh, bf[cur][1][n], acc[m][n]);
+          acc[m][n] = h3_mfma(af[cur][1][m], bf[cur][0][n], acc[m][n]);
+        }
+      }
+      if (s == 0) mid();
+    }
+  };
+
+  unsigned n_ready = 0, n_done = 0;        // this wave's wait targets so far (monotonic over the whole tile)
+  // ================================================================ phase 1
+  if (tid < 2) cnt[tid] = 0;
+  zero_acc();
+  fetch_b(0);
+  fetch_a(w1r, 0, 0);
+  __syncthreads();                           // counters are zero
+  commit_b(0);
+  commit_a(0);
+  arrive(0);                                 // stage 0 (and input tile 0) committed by this wave
+  if (NCHUNK > 1) fetch_b(1);
+  {
+    // registers hold: ra = weights of the stage to be committed next (stage sidx + 1), rb = input of chunk + 1
+    // next stage of (chunk, g): (chunk, g + 1) or (chunk + 1, 0); behind the last stage of phase 1: w2's (0, 0)
+    fetch_a(w1r, 1 / NG, 1 % NG);
+  }
+  stamp(1);
+  int sidx = 0;
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    for_each_group<0, NG>([&](auto g_tag) {
+      constexpr int GG = decltype(g_tag)::value;
+      constexpr int TAPS = (NG > 1 && GG == NG - 1) ? K - (NG - 1) * G : G;
+      const int buf = sidx & 1;
+      n_ready += NW;
+      wait_for(0, n_ready);
+      compute(std::integral_constant<int, TAPS>{}, As + buf * A_ELEMS, Bs + (chunk & 1) * BS_ELEMS, WROW, GG * G, a.dil, [&]() {
+        // ---- middle of the stage: stage sidx + 1 goes to the other weight buffer (its last readers ran stage sidx - 1)
+        wait_for(1, n_done);
+        commit_a(buf ^ 1);
+        if (GG == 0 && chunk + 1 < NCHUNK) commit_b((chunk + 1) & 1);     // last read during chunk - 1: long over
+        arrive(0);
+        // refill the registers: the stage after the next one; the input of the chunk after the next one
+        const int t2 = chunk * NG + GG + 2;                                // the stage after the next one
+        if (t2 < NS) fetch_a(w1r, t2 / NG, t2 % NG);
+        else fetch_a(w2r, (t2 - NS) / NG, (t2 - NS) % NG);                // ... of phase 2 (its stage 0 or 1)
+        if (GG == 0 && chunk + 2 < NCHUNK) fetch_b(chunk + 2);
+      });
+      arrive(1);
+      n_done += NW;
+      ++sidx;
+    });
+  }
+  // here: every stage of phase 1 issued; As[sidx & 1] holds (or will hold) phase 2's stage 0, committed in the middle of
+  // the last stage; ra holds phase 2's stage 1
+  stamp(2);
+  __syncthreads();                           // every wave is done reading the input tiles: Y1 may overwrite them
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      const int c_t = wr * (WM * 32) + m * 32;
+      const int j = wc * (WN * 32) + n * 32 + i;
+      const int pos1 = n0 - H2 + j;
+      const bool live = pos1 >= 0 && pos1 < len;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const int cg = c_t + 8 * g;
+        half4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[m][n][4 * g + q] * inv + (a.b1 ? a.b1[cg + 4 * h + q] : 0.f);
+          v = fmaxf(v, v * slope);
+          v = live ? v : 0.f;
+          ovf |= !(fabsf(v) < kH3ActLimit);
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        char* e_hi = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 0) * 2 + (g & 1)) * N1P + j) + 8 * h;
+        char* e_lo = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 1) * 2 + (g & 1)) * N1P + j) + 8 * h;
+        *reinterpret_cast<half4*>(e_hi) = hi;
+        *reinterpret_cast<half4*>(e_lo) = lo;
+      }
+    }
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
+  zero_acc();
+  __syncthreads();                           // Y1 is complete
+  stamp(3);
+
+  // ================================================================ phase 2 (the stage counter runs on: sidx = NS ...)
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    for_each_group<0, NG>([&](auto g_tag) {
+      constexpr int GG = decltype(g_tag)::value;
+      constexpr int TAPS = (NG > 1 && GG == NG - 1) ? K - (NG - 1) * G : G;
+      const int buf = sidx & 1;
+      const bool has_next = !(chunk + 1 >= NCHUNK && GG + 1 >= NG);
+      n_ready += NW;
+      wait_for(0, n_ready);
+      compute(std::integral_constant<int, TAPS>{}, As + buf * A_ELEMS, Y1 + chunk * 4 * N1P, N1P, GG * G, 1, [&]() {
+        if (has_next) {
+          wait_for(1, n_done);
+          commit_a(buf ^ 1);
+          arrive(0);
+          const int t2 = chunk * NG + GG + 2;
+          if (t2 < NS) fetch_a(w2r, t2 / NG, t2 % NG);
+        }
+      });
+      arrive(1);
+      n_done += NW;
+      ++sidx;
+    });
+  }
+  stamp(4);
+  {
+    constexpr int P = 36;
+    static_assert(THREADS / 64 * 32 * P * 4 <= Y1_ELEMS * 16, "staging tiles must fit the Y1 region");
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(lds) + wave * (32 * P);
+    const int lr = lane >> 3, lc = (lane & 7) * 4;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * P + i] = acc[m][n][r] * inv;
+        __builtin_amdgcn_wave_barrier();
+        const int col0 = wc * (WN * 32) + n * 32 + lc;
+        const int pos0 = n0 + col0;
+        const bool ok = col0 < BN_OUT && pos0 < a.T;
+        float4 v[4], rv[4], pv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+          const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+          v[p] = *reinterpret_cast<const float4*>(stg + (lr + 8 * p) * P + lc);
+          rv[p] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          pv[p] = (ok && a.acc2_mode != ACC2_NONE && a.acc2_mode != ACC2_SET) ? *reinterpret_cast<const float4*>(a.y2 + off)
+                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+            const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+            const float bb = a.b2 ? a.b2[co] : 0.f;
+            float o[4] = {v[p].x + bb + rv[p].x, v[p].y + bb + rv[p].y, v[p].z + bb + rv[p].z, v[p].w + bb + rv[p].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pos0 + q < len ? o[q] : 0.f;
+            if (a.y) *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.acc2_mode != ACC2_NONE) {
+              const float pp[4] = {pv[p].x, pv[p].y, pv[p].z, pv[p].w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (a.acc2_mode == ACC2_ADD) o[q] = pp[q] + o[q];
+                else if (a.acc2_mode == ACC2_ADD_DIV) o[q] = (pp[q] + o[q]) / a.acc2_div;
+              }
+              *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+          }
+        }
+      }
+  }
+  stamp(5);
+}
+
 struct PairCfg {
   int C, K, n1, threads, variant, bn_out;
   bool wide;                     // wide epilogue: rows must be 16-byte aligned
@@ -827,6 +1169,13 @@ constexpr PairCfg make_adir() {
   constexpr size_t y1 = (size_t)(C / 16) * 4 * (32 * NT + kPairPadY), bs = (size_t)2 * 4 * (32 * NT + kPairHalo);
   return {C, K, 32 * NT, 64 * WR * WC, V, (32 * NT - (K - 1)) & ~3, true, (OVL ? y1 : y1 + bs) * 16,
           resblock_pair_adir_kernel<C, NT, WR, WC, K, G, OVL>};
+}
+template <int C, int NT, int WR, int WC, int K, int G, int V>
+constexpr PairCfg make_sp() {
+  constexpr size_t y1 = (size_t)(C / 16) * 4 * (32 * NT + kPairPadY), bs2 = (size_t)2 * 4 * (32 * NT + kPairHalo),
+                   as = (size_t)2 * G * 4 * C;
+  return {C, K, 32 * NT, 64 * WR * WC, V, (32 * NT - (K - 1)) & ~3, true, ((y1 > bs2 ? y1 : bs2) + as) * 16 + 64,
+          resblock_pair_sp_kernel<C, NT, WR, WC, K, G>};
 }
 // (C, K) instantiations of the RVC v2 decoders (resblock kernels 3 / 7 / 11): 512 threads, one workgroup per CU
 const PairCfg kPair[] = {
@@ -864,6 +1213,10 @@ const PairCfg kPair[] = {
     make_adir<32, 16, 1, 8, 3, 3, 7>(),  make_adir<32, 16, 1, 8, 7, 4, 7>(),  make_adir<32, 16, 1, 8, 11, 4, 7>(),
     make_adir<64, 16, 1, 8, 3, 2, 7, true>(),  make_adir<64, 16, 1, 8, 7, 2, 7, true>(),  make_adir<64, 16, 1, 8, 11, 2, 7, true>(),
     make_adir<128, 8, 2, 4, 3, 2, 7, true>(),  make_adir<128, 8, 2, 4, 7, 2, 7, true>(),  make_adir<128, 8, 2, 4, 11, 2, 7, true>(),
+    // variant 8 (round 4): split-phase staging -- no s_barrier in the k-loops, LDS counters instead (see the kernel)
+    make_sp<32, 16, 1, 8, 3, 3, 8>(),  make_sp<32, 16, 1, 8, 7, 4, 8>(),  make_sp<32, 16, 1, 8, 11, 4, 8>(),
+    make_sp<64, 8, 2, 4, 3, 3, 8>(),   make_sp<64, 8, 2, 4, 7, 4, 8>(),   make_sp<64, 8, 2, 4, 11, 4, 8>(),
+    make_sp<128, 6, 4, 3, 3, 3, 8>(),  make_sp<128, 6, 4, 3, 7, 3, 8>(),  make_sp<128, 6, 4, 3, 11, 3, 8>(),
     // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
     make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
     make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),

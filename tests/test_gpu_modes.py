@@ -46,10 +46,10 @@ def test_channel_first_linear_mode_passes_the_reference_goldens():
     _run_mode({"RVCX_GEMM": "0"})
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "5", "6", "7"])
+@pytest.mark.parametrize("variant", ["1", "2", "5", "6", "7", "8"])
 def test_alternative_fused_resblock_tiles_are_bit_identical_too(variant):
     """RVCX_PAIR_VARIANT selects other forms of the fused ResBlock step (2: small tiles, two workgroups per CU; 5: 8 waves
     of 64 x 64 on 256-position tiles with the input tile overlaid on Y1; 6 / 7: weights straight from L2 into registers,
-    barrier-free c2 loop -- round-4 experiments): the k-order is the same, so each must equal the two conv
+    barrier-free c2 loop; 8: split-phase staging on LDS counters, no s_barrier in the k-loops -- round-4 experiments): the k-order is the same, so each must equal the two conv
     launches bit for bit and torch within fp32 rounding."""
     _run_mode({"RVCX_PAIR_VARIANT": variant}, "test_gpu_conv.py", "fused_resblock", "10 passed")

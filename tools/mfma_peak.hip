@@ -6,6 +6,8 @@
 //   f16 L : the same MFMAs fed from LDS, one ds_read_b128 per MFMA (the diet of the fused ResBlock step: six fragment
 //           reads for six MFMAs, resblock.hip)
 //   f16 L2: both operands from LDS, two ds_read_b128 per MFMA (is the LDS 128 or 256 B/clk/CU for 16-byte reads?)
+//   h3    : the k-step of the split-fp16 kernels (two accumulators x three dependent MFMAs, six LDS reads per six MFMAs),
+//           the dependent MFMAs back to back or interleaved
 //   f16 Z : all-zero operands (no toggling: the power floor; what the all-zero-input experiment of round 2 measured)
 // at 1, 2 and 3 waves per SIMD.  Per launch: wall time (HIP events) -> TFLOP/s, and the shader clock the chip held
 // (s_memtime cycles / s_memrealtime 100 MHz ticks, read by wave 0 of every workgroup).  The split-fp16 kernels form
@@ -115,6 +117,66 @@ __global__ __launch_bounds__(256) void spin_f16(float* out, Clocks* clk, int ite
   }
 }
 
+// The accumulation pattern of the split-fp16 kernels: TWO accumulators per wave, THREE dependent MFMAs on each per k-step
+// (hh, hl, lh), fed from LDS with 6 reads per 6 MFMAs.  DEP 1: the three MFMAs of an accumulator back to back (what the
+// compiler emits); DEP 0: the two accumulators interleaved (a0 a1 a0 a1 a0 a1).
+template <int DEP>
+__global__ __launch_bounds__(256) void spin_h3(float* out, Clocks* clk, int iters) {
+  __shared__ half8 lds[4 * 6 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned seed = 99u + 977u * (blockIdx.x * 256 + tid);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rnd_half(seed);
+    lds[(wave * 6 + q) * 64 + lane] = v;
+  }
+  __syncthreads();
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc0[j] = acc1[j] = 0.f;
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+    const half8 a0 = lds[(wave * 6 + 0) * 64 + lane], a1 = lds[(wave * 6 + 1) * 64 + lane];
+    const half8 b00 = lds[(wave * 6 + 2) * 64 + lane], b01 = lds[(wave * 6 + 3) * 64 + lane];
+    const half8 b10 = lds[(wave * 6 + 4) * 64 + lane], b11 = lds[(wave * 6 + 5) * 64 + lane];
+    asm volatile("" ::: "memory");
+    const half8 wh = a0 * (_Float16)(1.f / 256.f);
+    if (DEP) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b00, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b10, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b00, acc0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b01, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b11, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b01, acc1, 0, 0, 0);
+    } else {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b00, acc0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b01, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b10, acc0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b11, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b00, acc0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b01, acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += acc0[j] + acc1[j];
+  out[blockIdx.x * 256 + tid] = s;
+  if (tid == 0) {
+    clk[blockIdx.x].cyc = c1 - c0;
+    clk[blockIdx.x].ticks = w1 - w0;
+  }
+}
+
 template <int NACC>
 __global__ __launch_bounds__(256) void spin_f32(float* out, Clocks* clk, int iters) {
   unsigned seed = 7654321u + 31u * (blockIdx.x * 256 + threadIdx.x);
@@ -200,6 +262,8 @@ int main() {
     run("f16 L2 (2 ds_read_b128/MFMA)", spin_f16<3, 8>, wps, it16 / 2, 8, F16);
     run("f16 Z (registers, zeros)", spin_f16<2, 8>, wps, it16, 8, F16);
     run("f32   (registers, random)", spin_f32<8>, wps, it32, 8, F32);
+    run("h3 step, 3 dependent MFMAs back to back", spin_h3<1>, wps, it16, 6, F16);
+    run("h3 step, two accumulators interleaved", spin_h3<0>, wps, it16, 6, F16);
   }
   printf("{\"tool\": \"tools/mfma_peak.hip\", \"results\": [");
   for (size_t i = 0; i < g_results.size(); ++i) {
