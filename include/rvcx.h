@@ -222,7 +222,7 @@ int rvcx_convert_batch_ex(rvcx_ctx*, int model_id, int B, const void* const* wav
 /* utterances of n samples converted per launch sequence (memory-bounded; RVCX_MAX_BATCH, RVCX_ARENA_GB) */
 int rvcx_micro_batch(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* The sample count whose launch geometry an n-sample utterance is converted with (>= n): utterances with equal values
- * share micro-batches.  An uncut rmvpe clip: the longest clip of its length class; otherwise n itself. */
+ * share micro-batches.  An uncut rmvpe / mangio-crepe clip: the longest clip of its length class; otherwise n itself. */
 int64_t rvcx_bucket_length(rvcx_ctx*, int model_id, int64_t n, const rvcx_params* p);
 /* Member counts of the micro-batches the last rvcx_convert_batch* call of this context formed (in launch order);
  * returns their number (counts receives at most cap of them). */

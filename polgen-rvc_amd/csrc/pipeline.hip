@@ -432,7 +432,8 @@ int bucket_frames() {
 // the sample count whose geometry an n-sample utterance is run with (>= n)
 long bucket_length(long n, const rvcx_params& p, const Geometry& g) {
   const int cf = bucket_frames();
-  if (cf == 0 || p.f0_method != RVCX_F0_RMVPE || n + 160 > g.t_max) return n;   // cut clips keep their own geometry
+  // cut clips keep their own geometry; FCPE's network takes equal lengths only (crepe runs one item at a time anyway)
+  if (cf == 0 || p.f0_method == RVCX_F0_FCPE || n + 160 > g.t_max) return n;
   const long k = ((n + 2 * g.t_pad) / 160) / cf;
   return (k + 1) * cf * 160 - 1 - 2 * g.t_pad;          // the longest clip whose padded frame count is (k + 1) cf - 1
 }
@@ -505,15 +506,16 @@ long get_f0_device(Ctx& c, const float* apad, long n_pad, const rvcx_params& p, 
   // VC.get_f0 (pipeline.py:132-201) on already reflect-padded signals (B, n_pad); coarse / f0 rows of out_stride
   const long F = 1 + n_pad / 160, p_len = n_pad / 160;
   check_f0_backend(c, p);
-  RVCX_CHECK(!ns_host || p.f0_method == RVCX_F0_RMVPE, "get_f0: ragged batches are an rmvpe feature");
+  RVCX_CHECK(!ns_host || p.f0_method != RVCX_F0_FCPE, "get_f0: ragged batches are an rmvpe / mangio-crepe feature");
   float* f0raw = c.arena.alloc<float>((size_t)B * F);
   if (p.f0_method == RVCX_F0_CREPE) {   // pipeline.py:151-152: get_f0_crepe(x, f0_min, f0_max, p_len, hop_length)
     if (mid) (*mid)();
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < B; ++b) {      // one item at a time, each at ITS OWN length (rows stay n_pad apart)
       const size_t mark = c.arena.mark();
-      crepe_f0_device(c, apad + (size_t)b * n_pad, n_pad, p, p_len, extra ? extra + b : nullptr, f0raw + (size_t)b * F, s);
+      const long nb = ns_host ? ns_host[b] : n_pad, pl = nb / 160;
+      crepe_f0_device(c, apad + (size_t)b * n_pad, nb, p, pl, extra ? extra + b : nullptr, f0raw + (size_t)b * F, s);
       c.arena.reset(mark);
-      launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)p_len,
+      launch_f0_coarse(f0raw + (size_t)b * F, f0 + (size_t)b * out_stride, coarse + (size_t)b * out_stride, (int)pl,
                        p.pitch, p.f0_min, p.f0_max, s);
     }
     return p_len;

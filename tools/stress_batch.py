@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Stress of the pipelined batch path: many utterances of random lengths (equal lengths grouped into micro-batches of
-different sizes, long clips cut into chunks), both F0 back-ends, retrieval on / off -- every utterance of the batched
-call must be bit-identical to converting it alone.  usage: stress_batch.py [rounds=3]"""
+"""Stress of the pipelined batch path: many utterances of random lengths under two chunk geometries -- (1,1,2,3): most
+clips are cut into chunks and only equal lengths share a micro-batch; (1,6,38,41): nothing is cut and the lengths fall
+into ragged length classes -- both F0 back-ends, retrieval on / off: every utterance of the batched call must be
+bit-identical to converting it alone.  usage: stress_batch.py [rounds=3]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,22 +23,25 @@ for r in range(rounds):
     lens = list(rng.choice([1.3, 1.9, 2.6, 3.3, 5.1, 7.7], size=20)) + [float(rng.uniform(1.2, 9.0)) for _ in range(6)]
     rng.shuffle(lens)
     clips = [S.make_clip(100 * r + i, float(t)) for i, t in enumerate(lens)]
-    for method in (_lib.F0_RMVPE, _lib.F0_FCPE):
-        for index_rate in (0.0, 0.6):
-            if index_rate:
-                ctx.load_index(S.make_index(1024, hcfg["embed_dim"], r))
-            p = _lib.Params(1.0, 50.0, 1100.0, index_rate, 0.33, 0.7, 0, 1, 1, 2, 3, 40 + r)
-            p.f0_method = method
-            batch = ctx.convert_batch(mid, clips, p)
-            for i, c in enumerate(clips):
-                q = _lib.Params(1.0, 50.0, 1100.0, index_rate, 0.33, 0.7, 0, 1, 1, 2, 3, 40 + r + i)
-                q.f0_method = method
-                alone = ctx.convert_batch(mid, [c], q)[0]
-                if not np.array_equal(alone, batch[i]):
-                    bad += 1
-                    print(f"MISMATCH round {r} method {method} index {index_rate} clip {i} len {lens[i]:.2f}", flush=True)
-            if index_rate:
-                ctx.load_index(None)
-    print(f"round {r}: {len(clips)} clips x 4 configurations checked, mismatches so far {bad}", flush=True)
+    for geo in ((1, 1, 2, 3), (1, 6, 38, 41)):
+        for method in (_lib.F0_RMVPE, _lib.F0_FCPE):
+            for index_rate in (0.0, 0.6):
+                if index_rate:
+                    ctx.load_index(S.make_index(1024, hcfg["embed_dim"], r))
+                p = _lib.Params(1.0, 50.0, 1100.0, index_rate, 0.33, 0.7, 0, *geo, 40 + r)
+                p.f0_method = method
+                batch = ctx.convert_batch(mid, clips, p)
+                mbs = ctx.last_micro_batches()
+                for i, c in enumerate(clips):
+                    q = _lib.Params(1.0, 50.0, 1100.0, index_rate, 0.33, 0.7, 0, *geo, 40 + r + i)
+                    q.f0_method = method
+                    alone = ctx.convert_batch(mid, [c], q)[0]
+                    if not np.array_equal(alone, batch[i]):
+                        bad += 1
+                        print(f"MISMATCH round {r} geometry {geo} method {method} index {index_rate} clip {i} len {lens[i]:.2f}", flush=True)
+                if index_rate:
+                    ctx.load_index(None)
+                print(f"  round {r} geometry {geo} method {method} index {index_rate}: micro-batches {sorted(mbs, reverse=True)}", flush=True)
+    print(f"round {r}: {len(clips)} clips x 8 configurations checked, mismatches so far {bad}", flush=True)
 print("STRESS_OK" if bad == 0 else f"STRESS_FAILED {bad}")
 sys.exit(1 if bad else 0)
