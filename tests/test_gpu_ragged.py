@@ -139,3 +139,23 @@ def test_cut_clips_keep_equal_length_batches(ctx):
     for i, c in enumerate(clips):
         alone = ctx.convert_batch(mid, [c], _params(geo=geo, seed=5 + i))[0]
         assert np.array_equal(alone, pcm[i]), i
+
+
+def test_the_longest_member_of_a_class_takes_both_paths_to_the_same_bits(ctx):
+    """A clip whose length IS its class's geometry runs without length arrays when it is alone (nothing to mask) and with
+    them when a shorter clip shares its micro-batch: the masks are no-ops for it, the bits must not move.  Also the
+    neighbour one sample shorter, and a class of its own one sample longer."""
+    mid = _load(ctx, 7)
+    p = _params(volume_envelope=0.5)
+    top = ctx.bucket_length(mid, 24000, p)
+    assert top > 24000 and ctx.bucket_length(mid, top, p) == top and ctx.bucket_length(mid, top + 1, p) > top + 1
+    lens = [top, 24000, top - 1, top + 1]
+    clips = [_clip(500 + i, n) for i, n in enumerate(lens)]
+    pcm, f32 = ctx.convert_batch(mid, clips, p, want_f32=True)
+    assert sorted(ctx.last_micro_batches()) == [1, 3]
+    for i, c in enumerate(clips):
+        a_pcm, a_f32 = ctx.convert_batch(mid, [c], _params(volume_envelope=0.5, seed=5 + i), want_f32=True)
+        assert np.array_equal(a_f32[0], f32[i]) and np.array_equal(a_pcm[0], pcm[i]), i
+    # the full-length clip alone really took the mask-free path: a batch of two of them is not ragged either
+    two = ctx.convert_batch(mid, [clips[0], clips[0]], p)
+    assert ctx.last_micro_batches() == [2] and np.array_equal(two[0], pcm[0])
