@@ -268,20 +268,30 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* pd, const int
   }
 }
 
-// the exhaustive exact search of the queries rescore_kernel could not certify (one block per query; returns at once
-// for the others): 16 groups of 16 lanes walk the rows (of the query's inverted list when the index has lists)
+// The exact search of the queries rescore_kernel could not certify (ties, duplicated rows -- e.g. the silence frames a
+// real RVC index repeats; one block per query, returns at once for the others).  Round 4: not every row is
+// re-scored -- 200 MB of reads per query at 65 536 x 768 -- but only those that can still be among the best 8: a row whose
+// exact distance is <= the 8th exact distance found so far has an APPROXIMATE distance <= that + E (E: the error bound
+// rescore_kernel certifies with), and the approximate distances of all rows are still in memory (`dots`).  The scan of
+// that column costs N x 4 bytes per query (768x less); the survivors are re-scored with the same dot routine and ordered
+// by (distance, row id), so the result is what the exhaustive scan gives.  More than kMaxCand survivors: the full scan.
+constexpr int kMaxCand = 4096;
 __global__ __launch_bounds__(256) void exhaustive_kernel(const int* flag, const float* __restrict__ rows,
                                                          const float* __restrict__ bn, const float* __restrict__ qn,
                                                          const float* feats, int dim, int T, long N,
                                                          const int* __restrict__ assign, const int* __restrict__ qlist,
-                                                         float* fd, int* fi, int* counter) {
+                                                         float* fd, int* fi, int* counter, const float* __restrict__ dots,
+                                                         float max_norm) {
   const int t = blockIdx.x, tid = threadIdx.x;
   if (!flag[t]) return;
   if (tid == 0 && counter) atomicAdd(counter, 1);
   __shared__ float qs[kMaxDim];
   __shared__ float sd[16][TOPK];
   __shared__ int si[16][TOPK];
+  __shared__ int cand[kMaxCand];
+  __shared__ int ncand;
   for (int c = tid; c < dim; c += 256) qs[c] = feats[(long)c * T + t];
+  if (tid == 0) ncand = 0;
   __syncthreads();
   const int g = tid >> 4, l = tid & 15;
   const int mylist = qlist ? qlist[t] : -1;
@@ -292,10 +302,33 @@ __global__ __launch_bounds__(256) void exhaustive_kernel(const int* flag, const 
     bi[k] = -1;
   }
   const float q = qn[t];
-  for (long r = g; r < N; r += 16) {
-    if (assign && assign[r] != mylist) continue;
-    const float dot = dot16(qs, rows + r * dim, dim, l);
-    ordered_insert(bd, bi, fmaxf(q + bn[r] - 2.f * dot, 0.f), (int)r);
+  bool full = dots == nullptr;
+  if (!full) {
+    const float sq = sqrtf(q) + sqrtf(max_norm);
+    const float thr = fd[(long)t * TOPK + TOPK - 1] + 1.52587890625e-5f * sq * sq;     // 8th exact distance so far + E
+    for (long r = tid; r < N; r += 256) {
+      if (assign && assign[r] != mylist) continue;
+      const float ap = fmaxf(q + bn[r] - 2.f * dots[r * T + t], 0.f);
+      if (ap <= thr) {
+        const int k = atomicAdd(&ncand, 1);
+        if (k < kMaxCand) cand[k] = (int)r;
+      }
+    }
+    __syncthreads();
+    full = ncand > kMaxCand;
+  }
+  if (full) {
+    for (long r = g; r < N; r += 16) {
+      if (assign && assign[r] != mylist) continue;
+      const float dot = dot16(qs, rows + r * dim, dim, l);
+      ordered_insert(bd, bi, fmaxf(q + bn[r] - 2.f * dot, 0.f), (int)r);
+    }
+  } else {
+    for (int c = g; c < ncand; c += 16) {          // the order candidates were collected in does not matter: (d, id) is total
+      const long r = cand[c];
+      const float dot = dot16(qs, rows + r * dim, dim, l);
+      ordered_insert(bd, bi, fmaxf(q + bn[r] - 2.f * dot, 0.f), (int)r);
+    }
   }
   if (l == 0)
     for (int k = 0; k < TOPK; ++k) {
@@ -399,7 +432,7 @@ void index_blend(Ctx& c, const IndexData& ix, float* feats_ct, int T, float inde
   hipLaunchKernelGGL(rescore_kernel, dim3(T), dim3(256), 0, s, pd, pi, SPLITS, ix.rows, ix.norms, qn, feats_ct, ix.dim, T,
                      ix.max_norm, fd, fi, flag);
   hipLaunchKernelGGL(exhaustive_kernel, dim3(T), dim3(256), 0, s, flag, ix.rows, ix.norms, qn, feats_ct, ix.dim, T,
-                     (long)ix.n, ix.assign, qlist, fd, fi, ix.exhaustive);
+                     (long)ix.n, ix.assign, qlist, fd, fi, ix.exhaustive, dots, ix.max_norm);
   hipLaunchKernelGGL(blend_kernel, dim3(T), dim3(256), 0, s, fd, fi, ix.rows, (long)ix.n, feats_ct, ix.dim, T, index_rate,
                      (float)(1.0 - (double)index_rate), reinterpret_cast<long long*>(ids), dist);
   RVCX_HIP(hipGetLastError());

@@ -187,6 +187,19 @@ def test_index_with_duplicated_rows_is_searched_exhaustively_and_exactly(ctx):
     ctx.load_index(big2)
     out, ids, dist = ctx.index_blend(q, 0.5)
     assert ctx.index_exhaustive() == 0 and (ids == OP.index_blend(q, big2, 0.5)[1]).all()
+    # round 4: uncertified queries re-score only the rows whose APPROXIMATE distance can still reach the best 8 (at most
+    # 4096 of them; beyond that the full scan).  5000 identical "silence" rows among 8192 exceed that bound: a query at
+    # the silence vector must return the 8 lowest silence ids either way, one next to it likewise
+    big3 = S.make_index(8192, 128, 2)
+    sil = np.sort(g.permutation(8192)[:5000])
+    big3[sil] = big3[sil[0]]
+    qs = np.stack([big3[sil[0]], big3[sil[0]] + 1e-3 * g.standard_normal(128).astype(np.float32), big3[7]]).astype(np.float32)
+    ctx.load_index(big3)
+    ctx.index_exhaustive()
+    out, ids, dist = ctx.index_blend(qs, 0.5)
+    ref, rids, rdist = OP.index_blend(qs, big3, 0.5)
+    assert ctx.index_exhaustive() >= 2
+    assert (ids == rids).all() and (ids[0] == sil[:8]).all() and (ids[1] == sil[:8]).all()
     ctx.load_index(None)
 
 
