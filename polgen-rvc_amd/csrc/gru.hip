@@ -15,6 +15,7 @@
 //    the cluster grid would not be co-resident (large batches) -- the cluster kernel spins.
 #include "conv.h"
 #include "ops.h"
+#include <cstdio>
 
 namespace rvcx {
 
@@ -73,6 +74,9 @@ struct GruGeom {
 };
 constexpr int GRU_NC = 4;                 // default cluster size (scratch / co-residency bounds use the maximum, 8)
 constexpr unsigned GRU_SPIN_LIMIT = 1u << 22;   // ~seconds: a lost partner ends the kernel instead of hanging the GPU
+#ifndef RVCX_GRU_PLAIN_PUBLISH
+#define RVCX_GRU_PLAIN_PUBLISH 1
+#endif
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
 // tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): no cancellation near 0, saturates cleanly
@@ -282,7 +286,235 @@ __global__ __launch_bounds__(384) void bigru_cluster_kernel(const float* __restr
   if (tid == 0 && sfail) atomicExch(err, 1);
 }
 
-size_t bigru_scratch_bytes(int B) { return (size_t)B * 2 * 2 * GRU_H * sizeof(unsigned long long); }
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the cluster step again, 1.43 -> 1.03 us (tools/ab_gru.sh: kernel durations over T = 1000 .. 9001).  What changed,
+// with the per-step price of each piece from A/B builds of this kernel (all numbers on one box, 2.4 GHz):
+//  * h_t is published with a PLAIN store when the cluster sits on one XCD (checked with HW_REG_XCC_ID, not assumed): the
+//    line stays in that XCD's L2 and the partners' sc1 polls are served from it -- 650 instead of 890 cycles per hop
+//    (tools/handoff_latency.hip); across XCDs a plain store is never seen, so any other placement keeps the sc1 store.
+//    1.40 -> 1.15 us.
+//  * No wave carries a global load across the end of a step, and none waits on vmcnt inside the loop except for its
+//    own poll.  The round-3 kernel had `s_waitcnt vmcnt(0)` at the loop head and at the first FMAs (compiler-placed: the
+//    weight loads "may still be pending" on loop entry, the prefetched gi registers are copied at the head), so the gate wave
+//    waited there for the acknowledge of its own publish / y stores and for the gi prefetch it had just issued.  Now the
+//    weights and biases are "used" once in front of the loop, gi_t reaches the gate lanes through LDS (fetched one step
+//    ahead by the last polling wave, whose loads return before its poll's anyway), and the time-out flag is read beside h
+//    at the loop head instead of after the closing barrier (its LDS round trip was 0.04 us of serial path).
+//  * The dot products run on the packed fp32 pipe with whole waves, the same number on every SIMD: a thread owns the
+//    r, z, n rows of ONE unit over CPT columns as float2 pairs along the column axis (v_pk_fma_f32); the round-3 geometry
+//    (384 threads = 6 waves on 4 SIMDs, 128 scalar FMAs each) had two SIMDs with 1024 issue cycles per step.
+//      <4, 32>: 512 threads, 96 weights each, 2 waves per SIMD x 48 packed FMAs, 8 partial sums per gate      (default)
+//      <4, 64>: 256 threads, 192 weights each; a lone wave issues a packed FMA every 8 cycles, not 4 (dot products 0.28
+//               instead of 0.20 us) but reads 12 instead of 24 partial sums -- the same step time alone, 1.5 % slower in
+//               the pipeline (242 VGPRs x 4 waves leave HuBERT's kernels less room beside it)
+//    Partial sums go to LDS as part[slice][gate][unit] (4-byte stores, a wave writes 64 consecutive banks).
+//  What a step is made of now (A/B with the piece removed): exchange + partial-sum phase + barriers 0.64-0.72 us (the
+//  exchange alone is 914 cycles = 0.38 us in the stand-alone model, 1268 with the partial-sum phase), dot products 0.20,
+//  gate arithmetic 0.08, y store 0.03, gi 0.02.  Tried on top and not kept: two polls in flight per lane (worse: the
+//  unneeded one has to be waited for), in-wave reduction of the column slices with DPP / v_permlane swaps (8 distinct LDS
+//  addresses per 16-byte read of h: 1.12 us), 32 units x 2 slices per wave + one v_permlane32_swap (1.04).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NC, int CPT>
+struct GruUnitGeom {
+  static constexpr int U = GRU_H / NC, NCS = GRU_H / CPT, THREADS = U * NCS;
+  static_assert(U == 64, "one wave of gate lanes");
+  static_assert(THREADS - 64 >= GRU_H - U, "one polling thread per foreign unit");
+};
+
+template <int NC, int CPT>
+__global__ __launch_bounds__((GruUnitGeom<NC, CPT>::THREADS)) void bigru_unit_kernel(const float* __restrict__ gi,
+                                                                                     const float* __restrict__ whh_t,
+                                                                                     const float* __restrict__ bhh,
+                                                                                     float* __restrict__ y,
+                                                                                     unsigned long long* xbuf, int* err, int T,
+                                                                                     int nq, int colocate,
+                                                                                     const int* __restrict__ lens) {
+  using G = GruUnitGeom<NC, CPT>;
+  constexpr int H = GRU_H, U = G::U, NCS = G::NCS, THREADS = G::THREADS, GATHER0 = 64;
+  __shared__ __attribute__((aligned(16))) float hs[H];
+  __shared__ float part[NCS][3][U];
+  __shared__ float gis[2][3][U];            // input-projection terms of the owned units: this step's / the next one's
+  __shared__ int sfail, s_same;
+  int c, q;
+  if (colocate) {          // the NC members of a cluster share one XCD (see bigru_cluster_kernel)
+    const int g = blockIdx.x, rest = g >> 3;
+    c = rest % NC;
+    q = (rest / NC) * 8 + (g & 7);
+  } else {
+    c = blockIdx.x % NC;
+    q = blockIdx.x / NC;
+  }
+  if (q >= nq) return;
+  __builtin_amdgcn_s_setprio(3);
+  const int dir = q & 1, b = q >> 1;
+  const int Tn = lens ? lens[b] : T;
+  const int tid = threadIdx.x;
+  const int un = tid % U, cs = tid / U;     // a wave = one column slice of all 64 units
+  const float* W = whh_t + (long)dir * H * 3 * H;
+  // W_hh[gate H + c U + un][cs CPT + k], k pairs (whh_t is (H, 3H): column k of W_hh is row k of whh_t)
+  f32x2 w[3][CPT / 2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int grow = g * H + c * U + un;
+#pragma unroll
+    for (int k = 0; k < CPT / 2; ++k) {
+      w[g][k].x = W[(long)(cs * CPT + 2 * k) * 3 * H + grow];
+      w[g][k].y = W[(long)(cs * CPT + 2 * k + 1) * 3 * H + grow];
+    }
+  }
+  const float* gib = gi + (long)b * T * 6 * H + dir * 3 * H;
+  float* yb = y + ((long)b * 2 + dir) * H * T;
+  unsigned long long* xb = xbuf + ((long)b * 2 + dir) * 2 * H;
+  const int ju = c * U + tid;               // unit handled in the gate phase (tid < U)
+  float bh_r = 0.f, bh_z = 0.f, bh_n = 0.f;
+  if (tid < U) {
+    bh_r = bhh[dir * 3 * H + ju];
+    bh_z = bhh[dir * 3 * H + H + ju];
+    bh_n = bhh[dir * 3 * H + 2 * H + ju];
+  }
+  for (int k = tid; k < H; k += THREADS) hs[k] = 0.f;
+  if (tid == 0) sfail = 0;
+  // Which XCD is each member on?  When the whole cluster shares one (the observed round-robin placement, never assumed)
+  // h_t is published with a PLAIN store: the line stays in this XCD's L2 and the partners' sc1 polls are served from it --
+  // 650 instead of 890 cycles per hop (tools/handoff_latency.hip; across XCDs a plain store is never seen, so any other
+  // placement keeps the write-through sc1 store).
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15;
+    unsigned long long* ids = xbuf + (long)(nq / 2) * 2 * 2 * H + (long)q * 8;
+    Granule me;
+    me.s.v = __uint_as_float(xcc);
+    me.s.tag = 1;
+    __hip_atomic_store(ids + c, me.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int same = 1;
+    for (int m = 0; m < NC && !sfail; ++m) {
+      Granule o;
+      unsigned spins = 0;
+      do {
+        o.u = __hip_atomic_load(ids + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > GRU_SPIN_LIMIT) {
+          sfail = 1;
+          break;
+        }
+      } while (o.s.tag != 1);
+      if (__float_as_uint(o.s.v) != xcc) same = 0;
+    }
+    s_same = RVCX_GRU_PLAIN_PUBLISH ? same : 0;
+  }
+  __syncthreads();
+  if (sfail) {             // a partner never started: the caller re-runs on the single-workgroup kernel
+    if (tid == 0) atomicExch(err, 1);
+    return;
+  }
+  const bool same_xcd = s_same != 0;
+  // Every weight is "used" here, so the compiler's wait for their loads sits in front of the loop.  Left to itself it puts
+  // s_waitcnt vmcnt(12) ... vmcnt(0) at the first FMAs INSIDE the loop (the loads may still be pending on loop entry), and
+  // every later step then waits there for whatever its wave has in flight -- the gi prefetch just issued, or the
+  // acknowledge of the previous step's stores.
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int k = 0; k < CPT / 2; ++k) asm volatile("" ::"v"(w[g][k]));
+  asm volatile("" ::"v"(bh_r), "v"(bh_z), "v"(bh_n));
+  // The input-projection terms gi_t of the owned units reach the gate lanes through LDS, fetched by the LAST polling wave
+  // one step ahead.  No wave then carries a global load across the end of a step: with the loads in the gate wave the
+  // compiler's `s_waitcnt vmcnt(0)` at the loop head (the prefetched registers are copied there) made that wave wait for
+  // the write-acknowledge of its own publish and y stores, and a second poll in flight made the polling waves wait for a
+  // load they no longer needed -- 0.11 us of a 1.15 us step (A/B with the prefetch removed).
+  constexpr int GIW0 = GATHER0 + (H - U) - 64;        // first thread of that wave; its lane l fetches unit c U + l
+  const bool giw = tid >= GIW0 && tid < GIW0 + 64;
+  const int gu = c * U + (tid - GIW0);
+  if (giw && Tn > 0) {
+    const float* g = gib + (long)(dir == 0 ? 0 : Tn - 1) * 6 * H;
+    gis[0][0][tid - GIW0] = g[gu];
+    gis[0][1][tid - GIW0] = g[H + gu];
+    gis[0][2][tid - GIW0] = g[2 * H + gu];
+  }
+  __syncthreads();
+  int kf = tid - GATHER0;                    // the foreign unit a polling thread fetches
+  if (kf >= c * U) kf += U;
+  float gr_n = 0.f, gz_n = 0.f, gn_n = 0.f;   // outside the loop: re-zeroing them per step costs a vmcnt(0) at the loop head
+  for (int step = 0; step < Tn; ++step) {
+    const int t = dir == 0 ? step : Tn - 1 - step;
+    const int failed = sfail;       // read beside h (set, if at all, before the barrier that ended the previous step) ...
+    if (giw && step + 1 < Tn) {
+      const float* g = gib + (long)(dir == 0 ? t + 1 : t - 1) * 6 * H;
+      gr_n = g[gu];
+      gz_n = g[H + gu];
+      gn_n = g[2 * H + gu];
+    }
+    // ---- packed dot products: two chains per gate (even / odd 16-byte groups of h), lanes of a pair are columns k, k+1
+    f32x2 acc[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g][0] = acc[g][1] = f32x2{0.f, 0.f};
+    const float4* h4 = reinterpret_cast<const float4*>(hs + cs * CPT);
+#pragma unroll
+    for (int k = 0; k < CPT / 4; ++k) {
+      const float4 hv = h4[k];
+      const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        acc[g][0] = __builtin_elementwise_fma(w[g][2 * k], h01, acc[g][0]);
+        acc[g][1] = __builtin_elementwise_fma(w[g][2 * k + 1], h23, acc[g][1]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const f32x2 a = acc[g][0] + acc[g][1];
+      part[cs][g][un] = a.x + a.y;
+    }
+    lds_barrier();
+    if (failed) break;              // ... and acted on here: block-uniform, and its LDS latency is off the serial path
+    if (tid < U) {
+      float sr = 0.f, sz = 0.f, sn = 0.f;
+#pragma unroll
+      for (int p = 0; p < NCS; ++p) {
+        sr += part[p][0][tid];
+        sz += part[p][1][tid];
+        sn += part[p][2][tid];
+      }
+      const float g_r = gis[step & 1][0][tid], g_z = gis[step & 1][1][tid], g_n = gis[step & 1][2][tid];
+      const float ghr = sr + bh_r, ghz = sz + bh_z, ghn = sn + bh_n;
+      const float r = fast_sigmoid(g_r + ghr);
+      const float z = fast_sigmoid(g_z + ghz);
+      const float n = fast_tanh(g_n + r * ghn);
+      const float hn = (1.f - z) * n + z * hs[ju];
+      Granule gr;
+      gr.s.v = hn;
+      gr.s.tag = step + 1;
+      if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(xb + (step & 1) * H + ju), "v"(gr.u) : "memory");
+      else __hip_atomic_store(xb + (step & 1) * H + ju, gr.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      yb[(long)ju * T + t] = hn;
+      hs[ju] = hn;
+    } else if (tid < GATHER0 + (H - U)) {
+      // whole waves only (a wave holding publishing and polling lanes could poll first and never publish)
+      const unsigned long long* src = xb + (step & 1) * H + kf;
+      Granule ga;
+      unsigned spins = 0;
+      do {
+        ga.u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ga.s.tag == step + 1) break;
+        if (++spins > GRU_SPIN_LIMIT) {
+          sfail = 1;
+          break;
+        }
+      } while (true);
+      hs[kf] = ga.s.v;
+      if (giw) {            // the loads above returned before the poll's (in order): next step's terms for the gate lanes
+        gis[(step + 1) & 1][0][tid - GIW0] = gr_n;
+        gis[(step + 1) & 1][1][tid - GIW0] = gz_n;
+        gis[(step + 1) & 1][2][tid - GIW0] = gn_n;
+      }
+    }
+    lds_barrier();
+  }
+  if (tid == 0 && sfail) atomicExch(err, 1);
+}
+
+// granules: (B, 2 directions, 2 step parities, H) values of h, then (2 B clusters, 8) XCD ids
+size_t bigru_scratch_bytes(int B) { return ((size_t)B * 2 * 2 * GRU_H + (size_t)B * 2 * 8) * sizeof(unsigned long long); }
 
 void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* y, int B, int T, int H,
                   void* scratch, int* err, hipStream_t stream, const int* lens) {
@@ -297,7 +529,16 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
     if (colocate < 0) colocate = getenv("RVCX_GRU_COLOCATE") ? atoi(getenv("RVCX_GRU_COLOCATE")) : 1;
     const int nq = 2 * B;
     const int grid = colocate ? 8 * nc * cdiv(nq, 8) : nc * nq;
-    if (nc == 8)
+    // RVCX_GRU_FORM: 0 = the round-3 kernel (4 rows x 32 columns per thread, scalar FMAs; it hosts the RVCX_GRU_B128
+    // reproducer), 1 = unit rows + packed FMAs, 256 threads, 2 = the same with 512 threads (default)
+    static const int form = getenv("RVCX_GRU_FORM") ? atoi(getenv("RVCX_GRU_FORM")) : 2;
+    if (nc == 4 && form == 1)
+      hipLaunchKernelGGL((bigru_unit_kernel<4, 64>), dim3(grid), dim3(GruUnitGeom<4, 64>::THREADS), 0, stream, gi, whh_t, bhh,
+                         y, xbuf, err, T, nq, colocate, lens);
+    else if (nc == 4 && form == 2)
+      hipLaunchKernelGGL((bigru_unit_kernel<4, 32>), dim3(grid), dim3(GruUnitGeom<4, 32>::THREADS), 0, stream, gi, whh_t, bhh,
+                         y, xbuf, err, T, nq, colocate, lens);
+    else if (nc == 8)
       hipLaunchKernelGGL((bigru_cluster_kernel<8, 16>), dim3(grid), dim3(GruGeom<8, 16>::THREADS), 0, stream, gi, whh_t, bhh,
                          y, xbuf, err, T, nq, colocate, lens);
     else

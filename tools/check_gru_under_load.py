@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Is the BiGRU cluster kernel deterministic while other kernels share the GPU? (debugging aid)
 A second context keeps the chip busy with GEMM launches from another thread; the main thread runs rvcx_op_bigru on
-the same input N times and counts distinct results."""
+the same input N times and counts distinct results.
+The round-3 failure lives in the round-3 kernel: run the -DRVCX_GRU_B128=1 build with RVCX_GRU_FORM=0."""
 import hashlib, os, sys, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
