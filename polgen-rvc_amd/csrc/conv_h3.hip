@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
   const float pre_slope = a.pre_slope;
   const int nchunk = a.Cin_gp / 16;
   constexpr bool xsplit = XS;
-  static_assert(!XS || (!LIN && STRIDE == 1), "pre-split input: dense stride-1 tiles only");
+  static_assert(!XS || !LIN, "pre-split input: tap tiles only");
   const H3Rsrc xr = xsplit ? h3_rsrc(static_cast<const char*>(a.x_split) + (long)b * a.x_bs * 4, a.Cin_g * a.x_cs * 4)
                            : h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
   const H3Rsrc wr_ = h3_rsrc(a.w_h3, a.ksize * nchunk * 4 * a.Cout_gp * 16);
@@ -359,8 +359,8 @@ const H3Cfg kH3[] = {
     {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false, true>},
     {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false, true>},
     // stride 2
-    {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>, nullptr},
-    {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>, nullptr},
+    {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false, true>},
+    {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false, true>},
     // k = 1
     {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>, nullptr},
     {128, 64, 0, 1, true, 18.f, 1.00f, conv_h3_kernel<128, 64, 4, 1, 2, 0, 1, true>, nullptr},
@@ -408,7 +408,8 @@ void conv_h3_describe(ConvProfile* p) {
 
 bool conv_h3_split_ok(const ConvArgs& a) {
   if (!a.w_h3 || !conv_h3_enabled()) return false;
-  if (a.groups != 1 || a.stride != 1 || a.ksize == 1 || a.out_mode != OUT_NORMAL) return false;
+  if (a.groups != 1 || a.ksize == 1 || a.out_mode != OUT_NORMAL) return false;
+  if (a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) return false;      // stride 2: the HuBERT extractor's 1-D layers
   if (a.Cin_g % 16 != 0 || a.Cout_g % 16 != 0 || a.Cin_g != a.Cin_gp) return false;
   {
     int lo = 1 << 30, hi = -(1 << 30);

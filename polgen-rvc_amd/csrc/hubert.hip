@@ -118,21 +118,52 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
   }
   float* bufa = A.alloc<float>((size_t)B * C * t0);
   float* bufb = A.alloc<float>((size_t)B * C * t0);
+  float* gn_stats = A.alloc<float>((size_t)B * C * 2);
   // ---- conv feature extractor
   int64_t Tin = n;
   const float* x = wav;
   float* y = bufa;
+  // Layers 1 .. 4 (k = 3, stride 2, 512 -> 512: 143 of the extractor's 148 GFLOP per 30 s) hand their GELU outputs on
+  // already split into the fp16 hi / lo pairs the next layer's tiles are made of (ConvArgs::y_split -> x_split, the
+  // same bytes as fp32): a stride-2 layer stages two input positions per output, so converting them in the consumer --
+  // once per 64-channel block row, eight times over -- cost as many VALU cycles as the tile's MFMAs.  Same values,
+  // same fragments: the features are bit-identical to the fp32 hand-off (RVCX_NO_SPLIT=1).
+  static const bool no_split = getenv("RVCX_NO_SPLIT") && atoi(getenv("RVCX_NO_SPLIT")) != 0;
+  std::vector<ConvArgs> la(cf.n_conv);
+  {
+    int64_t ti = n;
+    for (int i = 0; i < cf.n_conv; ++i) {
+      const int64_t to = (ti - cf.conv_kernels[i]) / cf.conv_strides[i] + 1;
+      RVCX_CHECK(to > 0, "hubert: input too short");
+      la[i] = conv1d_args(m.convs[i], nullptr, nullptr, B, (int)ti, (int)to, cf.conv_strides[i], 1, 0);
+      if (i > 0) la[i].act = ACT_GELU;
+      ti = to;
+    }
+  }
+  auto split_after = [&](int i) {        // does layer i (0: its GroupNorm + GELU) store split outputs for layer i + 1?
+    if (no_split || i + 1 >= cf.n_conv || i > 3 || cf.conv_strides[i + 1] != 2 || !conv_h3_split_ok(la[i + 1])) return false;
+    return i == 0 ? C % 16 == 0 : (cf.conv_kernels[i + 1] == cf.conv_kernels[i] && conv_h3_split_ok(la[i]));
+  };
   for (int i = 0; i < cf.n_conv; ++i) {
-    const int64_t Tout = (Tin - cf.conv_kernels[i]) / cf.conv_strides[i] + 1;
-    RVCX_CHECK(Tout > 0, "hubert: input too short");
-    ConvArgs a = conv1d_args(m.convs[i], x, y, B, (int)Tin, (int)Tout, cf.conv_strides[i], 1, 0);
+    const int64_t Tout = la[i].Nout;
+    ConvArgs a = la[i];
+    a.x = x;
+    a.y = y;
     if (i == 0 && wav_bs > 0) a.x_bs = wav_bs;      // the B signals are slices of longer rows
-    if (i > 0) a.act = ACT_GELU;
     a.lens_out = d_tl[i];       // frames behind an item's last one: zeros, and tiles that hold nothing else are skipped
+    if (i > 0 && split_after(i - 1)) a.x_split = x;
+    if (i > 0 && split_after(i)) {
+      a.y_split = y;
+      a.y = nullptr;
+    }
     c.conv_on(a, s);
     if (i == 0) {
       float* z = (y == bufa) ? bufb : bufa;
-      launch_groupnorm_gelu(y, m.gn_g, m.gn_b, z, B, C, (int)Tout, 1e-5f, s, d_t0);
+      if (split_after(0))
+        launch_groupnorm_gelu_split(y, m.gn_g, m.gn_b, gn_stats, z, B, C, (int)Tout, 1e-5f, s, d_t0, c.dev_err,
+                                    m.convs[1].ovf_word, ++c.launch_seq);
+      else
+        launch_groupnorm_gelu(y, m.gn_g, m.gn_b, z, B, C, (int)Tout, 1e-5f, s, d_t0);
       y = z;
     }
     x = y;

@@ -43,6 +43,9 @@ void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, l
 // beyond are stored as zeros
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                            float eps, hipStream_t s, const int* lens = nullptr);
+// the same with the output already split for a conv_h3 tile that reads ConvArgs::x_split (stats: B*C*2 floats of scratch)
+void launch_groupnorm_gelu_split(const float* x, const float* gamma, const float* beta, float* stats, void* y_split, int B,
+                                 int C, int T, float eps, hipStream_t s, const int* lens, int* ovf, int* ovf_layer, int seq);
 // (B,R,Cc) -> (B,Cc,R)
 void launch_transpose(const float* x, float* y, int B, int R, int Cc, hipStream_t s);
 // x[c][t] = lrelu((x[c][t] + emb[pitch[t]][c]) * scale, slope) * (t<len)     [encoders.py:116-123]

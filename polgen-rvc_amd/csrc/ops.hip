@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "conv.h"
+#include "h3_device.h"
 #include "ops.h"
 
 namespace rvcx {
@@ -200,6 +201,7 @@ void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, l
 // ------------------------------------------------------------------ GroupNorm(C,C) + GELU
 // One block per (channel, item); two sweeps over the row (the second hits L2): fp64 sum / sum of squares in
 // one sweep (exact enough that var = E[x^2] - mean^2 matches the two-pass fp32 result to rounding), then apply.
+template <bool STATS_ONLY>
 __global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
@@ -242,6 +244,13 @@ __global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __rest
   const float mean = (float)meand;
   const float var = (float)fmax(tq / T - meand * meand, 0.0);
   const float rstd = 1.f / sqrtf(var + eps);
+  if (STATS_ONLY) {        // y = (B, C, 2): the apply pass is groupnorm_gelu_split_kernel
+    if (tid == 0) {
+      y[((long)b * C + c) * 2] = mean;
+      y[((long)b * C + c) * 2 + 1] = rstd;
+    }
+    return;
+  }
   const float g = gamma[c], bb = beta[c];
   t = tid;
   for (; t + 3 * 512 < T; t += 4 * 512) {
@@ -255,9 +264,50 @@ __global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __rest
   for (t = T + tid; t < Trow; t += 512) yr[t] = 0.f;
 }
 
+// The apply pass when the consumer is a split-fp16 conv tile reading pre-split input (ConvArgs::x_split): a thread owns 8
+// channels of one frame and stores them as one 16-byte element of fp16 hi parts and one of scaled lo parts,
+// XS[c/16][op][(c%16)/8][t][8] -- the layout and the arithmetic of store_tile_split (conv_h3.hip).
+__global__ __launch_bounds__(256) void groupnorm_gelu_split_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, void* __restrict__ ys, int C,
+                                                                   int Trow, const int* __restrict__ lens, int* ovf,
+                                                                   int* ovf_layer, int seq) {
+  const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  if (t >= Trow) return;
+  const int T = lens ? lens[b] : Trow;
+  const float* xr = x + ((long)b * C + cg * 8) * Trow + t;
+  half8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = cg * 8 + q;
+    const float mean = stats[((long)b * C + c) * 2], rstd = stats[((long)b * C + c) * 2 + 1];
+    float v = gelu_erf((xr[(long)q * Trow] - mean) * rstd * gamma[c] + beta[c]);
+    v = t < T ? v : 0.f;
+    if (!(fabsf(v) < kH3ActLimit)) {
+      if (ovf) atomicOr(ovf, kErrH3Overflow);
+      if (ovf_layer) atomicMax(ovf_layer, 0x7fffffff - seq);
+    }
+    const _Float16 vh = (_Float16)v;
+    hi[q] = vh;
+    lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+  }
+  uint4* base = reinterpret_cast<uint4*>(static_cast<char*>(ys) + (long)b * C * Trow * 4);
+  const int chunk = cg >> 1, hh = cg & 1;
+  base[(long)((chunk * 2 + 0) * 2 + hh) * Trow + t] = __builtin_bit_cast(uint4, hi);
+  base[(long)((chunk * 2 + 1) * 2 + hh) * Trow + t] = __builtin_bit_cast(uint4, lo);
+}
+
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                            float eps, hipStream_t s, const int* lens) {
-  hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3(C, B), dim3(512), 0, s, x, gamma, beta, y, C, T, eps, lens);
+  hipLaunchKernelGGL(groupnorm_gelu_kernel<false>, dim3(C, B), dim3(512), 0, s, x, gamma, beta, y, C, T, eps, lens);
+}
+
+void launch_groupnorm_gelu_split(const float* x, const float* gamma, const float* beta, float* stats, void* y_split, int B,
+                                 int C, int T, float eps, hipStream_t s, const int* lens, int* ovf, int* ovf_layer, int seq) {
+  RVCX_CHECK(C % 16 == 0, "groupnorm_gelu_split: channels must be a multiple of 16");
+  hipLaunchKernelGGL(groupnorm_gelu_kernel<true>, dim3(C, B), dim3(512), 0, s, x, gamma, beta, stats, C, T, eps, lens);
+  hipLaunchKernelGGL(groupnorm_gelu_split_kernel, dim3(cdiv(T, 256), C / 8, B), dim3(256), 0, s, x, stats, gamma, beta,
+                     y_split, C, T, lens, ovf, ovf_layer, seq);
 }
 
 // ------------------------------------------------------------------ batched transpose
