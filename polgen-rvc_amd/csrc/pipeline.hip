@@ -937,11 +937,13 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   // launches (mel, the shallow U-Net levels): then all of HuBERT is enqueued (its transformer launches queue up behind
   // the conv extractor), then the rest of the F0 model's ~300 small launches.  Neither stream waits for the host:
   // enqueued the other way round HuBERT sat idle for 2.6 ms of a single clip's 10 ms front end.
+  int mid_mark = -1;
   auto enqueue_models = [&](int k) {
     bool hub_done = false;
     const std::function<void()> mid = [&]() {
       if (hub_done) return;
       hub_done = true;
+      if (k == 0) mid_mark = clk.mark(sf);
       enqueue_hubert(k);
     };
     enqueue_f0(k, &mid);
@@ -1148,6 +1150,10 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       }
       for (auto& e : ev) (void)hipEventDestroy(e);
     }
+    if (getenv("RVCX_HOST_TRACE") && !mbs.empty())     // device-side times of the first micro-batch's front end, from its first event
+      fprintf(stderr, "[front] F0 model %.2f .. %.2f ms (shallow U-Net levels enqueued and done by %.2f), HuBERT %.2f .. %.2f ms\n",
+              clk.between(0, f0_ev0[0]), clk.between(0, f0_ev1[0]), clk.between(0, mid_mark), clk.between(0, hub_ev0[0]),
+              clk.between(0, hub_ev1[0]));
     if (getenv("RVCX_HOST_TRACE"))
       fprintf(stderr, "[wait] main stream waited %.1f ms for HuBERT / front sets and %.1f ms for F0\n", t_wait_hub, t_wait_f0);
     stage_ms[0] = t_hp;
