@@ -430,7 +430,8 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     RVCX_HIP(hipGetLastError());
     return 7;
   }
-  if ((a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) || a.groups != 1 || a.Cin_gp % 16 != 0) return -1;
+  if ((a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) || a.Cin_gp % 16 != 0) return -1;
+  if (a.groups != 1 && !a.w_h3) return -1;      // grouped layers: only the split-fp16 tiles take them (blockIdx.z = group)
   // the staging loads address x (per batch item) and the packed weights through 32-bit buffer offsets
   if ((long)a.Cin_gp * a.x_cs * 4 >= kBufOob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kBufOob) return -1;
   int off_min = 1 << 30, off_max = -(1 << 30);
@@ -444,6 +445,7 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     const int slot = launch_conv_h3(a, halo, off_min, stream);
     if (slot >= 0) return slot;
   }
+  if (a.groups != 1) return -1;
   // joint (tile, split-K) choice from a small cost model fitted to tools/sweep_conv.py on MI355X:
   //   block time = 2 bm bn (K/S + ovh_t) / (577 GFLOP/s x eff_t x f(c)),  c = blocks S / 256 blocks per CU,
   // f(c) = MFMA utilisation of a CU with c co-resident blocks (0.45 alone .. 1.0 from four up), ovh_t = the

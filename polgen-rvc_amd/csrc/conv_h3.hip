@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int i = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z / a.splitk, ks = blockIdx.z - b * a.splitk;
+  // blockIdx.z = (item, group, K split).  A group of a grouped layer (HuBERT's pos_conv: 16 x {48 -> 48, 128 taps}) is a dense
+  // layer of its own on Cin_g input rows, its own weight image and Cout_g output channels; grouped launches never split K.
+  const int bz = blockIdx.z / a.splitk, ks = blockIdx.z - bz * a.splitk;
+  const int b = bz / a.groups, grp = bz - b * a.groups;
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
@@ -101,8 +104,9 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
   constexpr bool xsplit = XS;
   static_assert(!XS || !LIN, "pre-split input: tap tiles only");
   const H3Rsrc xr = xsplit ? h3_rsrc(static_cast<const char*>(a.x_split) + (long)b * a.x_bs * 4, a.Cin_g * a.x_cs * 4)
-                           : h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
-  const H3Rsrc wr_ = h3_rsrc(a.w_h3, a.ksize * nchunk * 4 * a.Cout_gp * 16);
+                           : h3_rsrc(a.x + (long)b * a.x_bs + (long)grp * a.Cin_g * a.x_cs, a.Cin_g * a.x_cs * 4);
+  const H3Rsrc wr_ = h3_rsrc(static_cast<const char*>(a.w_h3) + (long)grp * a.ksize * nchunk * 4 * a.Cout_gp * 16,
+                             a.ksize * nchunk * 4 * a.Cout_gp * 16);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
     for (int m = 0; m < WM; ++m)
 #pragma unroll
       for (int n = 0; n < WN; ++n) store_tile_split(a, b, c_t + m * 32, nn_w + n * 32, h, acc[m][n], len_out);
-  } else if (fast_epilogue_ok(a)) {
+  } else if (fast_epilogue_ok(a) && a.groups == 1) {
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, ((LIN && BM * BN >= 8192) || BN >= 512) ? 2 : 
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
-      for (int n = 0; n < WN; ++n) store_tile(a, b, 0, co_w + m * 32, nn_w + n * 32, acc[m][n], len_out);
+      for (int n = 0; n < WN; ++n) store_tile(a, b, grp, co_w + m * 32, nn_w + n * 32, acc[m][n], len_out);
   }
 }
 
@@ -428,7 +432,8 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   const bool split = a.x_split || a.y_split;
   RVCX_CHECK(!split || conv_h3_split_ok(a), "conv_h3: pre-split activations on a launch that cannot take them");
   if (!a.w_h3 || !conv_h3_enabled()) return -1;
-  if (a.groups != 1 || a.Cin_gp % 16 != 0 || (a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize))) return -1;
+  if (a.Cin_gp % 16 != 0 || (a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize))) return -1;
+  if (a.groups != 1 && (split || a.ksize == 1 || a.stride != 1 || a.out_mode != OUT_NORMAL || a.Cin_g != a.Cin_gp)) return -1;
   if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kH3Oob) return -1;
   const bool lin = a.ksize == 1 && a.stride == 1;
   const int nchunk = a.Cin_gp / 16;
@@ -453,9 +458,9 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
       if (a.x_split && !F.kern_xs) continue;
       if (!wide3x3 && g_conv_override.tile < 100 && F.halo == 320 && F.bn >= 256) continue;
       if (!lin && (halo > F.halo || (F.halo == 320 && halo <= 64))) continue;
-      const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * Bsel;
+      const long blocks = (long)cdiv(a.Cout_gp, F.bm) * cdiv(a.Nout, F.bn) * Bsel * a.groups;
       const double ksteps = (double)a.ksize * nchunk;
-      for (int s = 1; s <= (split ? 1 : 8); s *= 2) {
+      for (int s = 1; s <= ((split || a.groups != 1) ? 1 : 8); s *= 2) {
         if (s > 1 && (!a.part || nchunk / s < 1 || ksteps / s < 8.0 || (long)s * a.Cout_g * a.Nout > cap_item ||
                       (long)s * a.B * a.Cout_g * a.Nout > a.part_cap))
           break;
@@ -497,7 +502,7 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
     if (dbg < 0) dbg = getenv("RVCX_CONV_DBG") ? atoi(getenv("RVCX_CONV_DBG")) : 0;
     a.dbg = dbg;
   }
-  dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * S);
+  dim3 grid(cdiv(a.Nout, F.bn), cdiv(a.Cout_gp, F.bm), a.B * a.groups * S);
   {
     static const bool log = getenv("RVCX_CONV_LOG") != nullptr;
     if (log)

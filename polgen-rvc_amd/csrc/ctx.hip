@@ -164,8 +164,23 @@ static std::vector<float> pack_h3(const std::vector<float>& wp, int k, int cin_g
 // used is a region flag, so ranks that load placeholder values build the same layout and learn the flag from
 // the broadcast (zero-filled weight-norm tensors fold to NaN and used to shrink the layout).
 static void upload_h3(Ctx& c, ConvW& L, const std::vector<float>& wp, int k) {
-  const std::vector<float> hp = pack_h3(wp, k, L.cin_gp, L.cout_gp);
-  const size_t n = (size_t)k * (L.cin_gp / 16) * 4 * L.cout_gp * 4;
+  // grouped layers: one image per group, back to back (pack_conv_weight lays the groups out as dense layers)
+  const size_t per_w = (size_t)k * L.cin_gp * L.cout_gp, per_h = (size_t)k * (L.cin_gp / 16) * 4 * L.cout_gp * 4;
+  std::vector<float> hp;
+  if (L.groups == 1) {
+    hp = pack_h3(wp, k, L.cin_gp, L.cout_gp);
+  } else {
+    for (int g = 0; g < L.groups; ++g) {
+      const std::vector<float> one =
+          pack_h3(std::vector<float>(wp.begin() + g * per_w, wp.begin() + (g + 1) * per_w), k, L.cin_gp, L.cout_gp);
+      if (one.empty()) {
+        hp.clear();
+        break;
+      }
+      hp.insert(hp.end(), one.begin(), one.end());
+    }
+  }
+  const size_t n = per_h * L.groups;
   L.w_h3 = hp.empty() ? c.slab.cur().reserve(n * sizeof(float)) : c.slab.upload(hp);
   L.h3_ok = c.slab.new_flag(!hp.empty());
   L.ovf_word = c.slab.cur().ovf_word(L.h3_ok);
@@ -181,7 +196,7 @@ ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, 
   L.cout_gp = conv_cout_pad(cout / groups);
   const std::vector<float> wp = pack_conv_weight(w, cout, cin_g, k, groups);
   L.w = c.slab.upload(wp);
-  if (h3 && groups == 1 && L.cin_gp % 16 == 0 && conv_h3_configured()) upload_h3(c, L, wp, k);
+  if (h3 && L.cin_gp % 16 == 0 && (groups == 1 || k > 1) && conv_h3_configured()) upload_h3(c, L, wp, k);
   L.bias = bias ? c.slab.upload(bias, (size_t)cout) : nullptr;
   return L;
 }

@@ -33,7 +33,9 @@ CASES_1D = [
     (2, 512, 300, 512, 2, 2, 1, 1),     # HuBERT conv5-6 shape
     (1, 64, 4097, 200, 3, 2, 1, 1),
     (1, 1, 6000, 40, 24, 12, 1, 1),     # noise conv (Cin=1, k=2*stride)
-    (1, 128, 70, 128, 128, 1, 1, 16),   # HuBERT pos_conv (grouped, k=128)
+    (1, 128, 70, 128, 128, 1, 1, 16),   # HuBERT pos_conv (grouped, k=128); 8 channels per group: the generic kernel
+    (2, 768, 203, 768, 128, 1, 1, 16),  # its real shape, 48 channels per group: split-fp16 tiles, blockIdx.z = (item, group)
+    (1, 96, 333, 64, 5, 1, 1, 2),       # grouped with Cout_g != Cin_g
     (1, 24, 50, 288, 1, 1, 1, 1),       # odd channel counts -> padding guards
     (3, 5, 33, 7, 5, 1, 1, 1),
     (1, 32, 1, 1, 7, 1, 1, 1),          # conv_post shape, T=1
@@ -70,6 +72,27 @@ def test_conv1d_fused_epilogue(ctx):
         ref = fn(F.conv1d(x, w, b, padding=3)) + r
         got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), res=r.numpy(), pad_left=3, act=act, act_slope=0.1)
         _chk(got, ref, f"act{act}")
+
+
+def test_grouped_conv_with_the_pos_conv_epilogue_ragged(ctx):
+    """x + gelu(pos_conv(x)) of a ragged batch (hubert.hip): grouped split-fp16 tiles with the GELU, the residual and the
+    per-item zero padding; every item equals its single run bit for bit and torch within the tolerance."""
+    gen = torch.Generator().manual_seed(9)
+    lens = [150, 97, 31]
+    x = torch.randn(3, 768, 150, generator=gen)
+    for i, L in enumerate(lens):
+        x[i, :, L:] = 0
+    w = torch.randn(768, 48, 128, generator=gen) / (48 * 128) ** 0.5
+    b = torch.randn(768, generator=gen)
+    got = ctx.conv1d(x.numpy(), w.numpy(), b.numpy(), res=x.numpy(), pad_left=64, groups=16, act=3, Tout=150, lens_in=lens,
+                     lens_out=lens)
+    for i, L in enumerate(lens):
+        xi = x[i:i + 1, :, :L]
+        ref = (xi + F.gelu(F.conv1d(xi, w, b, padding=64, groups=16)[:, :, :L]))[0]
+        _chk(got[i, :, :L], ref, f"item{i}")
+        assert (got[i, :, L:] == 0).all()
+        one = ctx.conv1d(xi.numpy(), w.numpy(), b.numpy(), res=xi.numpy(), pad_left=64, groups=16, act=3, Tout=L)
+        assert np.array_equal(one[0], got[i, :, :L])
 
 
 def test_conv1d_ragged_lengths(ctx):
