@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 evidence for every driver-timed line (run on the GPU box through gpurun): serial-mode kernel traces of the C2
-# (split-fp16 and exact-fp32), C3 and C5 workloads, and the HBM-traffic PMC passes for C2 and C3 -> gpurun_out/prof_r04/
+# (split-fp16 and exact-fp32), C3 and C5 workloads, and the HBM-traffic PMC passes for C2 (C3: PMC_C3=1, very slow) -> gpurun_out/prof_r04/
 set -u
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp RVCX_SERIAL=1
@@ -25,7 +25,7 @@ pmc() {     # tag, bench args...
   rm -rf /tmp/pf_$tag /tmp/pw_$tag
 }
 pmc c2 --steps 3 --warmup 1
-pmc c3 --workload c3 --steps 1 --warmup 1
+[ -n "${PMC_C3:-}" ] && pmc c3 --workload c3 --steps 1 --warmup 1    # > 40 minutes under the counter passes: off by default
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F16 \
   --output-format csv -d /tmp/pm_c2 -- python3 bench.py --no-cpu-baseline --no-children --no-roofline --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc_mfma.err
 python3 tools/pmc_summary.py /tmp/pm_c2 > $OUT/pmc_mfma_r04.txt
