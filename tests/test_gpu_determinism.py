@@ -43,7 +43,7 @@ def _victims(ctx):
         ("resblock_pair C=128 k=11 d=5", lambda: ctx.resblock_pair(x3b, w3b, b3b, w3b, b3b, dil=5)),
         ("gemm_h3 (time-major) 768->2304 T=1599", lambda: ctx.gemm_tm(x4, w4)[0]),
         ("attn_h3 12 x 64 T=1599", lambda: ctx.attention(q, q * 0.5, q * 0.25, 12, 0.125)),
-        ("bigru_cluster T=3232", lambda: ctx.bigru(xg, sd)),
+        ("bigru (cluster of 4 workgroups per direction) T=3232", lambda: ctx.bigru(xg, sd)),
     ]
 
 

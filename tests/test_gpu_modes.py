@@ -53,3 +53,18 @@ def test_alternative_fused_resblock_tiles_are_bit_identical_too(variant):
     barrier-free c2 loop; 8: split-phase staging on LDS counters, no s_barrier in the k-loops -- round-4 experiments): the k-order is the same, so each must equal the two conv
     launches bit for bit and torch within fp32 rounding."""
     _run_mode({"RVCX_PAIR_VARIANT": variant}, "test_gpu_conv.py", "fused_resblock", "10 passed")
+
+
+@pytest.mark.parametrize("env", [{"RVCX_GRU_FORM": "0"}, {"RVCX_GRU_FORM": "1"}, {"RVCX_GRU_COLOCATE": "0"},
+                                 {"RVCX_GRU_FORM": "1", "RVCX_GRU_COLOCATE": "0"}])
+def test_bigru_forms_and_the_cross_xcd_hand_off_pass_the_f0_goldens(env):
+    """Round 4's BiGRU kernel publishes h_t with a plain store when its cluster sits on one XCD (read from HW_REG_XCC_ID) and
+    with the write-through sc1 store otherwise.  RVCX_GRU_COLOCATE=0 spreads every cluster over XCDs, so the second path --
+    the one a different dispatch pattern would take -- runs the same goldens (torch GRU, rmvpe_tiny / full_1s / illcond);
+    RVCX_GRU_FORM selects the 256-thread form (1) and the round-3 kernel (0)."""
+    _run_mode(env, "test_gpu_rmvpe_hubert.py", "gru or rmvpe", "passed")
+
+
+def test_fp32_hand_off_between_layers_passes_the_hubert_and_f0_goldens():
+    """RVCX_NO_SPLIT=1: no pre-split fp16 hand-off (HuBERT extractor, U-Net blocks): consumers convert fp32 themselves."""
+    _run_mode({"RVCX_NO_SPLIT": "1"}, "test_gpu_rmvpe_hubert.py", "hubert or rmvpe", "passed")
