@@ -134,6 +134,11 @@ int rvcx_create(int device, rvcx_ctx** out) {
     auto* h = new rvcx_ctx();
     h->c.device = device;
     RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking));
+    // Exactly four streams (main, F0 / front, two auxiliaries) and no more: HIP multiplexes a process's streams onto four
+    // hardware queues, and a stream that shares one pays for it on every launch.  Rounds 2-3 gave HuBERT a fifth, CU-masked
+    // stream ("masked streams get their own queue" -- not in this process): its 143 launches ran at twice their stand-alone
+    // time whenever the F0 model was busy too, 4 ms per call in the batched workloads (round 4: HuBERT rides aux[0], which is
+    // idle while the front end runs; C3 1220 -> 1290x, C5 1055 -> 1203x; tools/stream_queue_probe.hip shows the sharing).
     {
       // RMVPE ends in a latency-bound serial GRU: give its stream dispatch priority over HuBERT's wide kernels
       int lo = 0, hi = 0;
@@ -152,26 +157,6 @@ int rvcx_create(int device, rvcx_ctx** out) {
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_io, hipEventDisableTiming));
     for (auto& e : h->c.ev_front) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : h->c.ev_done) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    {
-      // HuBERT gets its own stream, restricted to 216 of the 256 CUs: RMVPE's many small kernels (and the 8
-      // workgroups of its GRU) always find free CUs instead of queueing behind HuBERT's wide launches.  Round-3 sweep
-      // with the time-major HuBERT (5.5 ms alone, F0 model 8.1 alone; C2, same box, two runs each): 96 CUs 904x,
-      // 128 951x, 160 973x, 192-200 989-993x, 216 991-998x, 224-232 980-985x.  The F0 model takes >= 9.9 ms beside
-      // HuBERT however few CUs HuBERT gets: what it loses is clock (the chip throttles under HuBERT's MFMA kernels and
-      // the latency-bound GRU steps stretch with it), not CUs.  RVCX_HUBERT_CUS=0: main stream.
-      const int n = getenv("RVCX_HUBERT_CUS") ? atoi(getenv("RVCX_HUBERT_CUS")) : 216;
-      if (n > 0 && n < 256) {
-        uint32_t mask[8] = {0};
-        for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
-        if (hipExtStreamCreateWithCUMask(&h->c.stream_h, 8, mask) != hipSuccess) {
-          (void)hipGetLastError();
-          h->c.stream_h = nullptr;
-          RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream_h, hipStreamNonBlocking));
-        }
-      } else if (n >= 256) {
-        RVCX_HIP(hipStreamCreateWithFlags(&h->c.stream_h, hipStreamNonBlocking));
-      }
-    }
     conv_init();
     resblock_pair_init();
     gemm_init();
@@ -187,7 +172,7 @@ int rvcx_create(int device, rvcx_ctx** out) {
       // high-pass stage): the code object is loaded on the first launch, and every stream / hardware queue is
       // created on its first use.  One trivial launch per stream, then wait.
       float* w = h->c.arena.alloc<float>(256);
-      hipStream_t ss[] = {h->c.stream, h->c.stream2, h->c.aux[0], h->c.aux[1], h->c.stream_h};
+      hipStream_t ss[] = {h->c.stream, h->c.stream2, h->c.aux[0], h->c.aux[1]};
       for (hipStream_t s : ss)
         if (s) launch_randn(w, 64, 1, 0, s);
       RVCX_HIP(hipDeviceSynchronize());
@@ -1177,10 +1162,11 @@ int rvcx_hubert_features(rvcx_ctx* ctx, int B, const float* wav, int64_t n, int 
   float* dw = any_to_dev(*C, wav, (size_t)B * n);
   float* fct = C->arena.alloc<float>((size_t)B * E * T);
   float* ftc = C->arena.alloc<float>((size_t)B * E * T);
-  hubert_forward(*C, *C->hubert, B, dw, n, output_layer, fct, C->stream);
-  launch_transpose(fct, ftc, B, E, T, C->stream);   // (B,E,T) -> (B,T,E)
-  RVCX_HIP(hipMemcpyAsync(feats, ftc, (size_t)B * E * T * 4, hipMemcpyDefault, C->stream));
-  RVCX_HIP(hipStreamSynchronize(C->stream));
+  hipStream_t st = C->stream;
+  hubert_forward(*C, *C->hubert, B, dw, n, output_layer, fct, st);
+  launch_transpose(fct, ftc, B, E, T, st);   // (B,E,T) -> (B,T,E)
+  RVCX_HIP(hipMemcpyAsync(feats, ftc, (size_t)B * E * T * 4, hipMemcpyDefault, st));
+  RVCX_HIP(hipStreamSynchronize(st));
   C->arena.reset();
   API_END
 }

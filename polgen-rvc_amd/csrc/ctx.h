@@ -167,7 +167,6 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second stream: RMVPE runs beside HuBERT
-  hipStream_t stream_h = nullptr; // optional CU-masked stream for HuBERT (RVCX_HUBERT_CUS): leaves CUs free for RMVPE
   hipEvent_t ev_hub = nullptr;
   hipEvent_t ev_syn[2] = {nullptr, nullptr};       // the main stream reached micro-batch k's synthesizer
   hipEvent_t ev_hubdone[2] = {nullptr, nullptr};   // HuBERT features of micro-batch k (front set k & 1) are ready
@@ -183,7 +182,7 @@ struct Ctx {
   hipEvent_t ev_src[2] = {nullptr, nullptr};   // NSF source branch (sine + noise convs) beside TextEncoder/flow
   Arena arena;
   Arena arena_f0;                 // RMVPE workspace: lives on stream2 across the main stream's arena resets
-  Arena arena_hub;                // HuBERT workspace: lives on stream_h, so micro-batch k+1's HuBERT runs beside k's decoder
+  Arena arena_hub;                // HuBERT workspace: lives on HuBERT's stream (aux[0]), so micro-batch k+1's HuBERT runs beside k's decoder
   WeightSlab slab;
   std::string last_error;
   double flops = 0.0;
@@ -209,7 +208,7 @@ struct Ctx {
   Ctx();
   ~Ctx();
   // split-K partial-sum scratch, one per stream (RMVPE and HuBERT run concurrently)
-  float* splitk_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // main, stream2, aux0, aux1, stream_h
+  float* splitk_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // main, stream2, aux0 (HuBERT and a decoder branch: one stream, in order), aux1
   static constexpr long kSplitKFloats = 32L << 20;   // 128 MiB per batch item each
   int splitk_items = 1;                              // batch items the buffers are sized for (ensure_splitk)
   // Called before a micro-batch is enqueued: the split-K decision is taken per item (batch invariance), so the
@@ -242,7 +241,7 @@ struct Ctx {
   void conv(const ConvArgs& a) { conv_on(a, stream); }
   void conv_on(ConvArgs a, hipStream_t s) {
     flops += conv_flops(a);
-    const int si = (s == stream2) ? 1 : (s == aux[0] ? 2 : (s == aux[1] ? 3 : ((stream_h && s == stream_h) ? 4 : 0)));
+    const int si = (s == stream2) ? 1 : (s == aux[0] ? 2 : (s == aux[1] ? 3 : 0));
     if (!splitk_buf[si]) RVCX_HIP(hipMalloc(&splitk_buf[si], kSplitKFloats * splitk_items * sizeof(float)));
     a.part = splitk_buf[si];
     a.part_cap = kSplitKFloats * splitk_items;

@@ -107,7 +107,6 @@ Ctx::~Ctx() {
   for (auto s : aux)
     if (s) (void)hipStreamDestroy(s);
   if (stream2) (void)hipStreamDestroy(stream2);
-  if (stream_h) (void)hipStreamDestroy(stream_h);
   if (ev_hub) (void)hipEventDestroy(ev_hub);
   for (auto e : ev_hubdone)
     if (e) (void)hipEventDestroy(e);

@@ -812,7 +812,10 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   front(0);
   const bool use_protect = p.protect < 0.5f;
   const bool use_index = c.index && p.index_rate != 0.f;
-  hipStream_t sh = (c.stream_h && !c.serial) ? c.stream_h : s;   // HuBERT's stream
+  // HuBERT's stream: the decoder's first auxiliary stream, idle while the front end runs (no fifth stream: api.hip).
+  // RVCX_HUBERT_ON=main: the main stream
+  static const bool hub_on_main = getenv("RVCX_HUBERT_ON") && std::string(getenv("RVCX_HUBERT_ON")) == "main";
+  hipStream_t sh = (c.serial || hub_on_main) ? s : c.aux[0];
 
   // ---- chunk jobs of a micro-batch, grouped by chunk length (order of first appearance); group gi's HuBERT
   // features live at fr[k & 1].feats + feats_off[gi]
@@ -933,20 +936,30 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     hub_ev1[k] = clk.mark(sh);
     if (sh != s) RVCX_HIP(hipEventRecord(c.ev_hubdone[k & 1], sh));
   };
-  // One host thread feeds both branches of the front end.  The F0 model goes first, but only as far as its long
-  // launches (mel, the shallow U-Net levels): then all of HuBERT is enqueued (its transformer launches queue up behind
-  // the conv extractor), then the rest of the F0 model's ~300 small launches.  Neither stream waits for the host:
-  // enqueued the other way round HuBERT sat idle for 2.6 ms of a single clip's 10 ms front end.
+  // One host thread feeds both branches of the front end, and the GPU runs them in this order: the F0 model's mel + U-Net
+  // first (throughput work, 3.7 ms of a single clip), then its recurrence (3.3 ms on 16 CUs) with ALL of HuBERT beside it.
+  // HuBERT is enqueued from the F0 model's hook behind the U-Net (rmvpe.hip: RVCX_HUBERT_AFTER) and its stream waits there on the
+  // GPU too (RVCX_HUBERT_GATE=0: no wait).  Round 4, once the two streams really ran side by side (api.hip: the fifth
+  // stream): starting HuBERT beside the shallow U-Net levels (rounds 2-3) slows the U-Net by more than HuBERT gains --
+  // C2 on one box, HuBERT enqueued behind level 2 / 3 / 4 / the intermediate layers / the whole U-Net: 1041-1055 /
+  // 1039-1050 / 1044-1064 / 1058-1072 / 1078-1081x; batched calls do not care (C3 1290 / 1295x with / without the wait).
+  // Other F0 methods have no such hook: HuBERT is enqueued behind them and does not wait.
   int mid_mark = -1;
+  static const bool hub_gate = !getenv("RVCX_HUBERT_GATE") || atoi(getenv("RVCX_HUBERT_GATE")) != 0;
   auto enqueue_models = [&](int k) {
-    bool hub_done = false;
+    bool hub_done = false, from_hook = true;
     const std::function<void()> mid = [&]() {
       if (hub_done) return;
       hub_done = true;
       if (k == 0) mid_mark = clk.mark(sf);
+      if (hub_gate && from_hook && sh != sf) {
+        RVCX_HIP(hipEventRecord(c.ev_hub, sf));
+        RVCX_HIP(hipStreamWaitEvent(sh, c.ev_hub, 0));
+      }
       enqueue_hubert(k);
     };
     enqueue_f0(k, &mid);
+    from_hook = false;
     if (!hub_done) mid();
   };
 

@@ -255,6 +255,10 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   Arena& A = c.arena;
   const int F = (int)(1 + n / HOP), Tp = padded_frames(F);
   const int nenc = m.cfg.en_de_layers;
+  // where the caller's hook (pipeline.hip: "now enqueue HuBERT") runs: behind encoder level 0 .. nenc-1, behind the
+  // intermediate layers (nenc), or behind the whole U-Net, in front of the recurrence (nenc + 1 and above; the default)
+  static const int hook_env = getenv("RVCX_HUBERT_AFTER") ? atoi(getenv("RVCX_HUBERT_AFTER")) : 99;
+  const int hook_at = std::min(hook_env, nenc + 1);
   RVCX_CHECK(Tp % (1 << nenc) == 0, "rmvpe: clip too short for the U-Net depth");
   const int nb = N_FFT / 2 + 1;
   // ---- ragged batch: item b holds ns_host[b] <= n samples.  The launch geometry is that of n for every item; the
@@ -352,7 +356,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
                         (long)Hs[l + 1] * Ws[l + 1], s);
     }
     x = y;
-    if (after_shallow && l == std::min(2, nenc - 1)) (*after_shallow)();
+    if (after_shallow && hook_at < nenc && l == std::min(hook_at, nenc - 1)) (*after_shallow)();
   }
   for (const auto& layer : m.inter)
     for (const auto& blk : layer) {
@@ -360,6 +364,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
       run_block(c, blk, x, y, w1, w2, B, s, d_lv[nenc]);
       x = y;
     }
+  if (after_shallow && hook_at == nenc) (*after_shallow)();
   for (int l = 0; l < nenc; ++l) {
     const int lv = nenc - 1 - l;
     const auto& D = m.dec[l];
@@ -377,6 +382,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
       x = y;
     }
   }
+  if (after_shallow && hook_at == nenc + 1) (*after_shallow)();
   // ---- cnn -> BiGRU -> Linear -> sigmoid   (RMVPE.py:373-376)
   float* cnn = w1;
   {
