@@ -269,6 +269,24 @@ __global__ __launch_bounds__(256) void att_presplit_kernel(const float* __restri
   if (ovf) report_h3_overflow(ovf_word, ovf_layer, seq);
 }
 
+typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));    // a native vector: arrays of HIP's uint4 wrapper stayed in scratch
+template <int NKE, int NVE>
+__device__ __forceinline__ void att_fetch(att_u32x4 (&rk)[NKE], att_u32x4 (&rv)[NVE], const uint4* __restrict__ kp,
+                                          const uint4* __restrict__ vp, int tid) {
+#pragma unroll
+  for (int j = 0; j < NKE; ++j) rk[j] = *reinterpret_cast<const att_u32x4*>(kp + tid + 256 * j);
+#pragma unroll
+  for (int j = 0; j < NVE; ++j) rv[j] = *reinterpret_cast<const att_u32x4*>(vp + tid + 256 * j);
+}
+template <int NKE, int NVE>
+__device__ __forceinline__ void att_commit(const att_u32x4 (&rk)[NKE], const att_u32x4 (&rv)[NVE], uint4* Ks, uint4* Vs,
+                                           int tid) {
+#pragma unroll
+  for (int j = 0; j < NKE; ++j) *reinterpret_cast<att_u32x4*>(Ks + tid + 256 * j) = rk[j];
+#pragma unroll
+  for (int j = 0; j < NVE; ++j) *reinterpret_cast<att_u32x4*>(Vs + tid + 256 * j) = rv[j];
+}
+
 template <int DT>  // D <= 32*DT
 __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ q, const uint4* __restrict__ kimg,
                                                       const uint4* __restrict__ vimg, float* __restrict__ out,
@@ -325,21 +343,14 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
   const int ntile = (T + 31) / 32;
   const uint4* kt_base = kimg + ((long)b * H + hd) * ntile * KSZ;
   const uint4* vt_base = vimg + ((long)b * H + hd) * ntile * VSZ;
-  uint4 rk[NKE], rv[NVE];
+  // (plain arrays handed to force-inlined functions: as captures of [&] lambdas they stayed in scratch memory -- 80 bytes per
+  // thread, a scratch store right behind every prefetch load and a scratch load in front of every commit -- so the
+  // "prefetch under the MFMAs" waited for its loads at once; round 4, found in the disassembly)
+  att_u32x4 rk[NKE], rv[NVE];
   auto fetch = [&](int k0) {
-    const uint4* kp = kt_base + (long)(k0 >> 5) * KSZ;
-    const uint4* vp = vt_base + (long)(k0 >> 5) * VSZ;
-#pragma unroll
-    for (int j = 0; j < NKE; ++j) rk[j] = kp[tid + 256 * j];
-#pragma unroll
-    for (int j = 0; j < NVE; ++j) rv[j] = vp[tid + 256 * j];
+    att_fetch<NKE, NVE>(rk, rv, kt_base + (long)(k0 >> 5) * KSZ, vt_base + (long)(k0 >> 5) * VSZ, tid);
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int j = 0; j < NKE; ++j) Ks[tid + 256 * j] = rk[j];
-#pragma unroll
-    for (int j = 0; j < NVE; ++j) Vs[tid + 256 * j] = rv[j];
-  };
+  auto commit = [&]() { att_commit<NKE, NVE>(rk, rv, Ks, Vs, tid); };
 
   const int tiles = (len + 31) / 32;
   const int klo = (int)((long)tiles * split / nsplit) * 32;
