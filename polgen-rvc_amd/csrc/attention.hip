@@ -288,7 +288,7 @@ __device__ __forceinline__ void att_commit(const att_u32x4 (&rk)[NKE], const att
 }
 
 template <int DT>  // D <= 32*DT
-__global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ q, const uint4* __restrict__ kimg,
+__global__ __launch_bounds__(256, 2) void attn_h3_kernel(const float* __restrict__ q, const uint4* __restrict__ kimg,
                                                       const uint4* __restrict__ vimg, float* __restrict__ out,
                                                       float* __restrict__ m_out, float* __restrict__ l_out,
                                                       const float* __restrict__ relq, int H, int D, int T,
@@ -382,19 +382,31 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
         sacc = att_mfma(a2, qh[s], sacc);
       }
     }
+    // Only two kinds of tile need per-element tests: the few on the relative-position band (TextEncoder) and the one that
+    // holds an item's last key.  Every other tile takes the straight-line form (same arithmetic on the same values: the
+    // tests it drops are all false there) -- round 4: 16 exec-masked branch blocks per tile came out of the common path.
     const bool band = relq && (k0 <= q0 + 31 + window) && (k0 + 31 >= q0 - window);
+    const bool edge = band || k0 + 32 > len;
     float mloc = -INFINITY;
+    if (edge) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float sv = sacc[r] * invS;
-      if (band) {
-        const int rel = key - qi + window;
-        if (rel >= 0 && rel < nrel && qi < T) sv += relrow[rel];
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float sv = sacc[r] * invS;
+        if (band) {
+          const int rel = key - qi + window;
+          if (rel >= 0 && rel < nrel && qi < T) sv += relrow[rel];
+        }
+        if (key >= len) sv = -INFINITY;
+        sacc[r] = sv;
+        mloc = fmaxf(mloc, sv);
       }
-      if (key >= len) sv = -INFINITY;
-      sacc[r] = sv;
-      mloc = fmaxf(mloc, sv);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] *= invS;
+        mloc = fmaxf(mloc, sacc[r]);
+      }
     }
     const float mtile = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mtile);
@@ -403,7 +415,8 @@ __global__ __launch_bounds__(256) void attn_h3_kernel(const float* __restrict__ 
     ahalf8 ph[2], pl[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = (sacc[r] == -INFINITY) ? 0.f : ((kAttAbl & 8) ? sacc[r] - m_new : __expf(sacc[r] - m_new));
+      float p = (kAttAbl & 8) ? sacc[r] - m_new : __expf(sacc[r] - m_new);
+      if (edge) p = (sacc[r] == -INFINITY) ? 0.f : p;      // (exp(-inf - m) is 0 too, but m itself may be -inf there)
       lloc += p;
       const _Float16 vh = (_Float16)p;
       ph[r >> 3][r & 7] = vh;
