@@ -1,13 +1,13 @@
 #!/bin/bash
-# C2 front-end scheduling sweep: HuBERT on its own stream (RVCX_HUBERT_ON_AUX unset) or on the decoder's aux stream 0/1, where in the
-# F0 model's launch sequence it is enqueued (RVCX_HUBERT_AFTER: behind U-Net encoder level 0..4, 5 = behind the intermediate
-# layers, 6 = behind the whole U-Net) and whether its stream also waits there on the GPU (RVCX_HUBERT_GATE)
+# C2 front-end scheduling sweep: where in the F0 model's launch sequence HuBERT is enqueued (RVCX_HUBERT_AFTER: behind U-Net
+# encoder level 0..4, 5 = behind the intermediate layers, 6 = behind the whole U-Net = default), whether its stream also waits
+# there on the GPU (RVCX_HUBERT_GATE, default 1), and HuBERT on the main stream instead of aux[0] (third field "main")
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
-for cfg in ${CFGS:-"- 2 0" "0 2 0" "0 2 1" "0 3 1" "0 4 1" "0 5 1" "0 6 1" "1 5 1"}; do
+for cfg in ${CFGS:-"6 1 aux" "6 0 aux" "5 1 aux" "4 1 aux" "2 1 aux" "2 0 aux" "6 1 main"}; do
   set -- $cfg
-  [ "$1" = "-" ] && unset RVCX_HUBERT_ON_AUX || export RVCX_HUBERT_ON_AUX=$1
-  echo -n "aux $1 after $2 gate $3: "; RVCX_HUBERT_AFTER=$2 RVCX_HUBERT_GATE=$3 python bench.py --no-cpu-baseline --no-children --no-roofline --steps 20 2>/dev/null | python3 -c "
+  [ "$3" = "main" ] && export RVCX_HUBERT_ON=main || unset RVCX_HUBERT_ON
+  echo -n "after $1 gate $2 on $3: "; RVCX_HUBERT_AFTER=$1 RVCX_HUBERT_GATE=$2 python bench.py --no-cpu-baseline --no-children --no-roofline --steps 20 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
