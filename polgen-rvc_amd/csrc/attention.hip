@@ -533,7 +533,8 @@ __global__ __launch_bounds__(256) void rel_logits_kernel(const float* __restrict
   extern __shared__ float eks[];  // [nrel][D]
   for (int idx = threadIdx.x; idx < nrel * D; idx += 256) eks[idx] = ek[idx];
   __syncthreads();
-  const int tq = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int tq = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nmine = part < nrel ? (nrel - part + 3) / 4 : 0;       // rows r = part + 4 i < nrel
   const int t = blockIdx.x * 64 + tq;
   const int hd = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
@@ -547,21 +548,34 @@ __global__ __launch_bounds__(256) void rel_logits_kernel(const float* __restrict
     float qv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) qv[u] = qb[(long)(d + u) * ld + t] * scale;
+    // a wave holds one `part`: its rows r = part + 4 i are the same for every lane -- a scalar count instead of an
+    // exec-masked test around every FMA, and the embedding row read 16 bytes at a time (round 4; per output the order of
+    // the sum is unchanged)
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int i = 0; i < 8; ++i)
+      if (i < nmine) {
+        const float* e = eks + (part + 4 * i) * D + d;
+        if ((D & 3) == 0) {
+          const float4 e0 = *reinterpret_cast<const float4*>(e), e1 = *reinterpret_cast<const float4*>(e + 4);
+          acc[i] = fmaf(qv[0], e0.x, acc[i]);
+          acc[i] = fmaf(qv[1], e0.y, acc[i]);
+          acc[i] = fmaf(qv[2], e0.z, acc[i]);
+          acc[i] = fmaf(qv[3], e0.w, acc[i]);
+          acc[i] = fmaf(qv[4], e1.x, acc[i]);
+          acc[i] = fmaf(qv[5], e1.y, acc[i]);
+          acc[i] = fmaf(qv[6], e1.z, acc[i]);
+          acc[i] = fmaf(qv[7], e1.w, acc[i]);
+        } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = part + 4 * i;
-        if (r < nrel) acc[i] = fmaf(qv[u], eks[r * D + d + u], acc[i]);
+          for (int u = 0; u < 8; ++u) acc[i] = fmaf(qv[u], e[u], acc[i]);
+        }
       }
   }
   for (; d < D; ++d) {
     const float qv = qb[(long)d * ld + t] * scale;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = part + 4 * i;
-      if (r < nrel) acc[i] = fmaf(qv, eks[r * D + d], acc[i]);
-    }
+    for (int i = 0; i < 8; ++i)
+      if (i < nmine) acc[i] = fmaf(qv, eks[(part + 4 * i) * D + d], acc[i]);
   }
   float* o = relq + (((long)b * H + hd) * T + t) * nrel;
 #pragma unroll
