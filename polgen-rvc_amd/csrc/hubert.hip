@@ -107,14 +107,17 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
   const int *d_t0 = nullptr, *d_T = nullptr;
   std::vector<const int*> d_tl(cf.n_conv, nullptr);     // valid frames behind extractor layer i
   if (ragged) {
-    d_t0 = dev_ints(A, t0b, s);
-    d_T = dev_ints(A, Tb, s);
+    std::vector<std::vector<int>> all{t0b, Tb};
     std::vector<int> tl(t0b);
-    d_tl[0] = d_t0;
     for (int i = 1; i < cf.n_conv; ++i) {
       for (auto& t : tl) t = (t - cf.conv_kernels[i]) / cf.conv_strides[i] + 1;
-      d_tl[i] = dev_ints(A, tl, s);
+      all.push_back(tl);
     }
+    const std::vector<int*> d = dev_ints_many(A, all, s);
+    d_t0 = d[0];
+    d_T = d[1];
+    d_tl[0] = d_t0;
+    for (int i = 1; i < cf.n_conv; ++i) d_tl[i] = d[1 + i];
   }
   float* bufa = A.alloc<float>((size_t)B * C * t0);
   float* bufb = A.alloc<float>((size_t)B * C * t0);

@@ -86,6 +86,7 @@ void launch_reflect_pad(const float* x, float* y, int B, int n, int p, long y_bs
 int* dev_ints(Arena& A, const int* v, int n, hipStream_t s);
 void set_dev_ints(int* dst, const int* v, int n, hipStream_t s);      // the same into memory the caller owns
 inline int* dev_ints(Arena& A, const std::vector<int>& v, hipStream_t s) { return dev_ints(A, v.data(), (int)v.size(), s); }
+std::vector<int*> dev_ints_many(Arena& A, const std::vector<std::vector<int>>& vs, hipStream_t s);   // one launch for all of them
 // |STFT|: ft (B, 2*nb, F) -> mag (B, nb, F) = sqrt(re^2 + im^2 + eps)   (eps: FCPE.py:147)
 void launch_magnitude(const float* ft, float* mag, int B, int nb, int F, hipStream_t s, float eps = 0.f);
 // log(clamp(mel,1e-5)) -> BN affine -> row-padded (B,1,Tp,Wp=130) with reflect padding of frames to Tp

@@ -614,6 +614,37 @@ int* dev_ints(Arena& A, const int* v, int n, hipStream_t s) {
   return d;
 }
 
+namespace {
+struct IntPack8 {
+  int v[256];
+};
+__global__ void set_ints8_kernel(int* dst, IntPack8 pk, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = pk.v[threadIdx.x];
+}
+}  // namespace
+// several arrays behind one launch (a model's per-level length arrays: HuBERT needs 8, the F0 model 9 -- one tiny launch
+// each was 40-55 us of serial path at the head of either model)
+std::vector<int*> dev_ints_many(Arena& A, const std::vector<std::vector<int>>& vs, hipStream_t s) {
+  size_t total = 0;
+  for (const auto& v : vs) total += std::max<size_t>(v.size(), 1);
+  int* d = A.alloc<int>(total);
+  std::vector<int> flat(total, 0);
+  std::vector<int*> out;
+  size_t o = 0;
+  for (const auto& v : vs) {
+    out.push_back(d + o);
+    std::copy(v.begin(), v.end(), flat.begin() + o);
+    o += std::max<size_t>(v.size(), 1);
+  }
+  for (size_t c = 0; c < total; c += 256) {
+    IntPack8 pk;
+    const int m = (int)std::min<size_t>(256, total - c);
+    for (int i = 0; i < 256; ++i) pk.v[i] = i < m ? flat[c + i] : 0;
+    hipLaunchKernelGGL(set_ints8_kernel, dim3(1), dim3(256), 0, s, d + c, pk, m);
+  }
+  return out;
+}
+
 __global__ void magnitude_kernel(const float* ft, float* mag, int nb, int F, long total, float eps) {
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long b = idx / ((long)nb * F);

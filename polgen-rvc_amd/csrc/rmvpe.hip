@@ -277,14 +277,17 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   const int *d_ns = nullptr, *d_F = nullptr, *d_T = nullptr;
   std::vector<const int*> d_lv(nenc + 1, nullptr);     // valid flat positions per U-Net level
   if (ragged) {
-    d_ns = dev_ints(A, ns_host, B, s);
-    d_F = dev_ints(A, Fb, s);
-    d_T = dev_ints(A, Tb, s);
+    std::vector<std::vector<int>> all{std::vector<int>(ns_host, ns_host + B), Fb, Tb};
     for (int l = 0; l <= nenc; ++l) {
       std::vector<int> v(B);
       for (int b = 0; b < B; ++b) v[b] = (Tb[b] >> l) * ((N_MELS >> l) + 2);
-      d_lv[l] = dev_ints(A, v, s);
+      all.push_back(v);
     }
+    const std::vector<int*> d = dev_ints_many(A, all, s);     // one launch
+    d_ns = d[0];
+    d_F = d[1];
+    d_T = d[2];
+    for (int l = 0; l <= nenc; ++l) d_lv[l] = d[3 + l];
   }
   // ---- mel
   const int Mh = cdiv((int)n + N_FFT, HOP);     // hops covering the reflect-padded signal
