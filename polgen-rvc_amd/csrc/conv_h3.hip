@@ -355,15 +355,20 @@ struct H3Cfg {
   void (*kern_xs)(const ConvArgs);   // same tile reading a pre-split input (null: none)
 };
 const H3Cfg kH3[] = {
-    // 1-D, halo <= 64
-    {32, 256, 64, 1, false, 18.f, 1.00f, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false>, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false, true>},
-    {64, 128, 64, 1, false, 16.f, 0.97f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false, true>},
+    // 1-D, halo <= 64.  Round 4 (tools/sweep_tiles_1d.py, profiles/sweep_tiles_1d_r04.txt): the 64 x 64 tile beats both wide
+    // tiles on EVERY 1-D shape of the path -- 1.1x on the C = 256 ResBlock convs, 1.4-1.6x on conv_pre / the first two
+    // upsamplers / C = 128 k = 7, 1.9-2.4x on the thin upsamplers and C <= 64 (64 -> 64, 2 taps, 767 k positions: 175 against
+    // 427 us) -- and the round-2 efficiencies (1.00 / 0.97 / 0.75, fitted before the staging and epilogue rewrites) sent most
+    // of them to the wide ones.  The wide tiles stay selectable (RVCX_CONV_TILE, tested bit-identical) at efficiencies that
+    // keep them out of the automatic choice; the 64 x 64 entry keeps its own number, so its split-K decisions are unchanged.
+    {32, 256, 64, 1, false, 18.f, 0.40f, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false>, conv_h3_kernel<32, 256, 1, 4, 4, 64, 1, false, true>},
+    {64, 128, 64, 1, false, 16.f, 0.45f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 1, false, true>},
     {64, 64, 64, 1, false, 16.f, 0.75f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false>, conv_h3_kernel<64, 64, 2, 2, 4, 64, 1, false, true>},
     // 3x3 on row-padded maps
     {32, 128, 320, 1, false, 22.f, 1.00f, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false>, conv_h3_kernel<32, 128, 1, 4, 4, 320, 1, false, true>},
     {64, 64, 320, 1, false, 20.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false>, conv_h3_kernel<64, 64, 2, 2, 4, 320, 1, false, true>},
     // stride 2
-    {64, 128, 64, 2, false, 18.f, 1.00f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false, true>},
+    {64, 128, 64, 2, false, 18.f, 0.50f, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false>, conv_h3_kernel<64, 128, 2, 2, 2, 64, 2, false, true>},   // (the same finding: 64 x 64 is 1.25x faster on the extractor's layers)
     {64, 64, 64, 2, false, 16.f, 0.80f, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false>, conv_h3_kernel<64, 64, 2, 2, 4, 64, 2, false, true>},
     // k = 1
     {64, 64, 0, 1, true, 16.f, 0.95f, conv_h3_kernel<64, 64, 2, 2, 4, 0, 1, true>, nullptr},
