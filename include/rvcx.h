@@ -306,7 +306,9 @@ int64_t rvcx_gru_fallbacks(rvcx_ctx*);
 /* retrieval: queries whose 8 neighbours could not be certified from the split-fp16 pre-filter and were searched
  * exhaustively instead (csrc/index.hip) since the last call of this function; waits for the device.  -1: no index */
 int64_t rvcx_index_exhaustive(rvcx_ctx*);
-/* test hook: what = 1 makes the next call behave as if the BiGRU cluster kernel had timed out */
+/* test hook: what = 1 makes the next call behave as if the BiGRU cluster kernel had timed out; what = 3 makes the next BiGRU
+ * cluster launch of the calling thread lose one workgroup, so that its partners really run into the device-side time-out
+ * (~1.5 s) and the call is repeated on the single-workgroup kernel; what = 2 reads and clears the raw device error word */
 int rvcx_debug_inject(rvcx_ctx*, int what);
 /* algorithmic FLOPs issued by conv/GEMM/attention launches since the last reset */
 double rvcx_flop_counter(rvcx_ctx*, int reset);

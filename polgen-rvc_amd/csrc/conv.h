@@ -103,6 +103,7 @@ struct PairArgs {
 constexpr float kH3ActLimit = 6.0e4f;
 constexpr int kErrGruTimeout = 1, kErrH3Overflow = 2;
 extern thread_local bool g_force_fp32;
+extern thread_local int g_gru_drop_member;   // test hook: the next BiGRU cluster launch loses one workgroup (a real device-side time-out)
 extern thread_local bool g_gru_no_cluster;   // this attempt of the API call runs the single-workgroup BiGRU kernel (gru.hip)
 bool resblock_pair_enabled();                                // RVCX_FUSE (default on) and the h3 kernels enabled
 bool resblock_pair_ok(const PairArgs& a);

@@ -393,6 +393,7 @@ constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
 
 thread_local bool g_force_fp32 = false;
 thread_local bool g_gru_no_cluster = false;
+thread_local int g_gru_drop_member = 0;
 
 bool conv_h3_enabled() {
   static const int mode = getenv("RVCX_H3") ? atoi(getenv("RVCX_H3")) : 1;   // initialised once, thread-safe

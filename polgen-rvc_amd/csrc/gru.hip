@@ -329,7 +329,7 @@ __global__ __launch_bounds__((GruUnitGeom<NC, CPT>::THREADS)) void bigru_unit_ke
                                                                                      float* __restrict__ y,
                                                                                      unsigned long long* xbuf, int* err, int T,
                                                                                      int nq, int colocate,
-                                                                                     const int* __restrict__ lens) {
+                                                                                     const int* __restrict__ lens, int drop) {
   using G = GruUnitGeom<NC, CPT>;
   constexpr int H = GRU_H, U = G::U, NCS = G::NCS, THREADS = G::THREADS, GATHER0 = 64;
   __shared__ __attribute__((aligned(16))) float hs[H];
@@ -346,6 +346,7 @@ __global__ __launch_bounds__((GruUnitGeom<NC, CPT>::THREADS)) void bigru_unit_ke
     q = blockIdx.x / NC;
   }
   if (q >= nq) return;
+  if (drop && c == NC - 1) return;          // test hook (rvcx_debug_inject 3): this member never shows up, its partners time out
   __builtin_amdgcn_s_setprio(3);
   const int dir = q & 1, b = q >> 1;
   const int Tn = lens ? lens[b] : T;
@@ -532,12 +533,14 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
     // RVCX_GRU_FORM: 0 = the round-3 kernel (4 rows x 32 columns per thread, scalar FMAs; it hosts the RVCX_GRU_B128
     // reproducer), 1 = unit rows + packed FMAs, 256 threads, 2 = the same with 512 threads (default)
     static const int form = getenv("RVCX_GRU_FORM") ? atoi(getenv("RVCX_GRU_FORM")) : 2;
+    const int drop = g_gru_drop_member;
+    g_gru_drop_member = 0;
     if (nc == 4 && form == 1)
       hipLaunchKernelGGL((bigru_unit_kernel<4, 64>), dim3(grid), dim3(GruUnitGeom<4, 64>::THREADS), 0, stream, gi, whh_t, bhh,
-                         y, xbuf, err, T, nq, colocate, lens);
+                         y, xbuf, err, T, nq, colocate, lens, drop);
     else if (nc == 4 && form == 2)
       hipLaunchKernelGGL((bigru_unit_kernel<4, 32>), dim3(grid), dim3(GruUnitGeom<4, 32>::THREADS), 0, stream, gi, whh_t, bhh,
-                         y, xbuf, err, T, nq, colocate, lens);
+                         y, xbuf, err, T, nq, colocate, lens, drop);
     else if (nc == 8)
       hipLaunchKernelGGL((bigru_cluster_kernel<8, 16>), dim3(grid), dim3(GruGeom<8, 16>::THREADS), 0, stream, gi, whh_t, bhh,
                          y, xbuf, err, T, nq, colocate, lens);

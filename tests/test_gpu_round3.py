@@ -171,6 +171,28 @@ def test_gru_cluster_timeout_falls_back_to_the_plain_kernel(ctx):
         c.close()
 
 
+def test_gru_cluster_that_really_loses_a_member_times_out_on_the_device_and_falls_back():
+    """Round 4: not an injected flag but the kernel's own time-out -- one workgroup of the BiGRU cluster returns at once
+    (rvcx_debug_inject 3), its partners spin out of their poll limit in the XCD-id exchange, report through the device error
+    word, and the call is repeated on the single-workgroup kernel with the same F0."""
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    cfg = S.RMVPE_CFG_FULL
+    c = _lib.Context(0)
+    try:
+        c.load_rmvpe(W.rmvpe_cfg_struct(cfg), S.rmvpe_state(cfg, 1900))
+        audio = S.make_clip(3, 2.0)
+        f0a = c.rmvpe_f0(audio)
+        n0 = c.gru_fallbacks()
+        c.debug_inject(3)
+        f0b = c.rmvpe_f0(audio)
+        assert c.gru_fallbacks() == n0 + 1
+        v = (f0a > 0) & (f0b > 0)
+        assert np.mean((f0a > 0) != (f0b > 0)) < 0.01 and np.abs(f0a[v] - f0b[v]).max() / f0a[v].max() < 1e-3
+        assert np.array_equal(c.rmvpe_f0(audio), f0a) and c.gru_fallbacks() == n0 + 1
+    finally:
+        c.close()
+
+
 def test_two_contexts_on_two_threads_reproduce_their_solo_results():
     """Round 3 found a kernel (the BiGRU cluster kernel's 16-byte LDS stores) whose results varied only while ANOTHER
     LDS-heavy kernel was resident on the same CU -- no single-context test saw it.  Here two contexts convert different
