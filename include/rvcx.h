@@ -6,8 +6,12 @@
  * them with ctypes behind the reference's own call signatures.
  *
  * Conventions: return 0 on success, negative on error (message via rvcx_last_error);
- * nothing throws across the ABI.  One context per GPU; calls on one context are
- * serialised by the caller, different contexts are fully concurrent.  "hd" pointers may
+ * nothing throws across the ABI.  One context per GPU.  Every entry point takes the
+ * context's own (recursive) mutex: threads that share a context QUEUE -- the reference
+ * builds fresh model objects per request (rvc/scripts/voice_conversion.py:71-100), so
+ * its concurrent requests are safe, and they stay safe here -- while different contexts
+ * are fully concurrent.  Throughput comes from one rvcx_convert_batch call over many
+ * utterances, not from threads.  rvcx_destroy must not race with any other call.  "hd" pointers may
  * be host or device memory (copied with hipMemcpyDefault); everything else is host.
  * All tensors are dense row-major float32 unless stated.
  */
@@ -291,6 +295,9 @@ int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, do
                       int32_t* bn, int32_t* kind, int cap);
 /* per-launch table (CSV text: tile,B,cin,cout,k,stride,nout,gflop,ms,tflops) of the last profile */
 const char* rvcx_conv_profile_csv(rvcx_ctx*);
+/* name and memory size of GPU `device` (no context needed) -- what Config._configure_gpu reads through
+ * torch.cuda.get_device_name / get_device_properties, rvc/infer/infer.py:49-63.  -1 without a visible device. */
+int rvcx_device_info(int device, char* name, int name_cap, int64_t* total_bytes);
 /* free / total bytes of the context's GPU (hipMemGetInfo): what is left for further voice models and indices */
 int rvcx_mem_info(rvcx_ctx*, int64_t* free_bytes, int64_t* total_bytes);
 /* calls this context repeated because a split-fp16 kernel met an activation beyond
@@ -306,6 +313,9 @@ int64_t rvcx_gru_fallbacks(rvcx_ctx*);
 /* retrieval: queries whose 8 neighbours could not be certified from the split-fp16 pre-filter and were searched
  * exhaustively instead (csrc/index.hip) since the last call of this function; waits for the device.  -1: no index */
 int64_t rvcx_index_exhaustive(rvcx_ctx*);
+/* DEBUG HOOKS -- rvcx_debug_inject, rvcx_bench_resblock_pair, rvcx_bench_conv1d, rvcx_bench_gemm, rvcx_conv_override are
+ * process-wide tuning / fault-injection levers.  They return -2 ("refused") unless the process was started with
+ * RVCX_DEBUG=1 in its environment (read once); the product path never calls them. */
 /* test hook: what = 1 makes the next call behave as if the BiGRU cluster kernel had timed out; what = 3 makes the next BiGRU
  * cluster launch of the calling thread lose one workgroup, so that its partners really run into the device-side time-out
  * (~1.5 s) and the call is repeated on the single-workgroup kernel; what = 2 reads and clears the raw device error word */
@@ -337,7 +347,7 @@ int rvcx_bench_resblock_pair(rvcx_ctx*, int B, int C, int T, int K, int dil, int
  * y = conv1d(lrelu(x)) + bias + res, average milliseconds per launch (HIP events on the library stream) */
 int rvcx_bench_conv1d(rvcx_ctx*, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
                       int iters, float* ms_per_launch);
-/* tuning hook for the tile-selection sweep (tools/sweep_conv.py): force the conv_fast tile index, the
+/* tuning hook for the tile-selection sweeps (tools/sweep_tiles_1d.py, sweep_unet.py, bench_conv.py): force the conv_fast tile index, the
  * staging variant (ignored: the LDS-DMA variant was removed in round 2) and the split-K factor; -1 = heuristic.
  * Process-wide; never set by the product path. */
 int rvcx_conv_override(int tile, int variant, int splitk);

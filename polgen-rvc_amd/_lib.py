@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -83,7 +84,7 @@ SYMBOLS = [
     "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
     "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
-    "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm",
+    "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm", "rvcx_device_info",
 ]
 
 
@@ -109,6 +110,15 @@ def lib() -> C.CDLL:
         _lib.rvcx_crepe_frames.restype = C.c_int64
         _lib.rvcx_index_exhaustive.restype = C.c_int64
     return _lib
+
+
+def device_info(device: int = 0):
+    """(name, total bytes) of GPU `device`, or (None, None) when no HIP device is visible"""
+    name = C.create_string_buffer(256)
+    total = C.c_int64(0)
+    if lib().rvcx_device_info(int(device), name, 256, C.byref(total)) != 0:
+        return None, None
+    return name.value.decode(), int(total.value)
 
 
 def f0_file_track(inp_f0) -> np.ndarray:
@@ -175,6 +185,10 @@ class Context:
         if rc != 0:
             raise RvcxError("rvcx_create: " + (lib().rvcx_last_error(None) or b"").decode())
         self.device = device
+        # Every C entry point takes the context's own mutex (csrc/api.hip), so threads that share this object queue
+        # instead of racing.  Multi-call sequences that must not interleave -- "make this index resident, then convert
+        # with it" in the mirror's VC.pipeline -- hold this lock around the whole sequence.
+        self.lock = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -231,7 +245,9 @@ class Context:
 
     @staticmethod
     def conv_override(tile=-1, variant=-1, splitk=-1):
-        lib().rvcx_conv_override(tile, variant, splitk)
+        """tuning hook; the library refuses it (and debug_inject / bench_*) unless the process started with RVCX_DEBUG=1"""
+        if lib().rvcx_conv_override(tile, variant, splitk) != 0:
+            raise RvcxError("conv_override: " + (lib().rvcx_last_error(None) or b"").decode())
 
     def bench_conv1d(self, B, Cin, Tin, Cout, K, stride=1, dil=1, groups=1, iters=10):
         ms = C.c_float(0)

@@ -2,6 +2,7 @@
 #include "../../include/rvcx.h"
 
 #include <cstdlib>
+#include <mutex>
 
 #include "ctx.h"
 #include "layers.h"
@@ -11,9 +12,17 @@
 
 using namespace rvcx;
 
+// One context = one set of streams, arenas and resident models.  The reference builds fresh model objects for every
+// request (rvc/scripts/voice_conversion.py:71-100), so two Gradio worker threads never share state there; here every
+// thread of a process shares the one resident context (infer/_state.py) and ctypes releases the GIL -- so every entry
+// point takes the context's mutex (recursive: an entry point may call another).  Calls on one context QUEUE; throughput
+// comes from rvcx_convert_batch (one call, many utterances), not from threads.  Different contexts stay concurrent.
 struct rvcx_ctx {
   Ctx c;
+  std::recursive_mutex mu;
 };
+using CtxLock = std::unique_lock<std::recursive_mutex>;
+static CtxLock lock_ctx(rvcx_ctx* h) { return h ? CtxLock(h->mu) : CtxLock(); }
 
 static thread_local std::string g_last_error;
 
@@ -69,6 +78,7 @@ static void reset_after_failure(Ctx& c) {
 template <typename F>
 static int api_call(rvcx_ctx* ctxp, bool repeat, F&& body) {
   Ctx* C = ctxp ? &ctxp->c : nullptr;
+  CtxLock guard = lock_ctx(ctxp);
   try {
     if (!C) fail("null context");
     RVCX_HIP(hipSetDevice(C->device));
@@ -107,6 +117,23 @@ static int api_call(rvcx_ctx* ctxp, bool repeat, F&& body) {
     return -1;
   }
 }
+
+// Tuning / fault-injection hooks (rvcx_conv_override, rvcx_debug_inject, rvcx_bench_*) are process-wide levers a serving
+// process must never meet by accident: they are refused (-2) unless the process was started with RVCX_DEBUG=1
+// (read once; tests/conftest.py and tools/ set it).
+static bool debug_hooks_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RVCX_DEBUG");
+    return e && atoi(e) != 0;
+  }();
+  return on;
+}
+#define REQUIRE_DEBUG(ctxp, name)                                                             \
+  if (!debug_hooks_enabled()) {                                                               \
+    g_last_error = name ": debug / tuning hook refused (start the process with RVCX_DEBUG=1)"; \
+    if ((ctxp) != nullptr) ((rvcx_ctx*)(ctxp))->c.last_error = g_last_error;                        \
+    return -2;                                                                                \
+  }
 
 #define API_BEGIN(ctxp) return api_call((ctxp), true, [&](Ctx* C) {
 #define API_BEGIN_ONCE(ctxp) return api_call((ctxp), false, [&](Ctx* C) {
@@ -194,10 +221,33 @@ void rvcx_destroy(rvcx_ctx* ctx) {
 }
 
 const char* rvcx_last_error(rvcx_ctx* ctx) {
-  return ctx ? ctx->c.last_error.c_str() : g_last_error.c_str();
+  // a copy per calling thread: another thread's failing call may replace the context's string at any time
+  static thread_local std::string copy;
+  if (!ctx) return g_last_error.c_str();
+  CtxLock guard = lock_ctx(ctx);
+  copy = ctx->c.last_error;
+  return copy.c_str();
 }
 
-void* rvcx_stream(rvcx_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+void* rvcx_stream(rvcx_ctx* ctx) { CtxLock ctx_guard_ = lock_ctx(ctx); return ctx ? (void*)ctx->c.stream : nullptr; }
+
+int rvcx_device_info(int device, char* name, int name_cap, int64_t* total_bytes) {
+  try {
+    int n = 0;
+    RVCX_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) fail("device index out of range");
+    hipDeviceProp_t prop;
+    RVCX_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_cap > 0) {
+      snprintf(name, (size_t)name_cap, "%s", prop.name);
+    }
+    if (total_bytes) *total_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return -1;
+  }
+}
 
 int rvcx_mem_info(rvcx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
   API_BEGIN_ONCE(ctx)
@@ -208,18 +258,20 @@ int rvcx_mem_info(rvcx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
   API_END
 }
 
-int64_t rvcx_fp32_reruns(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.fp32_reruns : -1; }
+int64_t rvcx_fp32_reruns(rvcx_ctx* ctx) { CtxLock ctx_guard_ = lock_ctx(ctx); return ctx ? (int64_t)ctx->c.fp32_reruns : -1; }
 
 int64_t rvcx_fp32_layers(rvcx_ctx* ctx) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx) return -1;
   int64_t n = 0;
   for (WeightRegion* r : all_regions(ctx->c, nullptr)) n += r->dropped();
   return n;
 }
 
-int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
+int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { CtxLock ctx_guard_ = lock_ctx(ctx); return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
 
 int64_t rvcx_index_exhaustive(rvcx_ctx* ctx) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || !ctx->c.index || !ctx->c.index->exhaustive) return -1;
   int v = 0;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
@@ -229,6 +281,8 @@ int64_t rvcx_index_exhaustive(rvcx_ctx* ctx) {
 }
 
 int rvcx_debug_inject(rvcx_ctx* ctx, int what) {
+  REQUIRE_DEBUG(ctx, "rvcx_debug_inject")
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (ctx && what == 2) {          // read and clear the raw device error word (debugging builds set extra bits)
     int v = 0;
     (void)hipMemcpy(&v, ctx->c.dev_err, sizeof(int), hipMemcpyDeviceToHost);
@@ -245,6 +299,7 @@ int rvcx_debug_inject(rvcx_ctx* ctx, int what) {
 }
 
 double rvcx_flop_counter(rvcx_ctx* ctx, int reset) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx) return 0.0;
   double f = ctx->c.flops;
   if (reset) ctx->c.flops = 0.0;
@@ -381,6 +436,7 @@ int rvcx_op_resblock_pair(rvcx_ctx* ctx, const float* x, const float* w1, const 
 
 int rvcx_bench_resblock_pair(rvcx_ctx* ctx, int B, int Cc, int T, int K, int dil, int fused, int iters,
                              float* ms_per_launch) {
+  REQUIRE_DEBUG(ctx, "rvcx_bench_resblock_pair")
   API_BEGIN(ctx)
   TEMP_REGION(C);
   const size_t n = (size_t)B * Cc * T;
@@ -468,6 +524,7 @@ int rvcx_bench_resblock_pair(rvcx_ctx* ctx, int B, int Cc, int T, int K, int dil
 }
 
 int rvcx_conv_override(int tile, int variant, int splitk) {
+  REQUIRE_DEBUG(nullptr, "rvcx_conv_override")
   rvcx::g_conv_override.tile = tile;
   rvcx::g_conv_override.variant = variant;
   rvcx::g_conv_override.splitk = splitk;
@@ -476,6 +533,7 @@ int rvcx_conv_override(int tile, int variant, int splitk) {
 
 int rvcx_bench_conv1d(rvcx_ctx* ctx, int B, int Cin, int Tin, int Cout, int K, int stride, int dil, int groups,
                       int iters, float* ms_per_launch) {
+  REQUIRE_DEBUG(ctx, "rvcx_bench_conv1d")
   API_BEGIN(ctx)
   TEMP_REGION(C);
   const int pad = (K * dil - dil) / 2;
@@ -667,6 +725,7 @@ static SynthModel& get_synth(Ctx& c, int id) {
 }
 
 int rvcx_synth_upp(rvcx_ctx* ctx, int model_id) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
   return ctx->c.synths[model_id]->upp;
 }
@@ -691,6 +750,7 @@ static std::vector<WeightRegion*> all_regions(Ctx& c, uint64_t* hash) {
 }
 
 int rvcx_weights_regions(rvcx_ctx* ctx, int cap, void** dev_ptrs, int64_t* nbytes, uint64_t* layout_hash) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   Ctx* C = ctx ? &ctx->c : nullptr;
   try {
     if (!C) fail("null context");
@@ -711,6 +771,13 @@ int rvcx_weights_regions(rvcx_ctx* ctx, int cap, void** dev_ptrs, int64_t* nbyte
 }
 
 int rvcx_weights_clone(rvcx_ctx* ctx, rvcx_ctx* src) {
+  // both contexts' mutexes, acquired deadlock-free (two threads cloning A <- B and B <- A)
+  CtxLock ga, gb;
+  if (ctx && src && ctx != src) {
+    ga = CtxLock(ctx->mu, std::defer_lock);
+    gb = CtxLock(src->mu, std::defer_lock);
+    std::lock(ga, gb);
+  }
   API_BEGIN_ONCE(ctx)
   if (!src) fail("weights_clone: null source context");
   if (src->c.device != C->device) fail("weights_clone: contexts live on different devices (use the RCCL broadcast)");
@@ -743,6 +810,7 @@ static int synth_infer_impl(rvcx_ctx* ctx, int model_id, int B, int T, const int
 int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                      const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
                      const float* src_noise, uint64_t seed, float* out) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, nullptr,
                           nullptr);
 }
@@ -750,6 +818,7 @@ int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* l
 int rvcx_synth_infer_taps(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                           const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
                           const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, stats,
                           zflow);
 }
@@ -869,6 +938,7 @@ int rvcx_op_gemm_tm(rvcx_ctx* ctx, const float* x_cf, const float* w, const floa
 }
 
 int rvcx_bench_gemm(rvcx_ctx* ctx, int64_t rows, int Cin, int Cout, int iters, float* ms_per_launch) {
+  REQUIRE_DEBUG(ctx, "rvcx_bench_gemm")
   API_BEGIN(ctx)
   TEMP_REGION(C);
   C->arena.reserve(((size_t)rows * ((size_t)Cin + 2 * (size_t)Cout)) * 4 + (64 << 20));
@@ -1151,6 +1221,7 @@ int rvcx_rmvpe_mel(rvcx_ctx* ctx, int B, const float* audio, int64_t n, float* m
 }
 
 int rvcx_hubert_frames(rvcx_ctx* ctx, int64_t n) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || !ctx->c.hubert) return -1;
   return hubert_frames(*ctx->c.hubert, n);
 }
@@ -1259,11 +1330,13 @@ int rvcx_index_blend(rvcx_ctx* ctx, float* feats, int T, float index_rate, int64
 }
 
 int64_t rvcx_out_len(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
   return out_capacity(*ctx->c.synths[model_id], n, *p);
 }
 
 int64_t rvcx_noise_len(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
   return noise_len_for(ctx->c, *ctx->c.synths[model_id], n, *p);
 }
@@ -1306,24 +1379,28 @@ static int convert_impl(rvcx_ctx* ctx, int model_id, int B, const float* const* 
 int rvcx_convert_batch(rvcx_ctx* ctx, int model_id, int B, const float* const* wav16k, const int64_t* n,
                        const rvcx_params* p, const float* const* noise, int16_t* const* out, float* const* out_f32,
                        int64_t* out_n) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   return convert_impl(ctx, model_id, B, wav16k, nullptr, n, p, noise, out, out_f32, out_n);
 }
 
 int rvcx_convert_batch_f64(rvcx_ctx* ctx, int model_id, int B, const double* const* wav16k, const int64_t* n,
                            const rvcx_params* p, const float* const* noise, int16_t* const* out,
                            float* const* out_f32, int64_t* out_n) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   return convert_impl(ctx, model_id, B, nullptr, wav16k, n, p, noise, out, out_f32, out_n);
 }
 
 int rvcx_convert_batch_ex(rvcx_ctx* ctx, int model_id, int B, const void* const* wav16k, int wav_is_f64,
                           const int64_t* n, const rvcx_params* p, const float* const* noise,
                           const rvcx_utt_extra* extra, int16_t* const* out, float* const* out_f32, int64_t* out_n) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   return convert_impl(ctx, model_id, B, wav_is_f64 ? nullptr : reinterpret_cast<const float* const*>(wav16k),
                       wav_is_f64 ? reinterpret_cast<const double* const*>(wav16k) : nullptr, n, p, noise, out, out_f32,
                       out_n, extra);
 }
 
 int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || !p || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id] ||
       !ctx->c.hubert)
     return -1;
@@ -1336,6 +1413,7 @@ int rvcx_micro_batch(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* 
 }
 
 int64_t rvcx_bucket_length(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_params* p) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || !p || model_id < 0 || model_id >= (int)ctx->c.synths.size() || !ctx->c.synths[model_id]) return -1;
   try {
     return bucket_length(n, *p, make_geometry(*p, ctx->c.synths[model_id]->cfg.sr));
@@ -1346,6 +1424,7 @@ int64_t rvcx_bucket_length(rvcx_ctx* ctx, int model_id, int64_t n, const rvcx_pa
 }
 
 int rvcx_last_micro_batches(rvcx_ctx* ctx, int32_t* counts, int cap) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx) return -1;
   const auto& v = ctx->c.last_mbs;
   for (int i = 0; i < (int)v.size() && i < cap && counts; ++i) counts[i] = v[i];
@@ -1469,6 +1548,7 @@ int rvcx_resample_f64(rvcx_ctx* ctx, const double* x, int64_t frames, int channe
 }
 
 int rvcx_vc_frames(rvcx_ctx* ctx, int64_t n) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || !ctx->c.hubert) return -1;
   const int Th = hubert_frames(*ctx->c.hubert, n);
   if (Th <= 0) return -1;
@@ -1567,6 +1647,7 @@ int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops
 const char* rvcx_conv_profile_csv(rvcx_ctx*) { return conv_profile_csv(); }
 
 int rvcx_last_timing(rvcx_ctx* ctx, float* ms9) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx) return -1;
   for (int k = 0; k < 9; ++k) ms9[k] = ctx->c.timing[k];
   return 0;

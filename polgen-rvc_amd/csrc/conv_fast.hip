@@ -446,7 +446,8 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     if (slot >= 0) return slot;
   }
   if (a.groups != 1) return -1;
-  // joint (tile, split-K) choice from a small cost model fitted to tools/sweep_conv.py on MI355X:
+  // joint (tile, split-K) choice from a small cost model fitted on MI355X (round 2: tools/sweep_conv.py, since removed; refits and checks:
+  // tools/sweep_tiles_1d.py, tools/sweep_unet.py, tools/bench_conv.py -> profiles/sweep_tiles_1d_r04.txt):
   //   block time = 2 bm bn (K/S + ovh_t) / (577 GFLOP/s x eff_t x f(c)),  c = blocks S / 256 blocks per CU,
   // f(c) = MFMA utilisation of a CU with c co-resident blocks (0.45 alone .. 1.0 from four up), ovh_t = the
   // prologue + epilogue of a block in K-steps, the busiest CU runs ceil(c) blocks; split-K adds the finish

@@ -27,6 +27,7 @@ _dev_index = _state.dev_index
 _context = _state.context
 
 
+@_state.locked
 def clear_cache():
     """Drop every cached handle (voice models are unloaded once their callers released them too)."""
     _RESIDENT.clear()
@@ -41,8 +42,11 @@ class Config:
         self.device = device
         self.is_half = False
         self.n_cpu = cpu_count()
-        self.gpu_name = "AMD Instinct MI355X"
-        self.gpu_mem = 288
+        # infer.py:49-63 (_configure_gpu): name and GiB of the device, read from the HIP runtime; None without a GPU
+        # (the reference leaves both None on its CPU branch).  is_half stays False: rvcx computes in fp32.
+        name, total = _lib.device_info(_dev_index(device))
+        self.gpu_name = name
+        self.gpu_mem = None if total is None else int(total / 1024 / 1024 / 1024 + 0.4)
         self.x_pad, self.x_query, self.x_center, self.x_max = (1, 6, 38, 41)
 
 
@@ -67,10 +71,10 @@ def _torch_load(path):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
+@_state.locked_dev
 def load_hubert(device, is_half, model_path, state=None, cfg=None):
     """rvc/infer/infer.py:67-74.  ``model_path`` is a fairseq ``hubert_base.pt`` (its ``"model"``
     tensor dict is read with a restricted unpickler); alternatively pass the state dict directly."""
-    from .. import synthetic
     ctx = _context(device)
     slot, key = (_dev_index(device), "hubert"), None
     if state is None:
@@ -88,10 +92,10 @@ def load_hubert(device, is_half, model_path, state=None, cfg=None):
     return handle
 
 
+@_state.locked_dev
 def load_rmvpe(device, model_path=None, state=None, cfg=None):
     """RMVPE0Predictor.__init__ (rvc/lib/predictors/RMVPE.py:442-459); the reference loads it lazily
     inside VC.get_f0_rmvpe from rvc/models/predictors/rmvpe.pt (pipeline.py:123-126)."""
-    from .. import synthetic
     ctx = _context(device)
     slot, key = (_dev_index(device), "rmvpe"), None
     if state is None:
@@ -106,6 +110,7 @@ def load_rmvpe(device, model_path=None, state=None, cfg=None):
         _RESIDENT[slot] = (key, True)
 
 
+@_state.locked_dev
 def load_crepe(device, model_path=None, state=None):
     """torchcrepe.load.model (called inside torchcrepe.predict, rvc/infer/pipeline.py:96): the state dict of
     torchcrepe's model.Crepe -- its packaged ``assets/full.pth`` (or ``tiny.pth``), copied to ``model_path``, or given
@@ -127,6 +132,7 @@ def load_crepe(device, model_path=None, state=None):
         _RESIDENT[slot] = (key, True)
 
 
+@_state.locked_dev
 def load_fcpe(device, model_path=None, cpt=None):
     """FCPEF0Predictor.__init__ -> FCPEInfer.__init__ (rvc/lib/predictors/FCPE.py:806-826, 708-736): fcpe.pt is
     ``{"config": {...}, "model": state_dict}``; the reference builds it inside VC.get_f0 on every call from
@@ -152,6 +158,7 @@ def load_fcpe(device, model_path=None, cpt=None):
         _RESIDENT[slot] = (key, True)
 
 
+@_state.locked       # table lock only: validation must work without a GPU, and adding a model disturbs no request
 def get_vc(device, is_half, config, model_path, cpt=None):
     """rvc/infer/infer.py:78-105 -> (cpt, version, net_g, tgt_sr, vc).  A ``model_path`` seen before (same
     realpath, mtime and size) returns the voice model already resident in HBM; the returned ``cpt`` then
@@ -195,7 +202,9 @@ def load_audio(file, sample_rate, *, device=None):
         from .audio import read_audio
         audio, sr = read_audio(file)
         if sr != sample_rate:
-            audio = _context(device).resample(audio, sr, sample_rate)
+            ctx = _context(device)
+            with ctx.lock:
+                audio = ctx.resample(audio, sr, sample_rate)
         elif len(audio.shape) > 1:
             audio = np.asarray(audio, np.float64).mean(axis=1)        # librosa.to_mono(audio.T)
     except Exception as error:

@@ -18,6 +18,7 @@ Differences that are deliberate and documented:
 """
 from __future__ import annotations
 
+import functools
 import os
 import zlib
 
@@ -53,6 +54,18 @@ def _np(a, dtype=None):
         a = a.detach().cpu().numpy()
     a = np.asarray(a)
     return a if dtype is None else a.astype(dtype, copy=False)
+
+
+def _with_ctx_lock(method):
+    """Hold the context's lock for the whole method: a mirror call is a SEQUENCE of C calls (lazy predictor load, make the
+    index resident, convert) that must not interleave with another thread's sequence on the same context."""
+    @functools.wraps(method)
+    def wrapper(self, *a, **k):
+        net_g = k.get("net_g", a[1] if len(a) > 1 else None)
+        ctx = getattr(net_g, "ctx", None) or self._ctx()
+        with ctx.lock:
+            return method(self, *a, **k)
+    return wrapper
 
 
 class IndexHandle:
@@ -135,6 +148,7 @@ class VC:
         return self._ensure_fcpe(ctx) if f0_method == "fcpe" else self._ensure_rmvpe(ctx)
 
     # ------------------------------------------------------------------------------------
+    @_with_ctx_lock
     def get_f0_crepe(self, x, f0_min, f0_max, p_len, hop_length, model="full", *, dither=None):
         """pipeline.py:86-117: quantile normalisation, torchcrepe.predict (Viterbi decoder, batches of 2 * hop_length
         frames), resize to p_len -> f0 in Hz (float64, unshifted).  ``model`` names torchcrepe's capacity; the weights that
@@ -147,12 +161,14 @@ class VC:
             dither = _crepe_dither(ctx.crepe_frames(x.shape[0], p.hop_length))
         return ctx.get_f0_crepe_x(x, p_len, p, None, dither)[1].astype(np.float64)
 
+    @_with_ctx_lock
     def get_f0_rmvpe(self, x, f0_min=1, f0_max=40000, *args, **kwargs):
         """pipeline.py:119-130 -> f0 in Hz, 1 + len(x)//160 frames; out-of-range frames are 0 (rmvpe+)."""
         ctx = self._ensure_rmvpe()
         f0 = ctx.rmvpe_f0(_np(x, np.float32), 0.03, f0_min, f0_max)[0]
         return f0.astype(np.float64)
 
+    @_with_ctx_lock
     def get_f0(self, input_audio_path, x, p_len, pitch, f0_method, filter_radius, hop_length, inp_f0=None,
                f0_min=50, f0_max=1100, *, crepe_dither=None):
         """pipeline.py:132-201.  ``x`` is the reflect-padded, high-passed signal, as in the reference; returns
@@ -173,6 +189,7 @@ class VC:
             coarse, f0 = ctx.get_f0_x_ex(x, p_len, p, tab)
         return coarse.astype(np.int64), f0.astype(np.float64)
 
+    @_with_ctx_lock
     def vc(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect, *,
            z_noise=None, src_noise=None):
         """pipeline.py:203-287: one chunk of audio_pad -> np.float32 waveform (un-trimmed)."""
@@ -263,6 +280,7 @@ class VC:
                                    return_f32=return_f32, _single=True, hop_length=hop_length,
                                    crepe_dither=None if crepe_dither is None else [crepe_dither])
 
+    @_with_ctx_lock
     def pipeline_batch(self, model, net_g, sid, audios, pitch, f0_method, file_index, index_rate, pitch_guidance,
                        tgt_sr, resample_sr, volume_envelope, version, protect, f0_file=None, f0_min=50, f0_max=1100,
                        *, noise=None, return_f32=False, _single=False, hop_length=128, crepe_dither=None):

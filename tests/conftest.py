@@ -7,6 +7,10 @@ if ROOT not in sys.path:
 
 import pytest
 
+# the tuning / fault-injection hooks of librvcx.so (rvcx_conv_override, rvcx_debug_inject, rvcx_bench_*) are refused
+# unless the process starts with RVCX_DEBUG=1; the kernel-level tests use them.  Read once at first use by the library.
+os.environ.setdefault("RVCX_DEBUG", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

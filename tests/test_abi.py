@@ -46,3 +46,19 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_debug_hooks_are_refused_without_rvcx_debug():
+    """rvcx_conv_override / rvcx_debug_inject / rvcx_bench_* are process-wide tuning levers: a process that was not
+    started with RVCX_DEBUG=1 gets -2 from them (include/rvcx.h "DEBUG HOOKS"); with it they answer."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import polgen_rvc_amd; from polgen_rvc_amd import _lib; L = _lib.lib();"
+            "print(L.rvcx_conv_override(-1, -1, -1), L.rvcx_debug_inject(None, 1), L.rvcx_bench_gemm(None, 8, 16, 16, 1, None),"
+            " (L.rvcx_last_error(None) or b'').decode())" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "RVCX_DEBUG"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.startswith("-2 -2 -2 ") and "RVCX_DEBUG=1" in out, out
+    env["RVCX_DEBUG"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.startswith("0 -1 -1 "), out        # override accepted; the other two now fail on the null context instead

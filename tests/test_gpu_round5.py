@@ -1,0 +1,113 @@
+"""Round 5 (GPU): the shared context under threads, the fast-path counters."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_two_threads_share_one_context_through_the_mirror(tmp_path):
+    """The reference builds fresh model objects per request (rvc/scripts/voice_conversion.py:71-100), so two Gradio
+    worker threads never share state there.  Here every thread of the process gets the ONE resident context and ctypes
+    releases the GIL: every C entry point takes the context's mutex (csrc/api.hip) and the mirror holds the context's lock
+    around its call sequences.  Two threads x 4 requests on one context -- different clips, different index files (so
+    "make the index resident, then convert" must not interleave), one thread also asking for the F0 track -- give, bit for
+    bit, what each request gives alone; no error is left on the context."""
+    import faiss_writer as FW
+    from polgen_rvc_amd import _lib, synthetic as S
+    from polgen_rvc_amd.infer import infer as I, _state
+    hcfg, rcfg, scfg = S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY
+    seed = 3
+    saved = (dict(_state._CTX), dict(_state._RESIDENT), dict(_state._SYNTHS), dict(_state._INDEX_RESIDENT))
+    ctx = _lib.Context(0)
+    _state._CTX.clear()
+    _state._CTX[0] = ctx
+    try:
+        hub = I.load_hubert("cuda:0", False, None, state=S.hubert_state(hcfg, seed), cfg=hcfg)
+        I.load_rmvpe("cuda:0", state=S.rmvpe_state(rcfg, seed), cfg=rcfg)
+        cpt = S.synth_checkpoint(scfg, seed)
+        cpt["weight"] = S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])
+        cpt, version, net_g, tgt_sr, _ = I.get_vc("cuda:0", False, I.Config(), None, cpt=cpt)
+        idx = []
+        for k in range(2):
+            path = str(tmp_path / f"added_{k}.index")
+            open(path, "wb").write(FW.flat_bytes(S.make_index(512 + 64 * k, hcfg["embed_dim"], 40 + k)))
+            idx.append(path)
+        clips = [S.make_clip(60 + k, 1.5 + 0.4 * k).astype(np.float64) for k in range(2)]
+
+        def request(k):
+            vc = I.VC(tgt_sr, I.Config())          # a new VC per request, like get_vc gives every caller
+            vc.seed = 100 + k
+            pcm = vc.pipeline(hub, net_g, 0, clips[k], "x.wav", 0.0, "rmvpe+", idx[k], 0.6, 1, 3, tgt_sr, 0, 1.0, "v2",
+                              0.33, 128, None, 50, 1100)
+            f0 = vc.get_f0_rmvpe(clips[k].astype(np.float32)) if k == 1 else None
+            return pcm, f0
+
+        solo = [request(k) for k in range(2)]
+        assert not np.array_equal(solo[0][0][:1000], solo[1][0][:1000])
+        outs, errs = [[], []], []
+
+        def work(k):
+            try:
+                for _ in range(4):
+                    outs[k].append(request(k))
+            except Exception as e:  # noqa: BLE001 -- reported below
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for k in range(2):
+            assert len(outs[k]) == 4
+            for i, (pcm, f0) in enumerate(outs[k]):
+                assert np.array_equal(pcm, solo[k][0]), f"thread {k} request {i}: PCM differs from the solo run"
+                if f0 is not None:
+                    assert np.array_equal(f0, solo[k][1])
+        assert (_lib.lib().rvcx_last_error(ctx._h) or b"") == b""
+        assert ctx.gru_fallbacks() == 0
+    finally:
+        I.clear_cache()
+        for dst, src in zip((_state._CTX, _state._RESIDENT, _state._SYNTHS, _state._INDEX_RESIDENT), saved):
+            dst.clear()
+            dst.update(src)
+        del net_g
+        ctx.close()
+
+
+def test_raw_c_abi_calls_from_two_threads_queue_on_the_context_mutex():
+    """Below the mirror: two threads call rvcx_convert_batch on ONE context with no Python lock at all (ctypes drops the
+    GIL for the call).  Without the mutex in api_call the two calls would share the arena and the streams."""
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    hcfg, rcfg, scfg = S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY
+    c = _lib.Context(0)
+    try:
+        c.load_hubert(W.hubert_cfg_struct(hcfg), S.hubert_state(hcfg, 1))
+        c.load_rmvpe(W.rmvpe_cfg_struct(rcfg), S.rmvpe_state(rcfg, 1))
+        mid = c.load_synth(W.synth_cfg_struct(scfg, hcfg["embed_dim"]), S.synth_state(scfg, 1, input_dim=hcfg["embed_dim"]))
+        params = _lib.Params(0.0, 50.0, 1100.0, 0.0, 0.33, 1.0, 0, 1, 6, 38, 41, 9)
+        clips = [S.make_clip(70, 2.0), S.make_clip(71, 1.3)]
+        solo = [c.convert_batch(mid, [clips[k]], params)[0][0].copy() for k in range(2)]
+        outs, errs = [[], []], []
+
+        def work(k):
+            try:
+                for _ in range(6):
+                    outs[k].append(c.convert_batch(mid, [clips[k]], params)[0][0].copy())
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for k in range(2):
+            assert all(np.array_equal(o, solo[k]) for o in outs[k]) and len(outs[k]) == 6
+    finally:
+        c.close()

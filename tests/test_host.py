@@ -192,8 +192,10 @@ class _FakeCtx:
     """Counts loads/unloads so the residency cache can be tested without a GPU."""
 
     def __init__(self):
+        import threading
         self.loads = []
         self._h = None
+        self.lock = threading.RLock()      # what _lib.Context carries (the mirror holds it around its call sequences)
 
     def load_hubert(self, cfg, state):
         self.loads.append("hubert")

@@ -2,6 +2,7 @@
 """Micro-benchmark of the MFMA conv kernel on the layer shapes of the 30 s / 48 k workload."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 

@@ -3,6 +3,7 @@
 1599 per item) for every tile, B = 1 and B = 8.  usage: bench_gemm.py [iters=30]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 

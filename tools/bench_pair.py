@@ -5,6 +5,7 @@ state drifts over seconds: never compare numbers from different processes).
 usage: bench_pair.py [rounds=3] [only_fused=0] [shape indices, e.g. 2,5]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 

@@ -6,6 +6,7 @@ The round-3 failure lives in the round-3 kernel: run the -DRVCX_GRU_B128=1 build
 import hashlib, os, sys, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib, synthetic as S
 load = sys.argv[1] if len(sys.argv) > 1 else "gemm"

@@ -3,6 +3,7 @@
 import os, sys
 import numpy as np, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 ctx = _lib.Context(0)

@@ -3,6 +3,7 @@
 RVCX_CONV_TILE=100 (32 x 256), 101 (64 x 128), 102 (64 x 64), unset = the cost model's choice)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 ctx = _lib.Context(0)

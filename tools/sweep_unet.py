@@ -4,6 +4,7 @@ cost model picks against every forced (tile, split-K).  The 3x3 taps of a row-pa
 conv whose dilation gives the same halo (2 Wp + 2), which is all the staging depends on."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RVCX_DEBUG", "1")   # tuning hooks are refused without it
 import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 ctx = _lib.Context(0)
