@@ -202,6 +202,8 @@ def child_bench(extra_args, env_extra, label, roofline=True):
         out = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                "warmup": d["warmup"], "how": "child process of this bench run (started before the parent touched the GPU)"}
         out.update(label)
+        # did the child stay on the fast path?  (split-fp16 range guard / BiGRU cluster fallback counters of its context)
+        out["fast_path"] = {k: d["config"].get(k) for k in ("fp32_layers", "fp32_reruns", "gru_fallbacks")}
         if d.get("roofline"):
             out["roofline"] = d["roofline"]
         out["stage_ms"] = d.get("stage_ms")
@@ -482,6 +484,9 @@ def main():
                     "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "dominant_by": "algorithmic FLOPs",
+                    "definition": ("rounds 1-3: the profile slot with the most TIME; since round 4: the slot with the most "
+                                   "algorithmic FLOPs (a single-purpose kernel).  The time-dominant slot is reported as a "
+                                   "peer object, `roofline_by_time`, so that trends can follow either definition"),
                     "most_time": (None if by_time is dom else
                                   {"kernel": by_time["tile"], "launches": by_time["launches"], "ms": by_time["ms"],
                                    "achieved": by_time["flops"] / (by_time["ms"] * 1e-3) / 1e12,
@@ -523,12 +528,22 @@ def main():
                           "clips_per_step": len(clips), "micro_batch": ctx.micro_batch(mid, n, params),
                           "micro_batches": mbs_per_step, "index_exhaustive_queries": idx_exhaustive,
                           "out_samples": got[0] if len(got) == 1 else sum(got), "weights_bcast_bytes": nbytes,
-                          "weights_bcast_s": t_bcast, "load_s": t_load},
+                          "weights_bcast_s": t_bcast, "load_s": t_load,
+                          # fast-path evidence: layers the fp16-range guard pinned to the exact-fp32 kernels, calls it
+                          # repeated, calls that fell back to the single-workgroup BiGRU (all 0 = every launch of the
+                          # timed region ran on the kernels the roofline describes)
+                          "fp32_layers": ctx.fp32_layers(), "fp32_reruns": ctx.fp32_reruns(),
+                          "gru_fallbacks": ctx.gru_fallbacks()},
                "stage_ms": stage,
                "stage_ms_note": ("sums over the call's micro-batches of each stage's own span on its own stream; the "
                                  "streams overlap, so the stages do not add up to `total`" if multi else
                                  "single clip: rmvpe and hubert run side by side, the rest in sequence"),
-               "roofline": roofline, "conv_tiles": prof}
+               "roofline": roofline,
+               "roofline_by_time": (None if roofline is None else
+                                    ({"same_as": "roofline"} if roofline["most_time"] is None else
+                                     dict(roofline["most_time"], bound="mfma", peak=roofline["peak"], unit="TFLOP/s",
+                                          dominant_by="time in the serial profile step"))),
+               "conv_tiles": prof}
         if fp32 is not None:
             res["exact_fp32"] = fp32
         if c3_obj is not None:

@@ -386,6 +386,19 @@ int rvcx_op_bigru(rvcx_ctx*, const float* x, const float* w_ih, const float* w_h
 /* scipy.signal.filtfilt(bh, ah, x) of pipeline.py:19-22,329 (float64) */
 int rvcx_op_highpass(rvcx_ctx*, const double* x, double* y, int64_t n);
 
+/* ---- FLAC on the host (csrc/flac.hip; no GPU, no context) -------------------------------------------------------
+ * rvc/infer/infer.py:153 writes WAV bytes whatever the extension of output_path; the mirror writes a real FLAC stream when
+ * the path ends in ".flac"  and reads FLAC input where soundfile (rvc/lib/my_utils.py:9) is absent.
+ * Encoder: 16-bit PCM, interleaved, 1-8 channels, block size 4096, CONSTANT / VERBATIM / FIXED 0-4 + partitioned Rice,
+ * STREAMINFO with MD5.  Decoder: the whole format (LPC, wasted bits, Rice2 / escape partitions, stereo decorrelation,
+ * 4-32 bits), CRC-8 / CRC-16 / MD5 checked.  Errors: negative return, text via rvcx_flac_last_error (per thread). */
+int64_t rvcx_flac_encode_bound(int64_t frames, int channels);
+int64_t rvcx_flac_encode_s16(const int16_t* pcm, int64_t frames, int channels, int sample_rate, uint8_t* out, int64_t cap);
+int rvcx_flac_info(const uint8_t* data, int64_t n, int64_t* frames, int32_t* channels, int32_t* sample_rate, int32_t* bits);
+/* decoded samples, interleaved, right-justified at the stream's sample size; returns frames decoded */
+int64_t rvcx_flac_decode_s32(const uint8_t* data, int64_t n, int32_t* out, int64_t cap_samples);
+const char* rvcx_flac_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

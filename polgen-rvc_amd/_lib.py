@@ -85,6 +85,7 @@ SYMBOLS = [
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
     "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
     "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm", "rvcx_device_info",
+    "rvcx_flac_encode_bound", "rvcx_flac_encode_s16", "rvcx_flac_info", "rvcx_flac_decode_s32", "rvcx_flac_last_error",
 ]
 
 
@@ -109,6 +110,15 @@ def lib() -> C.CDLL:
         _lib.rvcx_noise_len.restype = C.c_int64
         _lib.rvcx_crepe_frames.restype = C.c_int64
         _lib.rvcx_index_exhaustive.restype = C.c_int64
+        _lib.rvcx_flac_encode_bound.restype = C.c_int64
+        _lib.rvcx_flac_encode_s16.restype = C.c_int64
+        _lib.rvcx_flac_decode_s32.restype = C.c_int64
+        _lib.rvcx_flac_last_error.restype = C.c_char_p
+        _lib.rvcx_flac_encode_bound.argtypes = [C.c_int64, C.c_int]
+        _lib.rvcx_flac_encode_s16.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        _lib.rvcx_flac_info.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        _lib.rvcx_flac_decode_s32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     return _lib
 
 
@@ -119,6 +129,37 @@ def device_info(device: int = 0):
     if lib().rvcx_device_info(int(device), name, 256, C.byref(total)) != 0:
         return None, None
     return name.value.decode(), int(total.value)
+
+
+def flac_encode(pcm, sample_rate: int) -> bytes:
+    """int16 PCM, (frames,) or (frames, channels) -> the bytes of a FLAC stream (host code, csrc/flac.hip)"""
+    a = np.ascontiguousarray(pcm)
+    if a.dtype != np.int16 or a.ndim not in (1, 2):
+        raise RvcxError("flac_encode: int16 array of shape (frames,) or (frames, channels) expected")
+    frames, ch = a.shape[0], (1 if a.ndim == 1 else a.shape[1])
+    cap = lib().rvcx_flac_encode_bound(frames, ch)
+    out = np.empty(max(int(cap), 64), np.uint8)
+    n = lib().rvcx_flac_encode_s16(a.ctypes.data, frames, ch, int(sample_rate), out.ctypes.data, out.shape[0])
+    if n < 0:
+        raise RvcxError((lib().rvcx_flac_last_error() or b"").decode())
+    return out[:n].tobytes()
+
+
+def flac_decode(data: bytes):
+    """bytes of a FLAC stream -> (int32 array (frames,) or (frames, channels), sample rate, bits per sample)"""
+    buf = np.frombuffer(data, np.uint8)
+    frames, ch, sr, bits = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    if lib().rvcx_flac_info(buf.ctypes.data, buf.shape[0], C.byref(frames), C.byref(ch), C.byref(sr), C.byref(bits)) != 0:
+        raise RvcxError((lib().rvcx_flac_last_error() or b"").decode())
+    total = int(frames.value)
+    if total == 0:          # unknown length in STREAMINFO (streamed files): an upper bound from the byte count
+        total = max(1, buf.shape[0]) * 8
+    out = np.empty((total, ch.value), np.int32)
+    n = lib().rvcx_flac_decode_s32(buf.ctypes.data, buf.shape[0], out.ctypes.data, out.size)
+    if n < 0:
+        raise RvcxError((lib().rvcx_flac_last_error() or b"").decode())
+    out = out[:n]
+    return (out[:, 0].copy() if ch.value == 1 else out.copy()), int(sr.value), int(bits.value)
 
 
 def f0_file_track(inp_f0) -> np.ndarray:

@@ -1,0 +1,706 @@
+// FLAC on the host (no device code): the lossless codec at the two file edges of the path.
+//
+//  * encoder  -- rvc_infer writes `sf.write(output_path, audio_opt, tgt_sr, format="WAV")` whatever the extension says
+//                (rvc/infer/infer.py:153): a ".flac" the reference hands out is a WAV in disguise.  The mirror keeps that for
+//                every extension EXCEPT ".flac", where it writes a real FLAC stream (rvcx_flac_encode_s16): 16-bit, fixed
+//                block size 4096, per channel the best of CONSTANT / VERBATIM / FIXED order 0-4 with partitioned Rice
+//                coding (exact bit counts decide), STREAMINFO with the MD5 of the PCM.  Lossless by construction.
+//  * decoder  -- load_audio reads files through soundfile (rvc/lib/my_utils.py:9); where that package is absent the
+//                mirror's reader decodes RIFF/WAVE itself and, with this file, FLAC too (rvcx_flac_decode_s32): every
+//                subframe type of the format (CONSTANT, VERBATIM, FIXED, LPC, wasted bits), Rice / Rice2 residuals with
+//                escape partitions, the three stereo decorrelation modes, 4-32 bits per sample, CRC-8 / CRC-16 / MD5 checked.
+//
+// Written from the published format description (xiph.org FLAC format / RFC 9639); libFLAC is not in this image, so the
+// codec is checked against an independent test-side reader / writer of the same format (tests/flac_codec.py) -- "parity
+// unpinned" against libFLAC's own output, like the other third-party edges (oracle/audio.py).
+#include "../../include/rvcx.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_flac_error;
+
+[[noreturn]] void flac_fail(const std::string& m) { throw std::runtime_error("flac: " + m); }
+
+// ---- MD5 (RFC 1321) --------------------------------------------------------------------------------------------
+struct Md5 {
+  uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+  uint64_t len = 0;
+  uint8_t buf[64];
+  size_t fill = 0;
+  static uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af,
+        0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa,
+        0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8,
+        0x676f02d9, 0x8d2a4c8a, 0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+        0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97,
+        0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1,
+        0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9,  14, 20, 5, 9,
+                              14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
+                              4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+    uint32_t w[16];
+    for (int i = 0; i < 16; ++i)
+      w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+    uint32_t A = a, B = b, C = c, D = d;
+    for (int i = 0; i < 64; ++i) {
+      uint32_t f;
+      int g;
+      if (i < 16) {
+        f = (B & C) | (~B & D);
+        g = i;
+      } else if (i < 32) {
+        f = (D & B) | (~D & C);
+        g = (5 * i + 1) & 15;
+      } else if (i < 48) {
+        f = B ^ C ^ D;
+        g = (3 * i + 5) & 15;
+      } else {
+        f = C ^ (B | ~D);
+        g = (7 * i) & 15;
+      }
+      const uint32_t t = D;
+      D = C;
+      C = B;
+      B = B + rol(A + f + K[i] + w[g], S[i]);
+      A = t;
+    }
+    a += A;
+    b += B;
+    c += C;
+    d += D;
+  }
+  void update(const uint8_t* p, size_t n) {
+    len += n;
+    while (n) {
+      const size_t k = std::min(n, (size_t)64 - fill);
+      memcpy(buf + fill, p, k);
+      fill += k;
+      p += k;
+      n -= k;
+      if (fill == 64) {
+        block(buf);
+        fill = 0;
+      }
+    }
+  }
+  void finish(uint8_t out[16]) {
+    const uint64_t bits = len * 8;
+    const uint8_t one = 0x80, zero = 0;
+    update(&one, 1);
+    while (fill != 56) update(&zero, 1);
+    uint8_t l[8];
+    for (int i = 0; i < 8; ++i) l[i] = (uint8_t)(bits >> (8 * i));
+    update(l, 8);
+    const uint32_t v[4] = {a, b, c, d};
+    for (int i = 0; i < 16; ++i) out[i] = (uint8_t)(v[i / 4] >> (8 * (i % 4)));
+  }
+};
+
+// ---- CRCs of the frame format -------------------------------------------------------------------------------------
+struct Crc {
+  uint8_t t8[256];
+  uint16_t t16[256];
+  Crc() {
+    for (int i = 0; i < 256; ++i) {
+      uint8_t c = (uint8_t)i;
+      for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1));           // x^8 + x^2 + x + 1
+      t8[i] = c;
+      uint16_t d = (uint16_t)(i << 8);
+      for (int k = 0; k < 8; ++k) d = (uint16_t)((d & 0x8000) ? (d << 1) ^ 0x8005 : (d << 1));      // x^16 + x^15 + x^2 + 1
+      t16[i] = d;
+    }
+  }
+  uint8_t crc8(const uint8_t* p, size_t n) const {
+    uint8_t c = 0;
+    for (size_t i = 0; i < n; ++i) c = t8[c ^ p[i]];
+    return c;
+  }
+  uint16_t crc16(const uint8_t* p, size_t n) const {
+    uint16_t c = 0;
+    for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ t16[(c >> 8) ^ p[i]]);
+    return c;
+  }
+};
+const Crc& crc() {
+  static const Crc c;
+  return c;
+}
+
+// ---- bit writer -----------------------------------------------------------------------------------------------------
+struct BitWriter {
+  std::vector<uint8_t>& out;
+  uint64_t acc = 0;
+  int nacc = 0;   // bits held in acc (< 8 after every put)
+  explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+  void put(uint32_t v, int bits) {   // bits <= 32, MSB first
+    if (bits == 0) return;
+    acc = (acc << bits) | (bits == 32 ? (uint64_t)v : ((uint64_t)v & ((1ull << bits) - 1)));
+    nacc += bits;
+    while (nacc >= 8) {
+      out.push_back((uint8_t)(acc >> (nacc - 8)));
+      nacc -= 8;
+    }
+  }
+  void put_signed(int32_t v, int bits) { put((uint32_t)v, bits); }
+  void put_unary(uint32_t q) {       // q zero bits, then a one
+    while (q >= 32) {
+      put(0, 32);
+      q -= 32;
+    }
+    put(1, (int)q + 1);
+  }
+  void align() {
+    if (nacc) put(0, 8 - nacc);
+  }
+};
+
+constexpr int kBlock = 4096;
+constexpr int kMaxRice = 14;        // 4-bit parameter field, 15 = escape
+constexpr int kMaxPorder = 8;
+
+inline uint32_t fold(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
+
+// residual of the fixed predictor of `order` over x[order .. n)
+void fixed_residual(const int32_t* x, int n, int order, int32_t* r) {
+  switch (order) {
+    case 0:
+      for (int i = 0; i < n; ++i) r[i] = x[i];
+      break;
+    case 1:
+      for (int i = 1; i < n; ++i) r[i] = x[i] - x[i - 1];
+      break;
+    case 2:
+      for (int i = 2; i < n; ++i) r[i] = x[i] - 2 * x[i - 1] + x[i - 2];
+      break;
+    case 3:
+      for (int i = 3; i < n; ++i) r[i] = x[i] - 3 * x[i - 1] + 3 * x[i - 2] - x[i - 3];
+      break;
+    default:
+      for (int i = 4; i < n; ++i) r[i] = x[i] - 4 * x[i - 1] + 6 * x[i - 2] - 4 * x[i - 3] + x[i - 4];
+      break;
+  }
+}
+
+struct RicePlan {
+  int porder = 0;
+  uint64_t bits = ~0ull;             // residual section incl. the 6 header bits
+  std::vector<int> k;                // parameter per partition
+};
+
+// best partition order + parameters for the folded residuals u[order .. n) (exact bit counts)
+RicePlan plan_rice(const uint32_t* u, int n, int order) {
+  // finest partition order this block admits: n divisible by 2^p and the first partition not shorter than the order
+  int pmax = 0;
+  while (pmax < kMaxPorder && (n % (2 << pmax)) == 0 && (n >> (pmax + 1)) > order) ++pmax;
+  const int parts = 1 << pmax;
+  // parameters worth counting: a window around log2(mean) of the block (a partition whose level is far from the
+  // block's still gets the best parameter of the window -- valid, merely not optimal)
+  uint64_t tot = 0;
+  for (int i = order; i < n; ++i) tot += u[i];
+  int kc = 0;
+  while (kc < kMaxRice && (tot >> (kc + 1)) >= (uint64_t)(n - order)) ++kc;
+  const int klo = std::max(0, kc - 3), khi = std::min(kMaxRice, kc + 3);
+  // sum over the partition of (u >> k), k = klo .. khi, at the finest order
+  std::vector<uint64_t> s((size_t)parts * (kMaxRice + 1), 0);
+  for (int p = 0; p < parts; ++p) {
+    const int lo = (p == 0) ? order : p * (n >> pmax), hi = (p + 1) * (n >> pmax);
+    uint64_t* sp = &s[(size_t)p * (kMaxRice + 1)];
+    for (int i = lo; i < hi; ++i) {
+      const uint32_t v = u[i];
+      for (int k = klo; k <= khi; ++k) sp[k] += v >> k;
+    }
+  }
+  RicePlan best;
+  std::vector<int> ks;
+  for (int po = pmax; po >= 0; --po) {
+    const int np = 1 << po, len = n >> po;
+    uint64_t total = 6;
+    ks.assign(np, 0);
+    for (int p = 0; p < np; ++p) {
+      const uint64_t cnt = (uint64_t)(len - (p == 0 ? order : 0));
+      const uint64_t* sp = &s[(size_t)p * (kMaxRice + 1)];
+      uint64_t bb = ~0ull;
+      int bk = 0;
+      for (int k = klo; k <= khi; ++k) {
+        const uint64_t b = cnt * (uint64_t)(k + 1) + sp[k];
+        if (b < bb) {
+          bb = b;
+          bk = k;
+        }
+      }
+      ks[p] = bk;
+      total += 4 + bb;
+    }
+    if (total < best.bits) {
+      best.bits = total;
+      best.porder = po;
+      best.k = ks;
+    }
+    // merge neighbouring partitions for the next coarser order
+    for (int p = 0; p < np / 2; ++p)
+      for (int k = klo; k <= khi; ++k)
+        s[(size_t)p * (kMaxRice + 1) + k] = s[(size_t)(2 * p) * (kMaxRice + 1) + k] + s[(size_t)(2 * p + 1) * (kMaxRice + 1) + k];
+  }
+  return best;
+}
+
+void encode_subframe(BitWriter& bw, const int32_t* x, int n, int bps) {
+  bool constant = true;
+  for (int i = 1; i < n && constant; ++i) constant = x[i] == x[0];
+  if (constant) {
+    bw.put(0, 8);                    // pad 0 | type 000000 | no wasted bits
+    bw.put_signed(x[0], bps);
+    return;
+  }
+  // order by the sum of |residual| (as libFLAC estimates), exact Rice plan for the winner
+  int best_order = 0;
+  std::vector<int32_t> r((size_t)n);
+  std::vector<uint32_t> u((size_t)n);
+  if (n > 4) {
+    uint64_t best_sum = ~0ull;
+    for (int o = 0; o <= 4; ++o) {
+      fixed_residual(x, n, o, r.data());
+      uint64_t sum = 0;
+      for (int i = 4; i < n; ++i) sum += (uint64_t)(r[i] < 0 ? -(int64_t)r[i] : (int64_t)r[i]);
+      if (sum < best_sum) {
+        best_sum = sum;
+        best_order = o;
+      }
+    }
+  }
+  const uint64_t verbatim_bits = (uint64_t)n * (uint64_t)bps;
+  RicePlan plan;
+  if (n > best_order) {
+    fixed_residual(x, n, best_order, r.data());
+    for (int i = best_order; i < n; ++i) u[i] = fold(r[i]);
+    plan = plan_rice(u.data(), n, best_order);
+  }
+  if (n <= best_order || plan.bits + (uint64_t)best_order * bps >= verbatim_bits) {
+    bw.put(0x02, 8);                 // pad 0 | type 000001 (VERBATIM) | no wasted bits
+    for (int i = 0; i < n; ++i) bw.put_signed(x[i], bps);
+    return;
+  }
+  bw.put((uint32_t)((0x08 | best_order) << 1), 8);     // pad 0 | type 001ooo (FIXED) | no wasted bits
+  for (int i = 0; i < best_order; ++i) bw.put_signed(x[i], bps);
+  bw.put(0, 2);                      // residual coding method 0: partitioned Rice, 4-bit parameters
+  bw.put((uint32_t)plan.porder, 4);
+  const int np = 1 << plan.porder, len = n >> plan.porder;
+  for (int p = 0; p < np; ++p) {
+    const int k = plan.k[p];
+    bw.put((uint32_t)k, 4);
+    const int lo = (p == 0) ? best_order : p * len, hi = (p + 1) * len;
+    for (int i = lo; i < hi; ++i) {
+      bw.put_unary(u[i] >> k);
+      bw.put(u[i], k);
+    }
+  }
+}
+
+void put_utf8(std::vector<uint8_t>& h, uint64_t v) {     // the frame number's "UTF-8" coding (up to 36 bits)
+  if (v < 0x80) {
+    h.push_back((uint8_t)v);
+    return;
+  }
+  const int extra = v < 0x800 ? 1 : v < 0x10000 ? 2 : v < 0x200000 ? 3 : v < 0x4000000 ? 4 : v < 0x80000000ull ? 5 : 6;
+  h.push_back((uint8_t)((0xFF << (7 - extra)) | (v >> (6 * extra))));     // extra + 1 leading ones, a zero, the top bits
+  for (int i = extra - 1; i >= 0; --i) h.push_back((uint8_t)(0x80 | ((v >> (6 * i)) & 0x3F)));
+}
+
+int64_t encode(const int16_t* pcm, int64_t frames, int channels, int sample_rate, std::vector<uint8_t>& out) {
+  if (frames < 0 || channels < 1 || channels > 8) flac_fail("1 .. 8 channels");
+  if (sample_rate < 1 || sample_rate > 655350) flac_fail("sample rate out of range");
+  const int bps = 16;
+  out.clear();
+  out.reserve((size_t)(frames * channels * 2 + 8192));
+  const char magic[4] = {'f', 'L', 'a', 'C'};
+  out.insert(out.end(), magic, magic + 4);
+  const size_t si = out.size();
+  out.resize(si + 4 + 34, 0);      // STREAMINFO, filled in at the end
+  uint32_t min_frame = 0xFFFFFF, max_frame = 0;
+  std::vector<int32_t> ch((size_t)kBlock);
+  std::vector<uint8_t> frame;
+  const int64_t nblocks = (frames + kBlock - 1) / kBlock;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int n = (int)std::min<int64_t>(kBlock, frames - b * kBlock);
+    frame.clear();
+    // header: sync 11111111 111110, reserved 0, fixed block size 0
+    frame.push_back(0xFF);
+    frame.push_back(0xF8);
+    const int bs_code = (n == kBlock) ? 0xC : 0x7;       // 1100: 256 * 2^4; 0111: 16-bit (size - 1) follows
+    frame.push_back((uint8_t)((bs_code << 4) | 0x0));    // sample rate: from STREAMINFO
+    frame.push_back((uint8_t)(((channels - 1) << 4) | (0x4 << 1)));   // independent channels | 100 = 16 bits | reserved 0
+    put_utf8(frame, (uint64_t)b);
+    if (bs_code == 0x7) {
+      frame.push_back((uint8_t)((n - 1) >> 8));
+      frame.push_back((uint8_t)(n - 1));
+    }
+    frame.push_back(crc().crc8(frame.data(), frame.size()));
+    BitWriter bw(frame);
+    for (int c = 0; c < channels; ++c) {
+      const int16_t* p = pcm + b * kBlock * channels + c;
+      for (int i = 0; i < n; ++i) ch[i] = p[(int64_t)i * channels];
+      encode_subframe(bw, ch.data(), n, bps);
+    }
+    bw.align();
+    const uint16_t c16 = crc().crc16(frame.data(), frame.size());
+    frame.push_back((uint8_t)(c16 >> 8));
+    frame.push_back((uint8_t)c16);
+    min_frame = std::min<uint32_t>(min_frame, (uint32_t)frame.size());
+    max_frame = std::max<uint32_t>(max_frame, (uint32_t)frame.size());
+    out.insert(out.end(), frame.begin(), frame.end());
+  }
+  if (nblocks == 0) min_frame = 0;
+  // STREAMINFO
+  uint8_t* s = &out[si];
+  s[0] = 0x80;                       // last metadata block | type 0
+  s[1] = 0;
+  s[2] = 0;
+  s[3] = 34;
+  s += 4;
+  s[0] = (uint8_t)(kBlock >> 8);
+  s[1] = (uint8_t)kBlock;
+  s[2] = (uint8_t)(kBlock >> 8);
+  s[3] = (uint8_t)kBlock;
+  s[4] = (uint8_t)(min_frame >> 16);
+  s[5] = (uint8_t)(min_frame >> 8);
+  s[6] = (uint8_t)min_frame;
+  s[7] = (uint8_t)(max_frame >> 16);
+  s[8] = (uint8_t)(max_frame >> 8);
+  s[9] = (uint8_t)max_frame;
+  // 20 bits rate | 3 bits channels - 1 | 5 bits bps - 1 | 36 bits total samples
+  const uint64_t packed = ((uint64_t)(sample_rate <= 0xFFFFF ? sample_rate : 0) << 44) | ((uint64_t)(channels - 1) << 41) |
+                          ((uint64_t)(bps - 1) << 36) | ((uint64_t)frames & 0xFFFFFFFFFull);
+  for (int i = 0; i < 8; ++i) s[10 + i] = (uint8_t)(packed >> (56 - 8 * i));
+  Md5 md5;
+  {
+    // little-endian interleaved 16-bit samples: the host is little-endian (x86-64), the buffer is the PCM itself
+    md5.update(reinterpret_cast<const uint8_t*>(pcm), (size_t)(frames * channels) * 2);
+    md5.finish(s + 18);
+  }
+  return (int64_t)out.size();
+}
+
+// ---- decoder ----------------------------------------------------------------------------------------------------
+struct BitReader {
+  const uint8_t* p;
+  size_t n, pos = 0;                 // pos in bits
+  BitReader(const uint8_t* d, size_t len) : p(d), n(len) {}
+  size_t byte_pos() const { return pos >> 3; }
+  bool aligned() const { return (pos & 7) == 0; }
+  uint32_t get(int bits) {           // <= 32
+    if (bits == 0) return 0;
+    if (pos + (size_t)bits > n * 8) flac_fail("truncated stream");
+    const size_t byte = pos >> 3;
+    const int off = (int)(pos & 7);
+    uint64_t w = 0;
+    if (byte + 8 <= n) {
+      memcpy(&w, p + byte, 8);
+      w = __builtin_bswap64(w);
+    } else {
+      for (size_t i = 0; i < 8; ++i) w = (w << 8) | (byte + i < n ? p[byte + i] : 0);
+    }
+    pos += (size_t)bits;
+    return (uint32_t)((w << off) >> (64 - bits));     // off + bits <= 39 bits of the 64 loaded
+  }
+  int32_t get_signed(int bits) {
+    if (bits == 0) return 0;
+    const uint32_t v = get(bits);
+    if (bits == 32) return (int32_t)v;
+    const uint32_t m = 1u << (bits - 1);
+    return (int32_t)((v ^ m) - m);
+  }
+  uint32_t get_unary() {             // zeros before the next one
+    uint32_t q = 0;
+    for (;;) {
+      if (pos >= n * 8) flac_fail("truncated stream");
+      const size_t byte = pos >> 3;
+      const int off = (int)(pos & 7);
+      const uint8_t rest = (uint8_t)(p[byte] << off);
+      if (rest) {
+        const int lz = __builtin_clz((uint32_t)rest) - 24;
+        q += (uint32_t)lz;
+        pos += (size_t)lz + 1;
+        return q;
+      }
+      q += (uint32_t)(8 - off);
+      pos += (size_t)(8 - off);
+    }
+  }
+};
+
+struct StreamInfo {
+  int min_block = 0, max_block = 0, sample_rate = 0, channels = 0, bps = 0;
+  int64_t total = 0;
+  uint8_t md5[16] = {0};
+  size_t audio_offset = 0;
+};
+
+StreamInfo parse_header(const uint8_t* d, size_t n) {
+  if (n < 4 + 4 + 34 || memcmp(d, "fLaC", 4) != 0) flac_fail("not a FLAC stream (no fLaC marker)");
+  StreamInfo si;
+  size_t o = 4;
+  bool first = true, last = false;
+  while (!last) {
+    if (o + 4 > n) flac_fail("truncated metadata");
+    last = (d[o] & 0x80) != 0;
+    const int type = d[o] & 0x7F;
+    const size_t len = ((size_t)d[o + 1] << 16) | ((size_t)d[o + 2] << 8) | d[o + 3];
+    o += 4;
+    if (o + len > n) flac_fail("truncated metadata block");
+    if (first) {
+      if (type != 0 || len != 34) flac_fail("first metadata block is not STREAMINFO");
+      const uint8_t* s = d + o;
+      si.min_block = (s[0] << 8) | s[1];
+      si.max_block = (s[2] << 8) | s[3];
+      uint64_t packed = 0;
+      for (int i = 0; i < 8; ++i) packed = (packed << 8) | s[10 + i];
+      si.sample_rate = (int)(packed >> 44);
+      si.channels = (int)((packed >> 41) & 7) + 1;
+      si.bps = (int)((packed >> 36) & 31) + 1;
+      si.total = (int64_t)(packed & 0xFFFFFFFFFull);
+      memcpy(si.md5, s + 18, 16);
+      first = false;
+    }
+    o += len;
+  }
+  si.audio_offset = o;
+  return si;
+}
+
+void decode_residual(BitReader& br, int n, int order, int32_t* r) {
+  const int method = (int)br.get(2);
+  if (method > 1) flac_fail("reserved residual coding method");
+  const int pbits = method == 0 ? 4 : 5, esc = method == 0 ? 15 : 31;
+  const int po = (int)br.get(4), np = 1 << po;
+  if ((n % np) != 0 || (n >> po) < order) flac_fail("invalid partition order");
+  int i = order;
+  for (int p = 0; p < np; ++p) {
+    const int cnt = (n >> po) - (p == 0 ? order : 0);
+    const int k = (int)br.get(pbits);
+    if (k == esc) {
+      const int raw = (int)br.get(5);
+      for (int j = 0; j < cnt; ++j) r[i++] = br.get_signed(raw);
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        const uint32_t q = br.get_unary();
+        const uint32_t u = (q << k) | br.get(k);
+        r[i++] = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+      }
+    }
+  }
+}
+
+void decode_subframe(BitReader& br, int n, int bps, int64_t* x, std::vector<int32_t>& r) {
+  if (br.get(1)) flac_fail("subframe padding bit set");
+  const int type = (int)br.get(6);
+  int wasted = 0;
+  if (br.get(1)) wasted = (int)br.get_unary() + 1;
+  if (wasted >= bps) flac_fail("wasted bits >= sample size");
+  bps -= wasted;
+  if (bps > 32) flac_fail("33-bit side channel of a 32-bit stream is not supported");
+  if (type == 0) {
+    const int64_t v = br.get_signed(bps);
+    for (int i = 0; i < n; ++i) x[i] = v;
+  } else if (type == 1) {
+    for (int i = 0; i < n; ++i) x[i] = br.get_signed(bps);
+  } else if (type >= 8 && type <= 12) {
+    const int order = type - 8;
+    if (order > n) flac_fail("fixed order beyond block size");
+    for (int i = 0; i < order; ++i) x[i] = br.get_signed(bps);
+    r.resize((size_t)n);
+    decode_residual(br, n, order, r.data());
+    switch (order) {
+      case 0:
+        for (int i = 0; i < n; ++i) x[i] = r[i];
+        break;
+      case 1:
+        for (int i = 1; i < n; ++i) x[i] = r[i] + x[i - 1];
+        break;
+      case 2:
+        for (int i = 2; i < n; ++i) x[i] = r[i] + 2 * x[i - 1] - x[i - 2];
+        break;
+      case 3:
+        for (int i = 3; i < n; ++i) x[i] = r[i] + 3 * x[i - 1] - 3 * x[i - 2] + x[i - 3];
+        break;
+      default:
+        for (int i = 4; i < n; ++i) x[i] = r[i] + 4 * x[i - 1] - 6 * x[i - 2] + 4 * x[i - 3] - x[i - 4];
+        break;
+    }
+  } else if (type >= 32) {
+    const int order = (type & 31) + 1;
+    if (order > n) flac_fail("LPC order beyond block size");
+    for (int i = 0; i < order; ++i) x[i] = br.get_signed(bps);
+    const int prec = (int)br.get(4) + 1;
+    if (prec == 16) flac_fail("invalid LPC precision");
+    const int shift = br.get_signed(5);
+    if (shift < 0) flac_fail("negative LPC shift");
+    int32_t coef[32];
+    for (int j = 0; j < order; ++j) coef[j] = br.get_signed(prec);
+    r.resize((size_t)n);
+    decode_residual(br, n, order, r.data());
+    for (int i = order; i < n; ++i) {
+      int64_t acc = 0;
+      for (int j = 0; j < order; ++j) acc += (int64_t)coef[j] * x[i - 1 - j];
+      x[i] = r[i] + (acc >> shift);
+    }
+  } else {
+    flac_fail("reserved subframe type");
+  }
+  if (wasted)
+    for (int i = 0; i < n; ++i) x[i] *= (int64_t)1 << wasted;
+}
+
+int64_t decode(const uint8_t* d, size_t n, int32_t* out, int64_t cap, StreamInfo* info_out) {
+  const StreamInfo si = parse_header(d, n);
+  if (info_out) *info_out = si;
+  if (!out) return si.total;
+  if (si.bps < 4 || si.bps > 32) flac_fail("unsupported sample size");
+  size_t o = si.audio_offset;
+  int64_t done = 0;
+  std::vector<int64_t> ch[8];
+  std::vector<int32_t> resid;
+  Md5 md5;
+  const int bytes_ps = (si.bps + 7) / 8;
+  std::vector<uint8_t> raw;
+  while (o + 2 <= n) {
+    if (d[o] != 0xFF || (d[o + 1] & 0xFE) != 0xF8) flac_fail("lost frame sync");
+    BitReader br(d + o, n - o);
+    br.get(15);
+    br.get(1);                       // blocking strategy: only affects what the coded number means
+    const int bs_code = (int)br.get(4), sr_code = (int)br.get(4), ch_code = (int)br.get(4), ss_code = (int)br.get(3);
+    if (br.get(1)) flac_fail("reserved header bit set");
+    {                                // coded frame / sample number: "UTF-8" with up to six continuation bytes
+      const uint32_t b0 = br.get(8);
+      if (b0 & 0x80) {
+        int ones = 0;
+        for (uint32_t m = 0x80; m && (b0 & m); m >>= 1) ++ones;
+        if (ones < 2 || ones > 7) flac_fail("bad coded number");
+        for (int i = 0; i < ones - 1; ++i)
+          if ((br.get(8) & 0xC0) != 0x80) flac_fail("bad coded number");
+      }
+    }
+    int bs;
+    if (bs_code == 0) flac_fail("reserved block size code");
+    else if (bs_code == 1) bs = 192;
+    else if (bs_code <= 5) bs = 576 << (bs_code - 2);
+    else if (bs_code == 6) bs = (int)br.get(8) + 1;
+    else if (bs_code == 7) bs = (int)br.get(16) + 1;
+    else bs = 256 << (bs_code - 8);
+    if (sr_code == 12) br.get(8);
+    else if (sr_code == 13 || sr_code == 14) br.get(16);
+    else if (sr_code == 15) flac_fail("invalid sample rate code");
+    const size_t hdr_bytes = br.byte_pos();
+    if (br.get(8) != crc().crc8(d + o, hdr_bytes)) flac_fail("frame header CRC-8 mismatch");
+    static const int ss_tab[8] = {0, 8, 12, -1, 16, 20, 24, 32};
+    const int bps = ss_code == 0 ? si.bps : ss_tab[ss_code];
+    if (bps < 0 || bps != si.bps) flac_fail("sample size changes mid-stream");
+    int nch;
+    if (ch_code < 8) nch = ch_code + 1;
+    else if (ch_code <= 10) nch = 2;
+    else flac_fail("reserved channel assignment");
+    if (nch != si.channels) flac_fail("channel count changes mid-stream");
+    for (int c = 0; c < nch; ++c) {
+      ch[c].resize((size_t)bs);
+      const bool side = (ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1);
+      decode_subframe(br, bs, bps + (side ? 1 : 0), ch[c].data(), resid);
+    }
+    if (!br.aligned()) br.get(8 - (int)(br.pos & 7));
+    const size_t body = br.byte_pos();
+    const uint16_t want = (uint16_t)br.get(16);
+    if (want != crc().crc16(d + o, body)) flac_fail("frame CRC-16 mismatch");
+    if (ch_code == 8)                // left / side
+      for (int i = 0; i < bs; ++i) ch[1][i] = ch[0][i] - ch[1][i];
+    else if (ch_code == 9)           // side / right
+      for (int i = 0; i < bs; ++i) ch[0][i] += ch[1][i];
+    else if (ch_code == 10)          // mid / side
+      for (int i = 0; i < bs; ++i) {
+        const int64_t side = ch[1][i], mid = ch[0][i] * 2 + (side & 1);
+        ch[0][i] = (mid + side) >> 1;
+        ch[1][i] = (mid - side) >> 1;
+      }
+    if ((done + bs) * nch > cap) flac_fail("output buffer too small");
+    raw.resize((size_t)bs * nch * bytes_ps);
+    size_t rp = 0;
+    for (int i = 0; i < bs; ++i)
+      for (int c = 0; c < nch; ++c) {
+        const int64_t v = ch[c][i];
+        out[(done + i) * nch + c] = (int32_t)v;
+        for (int k = 0; k < bytes_ps; ++k) raw[rp++] = (uint8_t)((uint64_t)v >> (8 * k));
+      }
+    md5.update(raw.data(), raw.size());
+    done += bs;
+    o += br.byte_pos();
+    if (si.total && done >= si.total) break;
+  }
+  if (si.total && done != si.total) flac_fail("stream holds fewer samples than STREAMINFO says");
+  bool have_md5 = false;
+  for (int i = 0; i < 16; ++i) have_md5 = have_md5 || si.md5[i] != 0;
+  if (have_md5) {
+    uint8_t got[16];
+    md5.finish(got);
+    if (memcmp(got, si.md5, 16) != 0) flac_fail("MD5 of the decoded audio does not match STREAMINFO");
+  }
+  return done;
+}
+
+template <typename F>
+int64_t guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    g_flac_error = e.what();
+    return -1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rvcx_flac_last_error(void) { return g_flac_error.c_str(); }
+
+int64_t rvcx_flac_encode_bound(int64_t frames, int channels) {
+  if (frames < 0 || channels < 1) return -1;
+  // VERBATIM is the worst case: 2 bytes per sample + per frame <= 16 header + 1 per channel + 2 CRC; plus fLaC + STREAMINFO
+  const int64_t blocks = (frames + kBlock - 1) / kBlock;
+  return 42 + frames * channels * 2 + blocks * (20 + channels);
+}
+
+int64_t rvcx_flac_encode_s16(const int16_t* pcm, int64_t frames, int channels, int sample_rate, uint8_t* out, int64_t cap) {
+  return guarded([&]() -> int64_t {
+    if ((!pcm && frames > 0) || !out) flac_fail("null buffer");
+    std::vector<uint8_t> buf;
+    const int64_t n = encode(pcm, frames, channels, sample_rate, buf);
+    if (n > cap) flac_fail("output buffer too small (size it with rvcx_flac_encode_bound)");
+    memcpy(out, buf.data(), (size_t)n);
+    return n;
+  });
+}
+
+int rvcx_flac_info(const uint8_t* data, int64_t n, int64_t* frames, int32_t* channels, int32_t* sample_rate, int32_t* bits) {
+  return (int)guarded([&]() -> int64_t {
+    if (!data) flac_fail("null buffer");
+    const StreamInfo si = parse_header(data, (size_t)n);
+    if (frames) *frames = si.total;
+    if (channels) *channels = si.channels;
+    if (sample_rate) *sample_rate = si.sample_rate;
+    if (bits) *bits = si.bps;
+    return 0;
+  });
+}
+
+int64_t rvcx_flac_decode_s32(const uint8_t* data, int64_t n, int32_t* out, int64_t cap_samples) {
+  return guarded([&]() -> int64_t {
+    if (!data || !out) flac_fail("null buffer");
+    return decode(data, (size_t)n, out, cap_samples, nullptr);
+  });
+}
+
+}  // extern "C"

@@ -3,8 +3,11 @@
 (rvc/scripts/voice_conversion.py:45-51).
 
 Decoding: when ``soundfile`` is importable (it is wherever the reference runs) it reads the file, so every container the
-reference accepts is accepted; otherwise RIFF/WAVE files (PCM 8/16/24/32, float 32/64) are read with scipy and anything
-else raises a clear error naming the missing decoder -- this image has neither soundfile nor ffmpeg.
+reference accepts is accepted; otherwise RIFF/WAVE files (PCM 8/16/24/32, float 32/64) are read with scipy, FLAC files
+with the library's own host-side decoder (csrc/flac.hip: the whole format, CRC / MD5 checked) and anything else (mp3,
+ogg, ...) raises a clear error naming the missing decoder -- this image has neither soundfile nor ffmpeg.
+Encoding: ``rvc_infer`` writes WAV bytes whatever the extension (infer.py:153) -- kept, except that a path ending in
+".flac" gets a real FLAC stream (``write_output``; 16-bit, lossless, csrc/flac.hip).
 Resampling runs on the GPU (``rvcx_resample_f64``, csrc/audio.hip): resampy's published "kaiser_best" filter;
 ``librosa.resample``'s current default (soxr_hq) is not published as a formula -- parity unpinned, see oracle/audio.py.
 """
@@ -26,6 +29,11 @@ def read_audio(path):
         return sf.read(path)
     with open(path, "rb") as f:
         head = f.read(12)
+    if head[:4] == b"fLaC":
+        from .. import _lib
+        with open(path, "rb") as f:
+            pcm, sr, bits = _lib.flac_decode(f.read())
+        return pcm.astype(np.float64) / float(1 << (bits - 1)), sr        # soundfile's float64 normalisation
     if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
         kind = next((v for k, v in _MAGIC.items() if head.startswith(k)), "unknown")
         raise ValueError(f"{path}: {kind} container -- this installation has no decoder for it (the 'soundfile' package "
@@ -55,6 +63,21 @@ def write_wav_pcm16(path, data, sr):
     a = np.asarray(data)
     if a.dtype.kind == "f":              # libsndfile: lrint(x * 0x7FFF), here with saturation
         a = np.clip(np.rint(a.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    wavfile.write(path, int(sr), a)
+
+
+def write_output(path, pcm, sr):
+    """What rvc_infer does with ``audio_opt`` (int16): ``sf.write(output_path, audio_opt, tgt_sr, format="WAV")``
+    (rvc/infer/infer.py:153) -- WAV bytes whatever the extension, so the UI's "mp3" / "flac" / "m4a" outputs are WAVs in
+    disguise.  SURVEY.md 8 f3: a path ending in ".flac" gets a real (lossless, 16-bit) FLAC stream instead; every other
+    extension keeps the reference's behaviour byte for byte."""
+    a = np.asarray(pcm)
+    if str(path).lower().endswith(".flac") and a.dtype == np.int16:
+        from .. import _lib
+        with open(path, "wb") as f:
+            f.write(_lib.flac_encode(a, int(sr)))
+        return
+    from scipy.io import wavfile
     wavfile.write(path, int(sr), a)
 
 

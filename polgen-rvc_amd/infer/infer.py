@@ -215,12 +215,13 @@ def load_audio(file, sample_rate, *, device=None):
 def rvc_infer(index_path, index_rate, input_path, output_path, pitch, f0_method, cpt, version, net_g,
               filter_radius, tgt_sr, volume_envelope, protect, hop_length, vc, hubert_model, f0_min=50,
               f0_max=1100):
-    """rvc/infer/infer.py:109-153: load -> vc.pipeline -> WAV (whatever the extension)."""
-    from scipy.io import wavfile
+    """rvc/infer/infer.py:109-153: load -> vc.pipeline -> WAV bytes whatever the extension -- except ".flac", which gets a
+    real FLAC stream (audio.write_output)."""
+    from .audio import write_output
     audio = load_audio(input_path, 16000)
     pitch_guidance = cpt.get("f0", 1)
     audio_opt = vc.pipeline(hubert_model, net_g, 0, audio, input_path, pitch, f0_method, index_path, index_rate,
                             pitch_guidance, filter_radius, tgt_sr, 0, volume_envelope, version, protect,
                             hop_length, f0_file=None, f0_min=f0_min, f0_max=f0_max)
     # infer.py:153: sf.write(output_path, audio_opt, tgt_sr, format="WAV") -- a WAV whatever the extension says
-    wavfile.write(output_path, tgt_sr, audio_opt)
+    write_output(output_path, audio_opt, tgt_sr)

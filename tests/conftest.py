@@ -25,6 +25,14 @@ def ctx():
     c.close()
 
 
+# Parity bars of the FULL-SIZE conversions (C1 / C2 / C3 / C5 against the reference's fixtures).  The north star allows
+# 1e-3 RMS on the float waveform; what is measured is 0.8e-5 .. 1.0e-5 (signal RMS 0.18) and 1-2 LSB on the strided PCM
+# samples, so the bars sit at 3x that: a 5x numerical regression fails (VERDICT r4 "tighten to what is measured").
+FULL_RMS_BAR = 3e-5
+FULL_PCM_BAR = 4
+TINY_RMS_BAR = 2e-5      # tiny-config goldens: measured 2e-6 .. 4e-6
+
+
 def rms(a):
     import numpy as np
     a = np.asarray(a, dtype=np.float64)

@@ -1,8 +1,9 @@
 """VC.pipeline on the GPU (rvcx_convert_batch through the rvc.infer mirror) against the goldens captured
 from the reference's own VC.pipeline (tools/gen_golden.py) and against the CPU oracle.
 
-Tolerances: float waveform <= 1e-3 RMS absolute (north-star) -- in practice asserted 10x tighter;
-int16 PCM <= 8 LSB max and < 2 % of samples off by more than 1 LSB (truncating astype on values that
+Tolerances: float waveform <= 1e-3 RMS absolute is the north star; asserted: 3e-5 at full size, 2e-5 on the tiny
+configs (conftest.FULL_RMS_BAR / TINY_RMS_BAR: 3x what is measured); int16 PCM <= 4 LSB max and < 2 % of samples off by
+more than 1 LSB (truncating astype on values that
 differ by 1e-5); f0 coarse identical on >= 99.9 % of frames; retrieval ids bit-exact."""
 import json
 import os
@@ -11,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rms
+from conftest import FULL_PCM_BAR, FULL_RMS_BAR, TINY_RMS_BAR, rms
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -86,7 +87,7 @@ def test_pipeline_vs_reference_golden(ctx, tag):
     assert pcm.shape == ref.shape, (pcm.shape, ref.shape)
     diff = np.abs(pcm.astype(np.int32) - ref.astype(np.int32))
     print(f"{tag}: pcm max diff {diff.max()} LSB, frac>1 {np.mean(diff > 1):.2e}")
-    assert diff.max() <= 8 and np.mean(diff > 1) < 0.02
+    assert diff.max() <= FULL_PCM_BAR and np.mean(diff > 1) < 0.02, f"{tag}: pcm max diff {diff.max()} LSB"
     if float(d["volume_envelope"]) == 1.0:
         # pre-quantisation float waveform: the reference's vc() outputs, trimmed and concatenated
         tp = int(tgt_sr) * int(d["geo"][0])
@@ -95,7 +96,7 @@ def test_pipeline_vs_reference_golden(ctx, tag):
         ref_f32 = np.concatenate([d["raw"][offs[i] + tp: offs[i + 1] - tp] for i in range(len(lens))])
         e = rms(f32 - ref_f32)
         print(f"{tag}: float rms err {e:.3e} (rms {rms(ref_f32):.3f})")
-        assert e < 1e-4                                          # north-star budget 1e-3
+        assert e < TINY_RMS_BAR, f"{tag}: float rms err {e:.3e} (north-star budget 1e-3)"
     # every 4096-sample block of the un-trimmed vc() output, through the pipeline's own trimmed float waveform
     _check_blocks(f32, d, tgt_sr) if float(d["volume_envelope"]) == 1.0 else None
     if diff.max() == 0:
@@ -114,7 +115,7 @@ def test_pipeline_vs_reference_golden(ctx, tag):
 
 
 def test_pipeline_float_waveform_vs_oracle(ctx):
-    """Pre-quantisation float waveform within 1e-4 RMS (budget 1e-3) of the CPU oracle, multi-chunk."""
+    """Pre-quantisation float waveform within 2e-5 RMS (measured 2e-6; budget 1e-3) of the CPU oracle, multi-chunk."""
     from oracle import pipeline as OP
     from polgen_rvc_amd import synthetic as S
     from polgen_rvc_amd.infer import infer as I
@@ -134,8 +135,8 @@ def test_pipeline_float_waveform_vs_oracle(ctx):
     assert len(parts["plan"]) >= 2
     e = rms(f32 - parts["audio_f32"])
     print(f"float waveform rms err {e:.3e} (rms {rms(parts['audio_f32']):.3f})")
-    assert e < 1e-4
-    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 8
+    assert e < TINY_RMS_BAR, e
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= FULL_PCM_BAR
 
 
 def test_unknown_f0_method_raises(ctx):
@@ -235,8 +236,9 @@ def test_full_size_pipeline_vs_reference_golden(ctx, tag):
     e = rms(f32[idx[keep] - t_pad_tgt] - raw_ref[keep])
     print(f"{tag}: float rms err {e:.3e} (rms {rms(raw_ref):.3f}); pcm max diff {diff.max()} LSB, "
           f"frac>1 {np.mean(diff > 1):.2e}; stage ms {ctx.last_timing()}")
-    assert e < 1e-4                                              # north-star budget: 1e-3
-    assert diff.max() <= 8 and np.mean(diff > 1) < 0.02
+    msg = f"{tag}: float rms err {e:.3e} (bar {FULL_RMS_BAR:g}; north star 1e-3), pcm max diff {diff.max()} LSB (bar {FULL_PCM_BAR})"
+    assert e < FULL_RMS_BAR, msg
+    assert diff.max() <= FULL_PCM_BAR and np.mean(diff > 1) < 0.02, msg
     # every sample is covered: RMS of each 4096-sample block of the reference's output vs ours
     nblk = _check_blocks(f32, d, tgt_sr)
     assert nblk >= (len(pcm) // 4096) - 1          # every block that lies inside the trimmed region
@@ -250,7 +252,7 @@ def test_full_size_pipeline_vs_reference_golden(ctx, tag):
 @pytest.mark.parametrize("seconds,clip", [(1.37, 71), (2.003, 72), (3.71, 73)])
 def test_odd_lengths_vs_oracle(ctx, seconds, clip):
     """Odd clip lengths (frame counts that are not multiples of any tile size, single- and multi-chunk) against the
-    CPU oracle: float waveform within 1e-4 RMS (budget 1e-3), PCM within 8 LSB."""
+    CPU oracle: float waveform within 2e-5 RMS (budget 1e-3), PCM within 4 LSB."""
     from oracle import pipeline as OP
     from polgen_rvc_amd import synthetic as S
     from polgen_rvc_amd.infer import infer as I
@@ -269,8 +271,8 @@ def test_odd_lengths_vs_oracle(ctx, seconds, clip):
                            128, None, 50, 1100, noise=noise, return_f32=True)
     assert pcm.shape == opcm.shape
     e = rms(f32 - parts["audio_f32"])
-    assert e < 1e-4, e
-    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 8
+    assert e < TINY_RMS_BAR, e
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= FULL_PCM_BAR
 
 
 def test_ivf_index_file_is_searched_like_faiss_nprobe_1(ctx, tmp_path):
