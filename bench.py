@@ -318,8 +318,9 @@ def dry_run(a, rank, world):
     if world > 1:
         torch.distributed.all_reduce(counts)
         torch.distributed.all_reduce(secs)
+    digests = D.gather_int64((1 << 63) + 7 * rank) if a.verify_ranks else None      # the --verify-ranks exchange, CPU side
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps or 1, "utterances_per_rank": counts.tolist(),
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_digests": digests, "steps": a.steps or 1, "utterances_per_rank": counts.tolist(),
                           "audio_seconds_per_rank": secs.tolist(), "value": float(secs.sum()) / dt, "workload": "c5"}))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -339,6 +340,8 @@ def main():
                     help="skip the exact_fp32 and c3 child benches of the default run")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default="")
+    ap.add_argument("--verify-ranks", action="store_true",
+                    help="every rank converts one probe clip after the weight broadcast; rank 0 reports whether all PCM digests agree")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing run (gloo): launcher, shard, timing")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1)
     a = ap.parse_args()
@@ -386,6 +389,15 @@ def main():
     params = make_params(fcpe=fcpe, crepe=crepe)
     if c3:
         params.index_rate = 0.75
+    ranks_agree = rank_digests = None
+    if a.verify_ranks:
+        # ranks != 0 loaded shape-only placeholders: the same PCM on every rank means rank 0's folded weights (and the
+        # index) arrived through the RCCL broadcast and were adopted.  Same clip, same Philox seed, outside the timed region.
+        import hashlib
+        probe = ctx.convert_batch(mid, [S.make_clip(9999, 2.0)], params)[0][0]
+        digest = int.from_bytes(hashlib.sha256(probe.tobytes()).digest()[:8], "little")
+        rank_digests = D.gather_int64(digest, dev)
+        ranks_agree = len(set(rank_digests)) == 1 and bool(np.any(probe != 0))
     # pinned host buffers: the step's H2D / D2H copies are asynchronous DMA inside the timed region
     if c5:
         lengths = c5_lengths()
@@ -529,6 +541,7 @@ def main():
                           "micro_batches": mbs_per_step, "index_exhaustive_queries": idx_exhaustive,
                           "out_samples": got[0] if len(got) == 1 else sum(got), "weights_bcast_bytes": nbytes,
                           "weights_bcast_s": t_bcast, "load_s": t_load,
+                          "ranks_agree": ranks_agree, "rank_pcm_digests": rank_digests,
                           # fast-path evidence: layers the fp16-range guard pinned to the exact-fp32 kernels, calls it
                           # repeated, calls that fell back to the single-workgroup BiGRU (all 0 = every launch of the
                           # timed region ran on the kernels the roofline describes)

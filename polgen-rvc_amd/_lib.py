@@ -788,11 +788,23 @@ class Context:
             if kd[i] >= 100000:
                 return f"conv_fast_sb<{bm[i]},{bn[i]},linear>"
             return f"conv_fast_sb<{bm[i]},{bn[i]},halo{kd[i] // 10}>"
+        self._tile_names = [name(i) for i in range(N)]
         return [dict(tile=name(i), launches=int(la[i]), flops=float(fl[i]), ms=float(ms[i]))
                 for i in range(N) if la[i] > 0]
 
     def conv_profile_csv(self) -> str:
-        return (lib().rvcx_conv_profile_csv(self._h) or b"").decode()
+        """per-launch table of the last profile; the tile column carries the kernel's name (conv_profile_end first)"""
+        txt = (lib().rvcx_conv_profile_csv(self._h) or b"").decode()
+        names = getattr(self, "_tile_names", None)
+        if not names:
+            return txt
+        out = []
+        for i, line in enumerate(txt.splitlines()):
+            head, _, rest = line.partition(",")
+            if i > 0 and head.isdigit() and int(head) < len(names):
+                head = '"' + names[int(head)].split(" (")[0] + '"'
+            out.append(head + "," + rest)
+        return "\n".join(out) + "\n"
 
     def last_timing(self):
         ms = (C.c_float * 9)()

@@ -111,6 +111,17 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_int64(value: int, device=None) -> List[int]:
+    """every rank's 64-bit value, on every rank (e.g. a digest of a probe conversion: did the broadcast weights arrive?)"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [int(value)]
+    v = int(value) & 0xFFFFFFFFFFFFFFFF
+    t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v], dtype=torch.int64, device=device if device is not None else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [int(o.item()) & 0xFFFFFFFFFFFFFFFF for o in out]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

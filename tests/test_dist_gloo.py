@@ -140,11 +140,12 @@ def test_bench_launches_its_own_ranks():
     on a GPU node), shard BASELINE configs[4]'s 256 utterances by length without overlap, and the parent relays
     exactly ONE JSON line -- rank 0's."""
     import json
-    r = _bench("--gpus", "2", "--dry-run", "--workload", "c5")
+    r = _bench("--gpus", "2", "--dry-run", "--workload", "c5", "--verify-ranks")
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True
+    assert d["rank_digests"] == [1 << 63, (1 << 63) + 7]              # --verify-ranks: every rank's 64-bit digest, unsigned
     assert d["utterances_per_rank"] == [128, 128]                       # +-0 items per rank
     a, b = d["audio_seconds_per_rank"]
     assert abs(a - b) / (a + b) < 0.02                                  # length-sorted round-robin balances audio
