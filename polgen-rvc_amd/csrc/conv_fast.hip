@@ -355,6 +355,69 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const ConvArgs a) {
     if (co0 + j < a.Cout_g) store_elem(a, b, co0 + j, nn, acc[j], len_out);
 }
 
+// Cout = 1 convolutions (NSF conv_post: 32 -> 1, k = 7 over 1.5 M positions per clip; rvc/lib/algorithm/nsf.py:142-144).
+// On a 32 x N MFMA tile 31 of 32 output rows are padding and the launch ran at 1 TB/s (198 us); the layer is a
+// Cin x k tap FIR bound by reading its input once: 196 MB at HBM speed.  A thread owns 4 consecutive outputs, per input
+// channel it loads the three aligned 16-byte words that cover its taps (neighbouring threads share two of them through
+// the vector L1), applies the pre-activation once per value and runs k x 4 FMAs; the weights are wave-uniform.
+// Exact fp32 (FMA chain, fixed order: channels ascending, taps ascending) -- nothing to split, no range guard needed.
+template <int K>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const ConvArgs a) {
+  constexpr int PADL = 4;                       // aligned words: positions t0 - 4 .. t0 + 7 cover taps t0 - pad .. t0 + 3 + K-1-pad
+  __shared__ float ws[64 * K];
+  const int b = blockIdx.z, Cin = a.Cin_g;
+  for (int idx = threadIdx.x; idx < Cin * K; idx += 256) {
+    const int ci = idx / K, kk = idx - ci * K;
+    ws[idx] = a.w[((long)kk * a.Cin_gp + ci) * a.Cout_gp];
+  }
+  __syncthreads();
+  const long t0 = (blockIdx.x * 256L + threadIdx.x) * 4;
+  if (t0 >= a.Nout) return;
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
+  const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
+  const float* xb = a.x + (long)b * a.x_bs;
+  const float slope = a.pre_act == ACT_LRELU ? a.pre_slope : 1.f;      // pre_act in {none, lrelu}
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool interior = t0 >= PADL && t0 + 8 <= len_in;
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xc = xb + (long)ci * a.x_cs;
+    float v[12];
+    if (interior) {
+      const float4 q0 = *reinterpret_cast<const float4*>(xc + t0 - 4);
+      const float4 q1 = *reinterpret_cast<const float4*>(xc + t0);
+      const float4 q2 = *reinterpret_cast<const float4*>(xc + t0 + 4);
+      v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+      v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+      v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const long pos = t0 - 4 + j;
+        v[j] = (pos >= 0 && pos < len_in) ? xc[pos] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j] = fmaxf(v[j], v[j] * slope);          // leaky_relu for 0 <= slope <= 1 (1: identity)
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      const float w = ws[ci * K + kk];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, v[PADL + q + kk - (K - 1) / 2], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (t0 + q < a.Nout) store_elem(a, b, 0, (int)(t0 + q), acc[q], len_out);
+}
+
+static bool conv_cout1_ok(const ConvArgs& a) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return a.Cout_g == 1 && a.groups == 1 && a.stride == 1 && a.dil == 1 && a.kw == a.ksize && a.ksize == 7 && a.pad == 3 &&
+         a.Cin_g >= 8 && a.Cin_g <= 64 && a.out_mode == OUT_NORMAL && !a.x_split && !a.y_split && a.acc2_mode == ACC2_NONE &&
+         (a.pre_act == ACT_NONE || (a.pre_act == ACT_LRELU && a.pre_slope >= 0.f && a.pre_slope <= 1.f)) && a.x_cs % 4 == 0 &&
+         a.x_bs % 4 == 0 && al(a.x) && a.Nout == a.Tin;
+}
+
 namespace {
 
 struct FastCfg {
@@ -410,6 +473,9 @@ void conv_fast_describe(ConvProfile* p) {
   p->bm[7] = 16;
   p->bn[7] = 256;
   p->halo[7] = 300000;   // slot 7: conv_cin1_kernel
+  p->bm[60] = 1;
+  p->bn[60] = 1024;
+  p->halo[60] = 300001;   // slot 60: conv_cout1_kernel
   for (int t = 0; t < kNumFast; ++t) {
     const int s = 8 + t;
     p->bm[s] = kFast[t].bm;
@@ -429,6 +495,14 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(conv_cin1_kernel, dim3(cdiv(a.Nout, 256), cdiv(a.Cout_g, 16), a.B), dim3(256), 0, stream, a);
     RVCX_HIP(hipGetLastError());
     return 7;
+  }
+  if (conv_cout1_ok(a)) {
+    static const bool on = !getenv("RVCX_COUT1") || atoi(getenv("RVCX_COUT1")) != 0;
+    if (on) {
+      hipLaunchKernelGGL(conv_cout1_kernel<7>, dim3((unsigned)cdiv64(cdiv64(a.Nout, 4), 256), 1, a.B), dim3(256), 0, stream, a);
+      RVCX_HIP(hipGetLastError());
+      return 60;
+    }
   }
   if ((a.stride != 1 && !(a.stride == 2 && a.kw == a.ksize)) || a.Cin_gp % 16 != 0) return -1;
   if (a.groups != 1 && !a.w_h3) return -1;      // grouped layers: only the split-fp16 tiles take them (blockIdx.z = group)

@@ -1150,11 +1150,426 @@ __global__ __launch_bounds__(64 * WR * WC) void resblock_pair_sp_kernel(const Pa
   stamp(5);
 }
 
+// ====================================================================================================================
+// Round 5: the PERSISTENT form of the fused step (RVCX_PAIR_VARIANT=10; the default where it is instantiated).
+//
+// Per-workgroup phase stamps of the kernel at the top of this file (tools/pair_trace.py, round 5) show how much of a
+// tile's life is NOT in the two k-loops:   C = 128, k = 11: 9.5 of 94 us    C = 64, k = 3: 10.8 of 18.9 us
+// C = 32, k = 3: 12.7 of 15.5 us -- launch + address set-up + the input tile's trip from HBM (2.2 - 5.7 us), the bias
+// loads inside the c1 epilogue, and the residual's round trip inside the final epilogue (4.5 - 6.6 us).  None of it is
+// work; all of it is latency that a workgroup with the CU to itself cannot hide.  Here a workgroup stays on its CU and
+// walks a CONTIGUOUS range of tiles (XCD x owns a contiguous eighth of the tiles, its workgroups contiguous parts of
+// that: neighbouring tiles share their halo in one L2, as before):
+//   * the input tile of tile t + 1 is requested when tile t's c1 loop ends, converted and committed to LDS in the last
+//     stage of tile t's c2 loop (the input staging area is idle in phase 2); its first weights are requested in that
+//     stage too: the prologue of every tile but the first is a weight commit, not a round trip to HBM;
+//   * the residual (the 16-byte-per-lane words of the wide epilogue) is requested in that same last stage and is there
+//     when the epilogue asks for it;
+//   * biases are read once per launch (into LDS; as registers they would cost 20 per lane and spill);
+//   * no launch, no dispatch, no resource set-up per tile.
+// The arithmetic is the first kernel's, instruction for instruction (same split, same k-order, same epilogues): the
+// results are bit-identical to it and to the two conv launches (tests: RVCX_PAIR_VARIANT 0 / 10 vs unfused).
+// EARLY: request tile t + 1's input and the first residual block as early as the staging registers allow (512-thread forms:
+// 256 registers per lane); false: at the c1 epilogue / in the last c2 stage (768-thread forms: 168 registers)
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool EARLY>
+__global__ __launch_bounds__(64 * WR * WC) void resblock_pair_persist_kernel(const PairArgs a) {
+  constexpr int THREADS = 64 * WR * WC;
+  constexpr int N1 = 32 * NT, N1P = N1 + kPairPadY, WROW = N1 + kPairHalo;
+  constexpr int WM = (C / 32) / WR, WN = NT / WC;
+  constexpr int NCHUNK = C / 16;
+  constexpr int NG = (K + KKT - 1) / KKT;
+  constexpr int SL = NCS * KKT;
+  constexpr int A_ELEMS = SL * 4 * C, NA = (A_ELEMS + THREADS - 1) / THREADS;
+  constexpr int B_TASKS = NCS * 2 * WROW, NBT = (B_TASKS + THREADS - 1) / THREADS;
+  constexpr int BN_OUT = (N1 - (K - 1)) & ~3, H2 = (K - 1) / 2;
+  static_assert(WM >= 1 && WN >= 1 && WM * WR * 32 == C && WN * WC == NT, "bad tile");
+  static_assert(NCS == 1 || KKT == K, "several chunks per stage only with all taps resident");
+  static_assert(NCHUNK % NCS == 0, "chunk sets must tile the channels");
+  extern __shared__ uint4 lds[];
+  constexpr int Y1_ELEMS = NCHUNK * 4 * N1P;
+  uint4* Y1 = lds;                              // [chunk][op][h][N1P]
+  uint4* As = Y1 + Y1_ELEMS;                    // [slot][op][h][C]
+  uint4* Bs = As + A_ELEMS;                     // [cl][op][h][WROW]
+  float* bias_s = reinterpret_cast<float*>(Bs + NCS * 4 * WROW);   // b1[C], b2[C]: read once per launch, 16-byte reads after
+
+  // per-thread coordinates: NOT const -- they are re-derived at the top of every tile from an opaque copy of the thread id,
+  // so that the hundred address terms built from them are recomputed per tile (a few dozen VALU instructions) instead of
+  // being hoisted out of the tile loop and kept in registers for the whole launch (first build: 256 VGPRs + 28-154 spilled)
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int wr = wave / WC, wc = wave % WC;
+  int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int pad1 = (K - 1) * a.dil / 2;
+  const int len = a.lens ? a.lens[b] : a.T;
+  const int wuse = N1 + (K - 1) * a.dil;
+  const float slope = a.slope;
+  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.bs, C * a.cs * 4);
+  const H3Rsrc w1r = h3_rsrc(a.w1, K * NCHUNK * 4 * C * 16);
+  const H3Rsrc w2r = h3_rsrc(a.w2, K * NCHUNK * 4 * C * 16);
+  const int xrow = a.cs * 4;
+  constexpr int slab = 4 * C * 16;
+
+  // ---- this workgroup's tiles: XCD (blockIdx.x & 7) owns a contiguous range, its workgroups contiguous parts of it
+  int first, count;
+  {
+    const int nt = (a.T + BN_OUT - 1) / BN_OUT, nwg = gridDim.x, w = blockIdx.x;
+    if (a.xcd_order && nwg >= 8) {
+      const int x = w & 7, j = w >> 3;
+      const int q = nt >> 3, r = nt & 7;
+      const int x0 = x * q + (x < r ? x : r), xn = q + (x < r ? 1 : 0);          // tiles of this XCD
+      const int m = (nwg >> 3) + (x < (nwg & 7) ? 1 : 0);                        // its workgroups
+      const int q2 = xn / m, r2 = xn % m;
+      first = x0 + j * q2 + (j < r2 ? j : r2);
+      count = q2 + (j < r2 ? 1 : 0);
+    } else {
+      const int q = nt / nwg, r = nt % nwg;
+      first = w * q + (w < r ? w : r);
+      count = q + (w < r ? 1 : 0);
+    }
+  }
+  if (count <= 0) return;
+  const int ntiles_all = (a.T + BN_OUT - 1) / BN_OUT;
+  int cur_tile = first;
+  auto stamp = [&](int k) {
+    if (a.trace && tid == 0) a.trace[((long)b * ntiles_all + cur_tile) * 8 + k] = (long long)wall_clock64();
+  };
+
+  f32x16 acc[WM][WN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  int a_cl[NA], a_kkl[NA], a_off[NA];
+  int b_off[NBT], b_row[NBT];
+  int lr = 0, lc = 0;
+  auto derive_thread = [&]() {
+    int t0 = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(t0));                   // opaque: nothing derived from it is loop-invariant to the compiler
+#endif
+    tid = t0;
+    lane = tid & 63;
+    wave = tid >> 6;
+    wr = wave / WC;
+    wc = wave % WC;
+    i = lane & 31;
+    h = lane >> 5;
+    lr = lane >> 3;
+    lc = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = tid + THREADS * j;
+      const int co = e % C, rest = e / C;
+      const int slot = rest / 4;
+      a_cl[j] = slot / KKT;
+      a_kkl[j] = slot % KKT;
+      a_off[j] = e < A_ELEMS ? ((rest % 4) * C + co) * 16 : kH3Oob;
+    }
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + THREADS * j;
+      const int ch2 = t / WROW;
+      b_row[j] = (ch2 >> 1) * 16 + (ch2 & 1) * 8;
+    }
+  };
+  derive_thread();
+  auto set_input_tile = [&](int tile) {           // where the input tasks of this thread read for `tile`
+    const int in_base = tile * BN_OUT - H2 - pad1;
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + THREADS * j;
+      const int ch2 = t / WROW, p = t - ch2 * WROW;
+      const int pos = in_base + p;
+      b_off[j] = (t < B_TASKS && p < wuse && pos >= 0 && pos < len) ? pos * 4 : kH3Oob;
+    }
+  };
+
+  uint4 ra[NA];
+  float rb[NBT][8];
+  bool ovf = false;
+  auto fetch_b = [&](int chunk0) {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int row0 = (chunk0 * 16 + b_row[j]) * xrow;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
+    }
+  };
+  auto fetch_a = [&](const H3Rsrc& wr_, int chunk0, int kk0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int kk = kk0 + a_kkl[j];
+      const bool ok = a_off[j] != kH3Oob && kk < K;
+      ra[j] = h3_load4(wr_, ok ? (kk * NCHUNK + chunk0 + a_cl[j]) * slab + a_off[j] : kH3Oob);
+    }
+  };
+  auto commit_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (NA * THREADS == A_ELEMS || tid + THREADS * j < A_ELEMS) As[tid + THREADS * j] = ra[j];
+  };
+  auto commit_b = [&]() {
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + THREADS * j;
+      if (NBT * THREADS == B_TASKS || t < B_TASKS) {
+        half8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v = rb[j][q];
+          v = v > 0.f ? v : v * slope;                 // leaky_relu ahead of c1
+          ovf |= !(fabsf(v) < kH3ActLimit);
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        const int ch2 = t / WROW, p = t - ch2 * WROW;
+        const int cl = ch2 >> 1, hh = ch2 & 1;
+        Bs[((cl * 2 + 0) * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, hi);
+        Bs[((cl * 2 + 1) * 2 + hh) * WROW + p] = __builtin_bit_cast(uint4, lo);
+      }
+    }
+  };
+  auto compute = [&](auto taps_tag, const uint4* Bt, int pitch, int cl_pitch, int kk0, int tap_step) {
+    constexpr int TAPS = decltype(taps_tag)::value;
+    constexpr int NS = NCS * TAPS;
+    half8 af[2][2][WM], bf[2][2][WN];
+    auto load = [&](int buf, int s) {
+      const int cl = s / TAPS, kkl = s % TAPS;
+      const int tp = (kk0 + kkl) * tap_step;
+      const uint4* Bc = Bt + cl * cl_pitch;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        af[buf][0][m] = __builtin_bit_cast(half8, As[(((cl * KKT + kkl) * 2 + 0) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+        af[buf][1][m] = __builtin_bit_cast(half8, As[(((cl * KKT + kkl) * 2 + 1) * 2 + h) * C + wr * (WM * 32) + m * 32 + i]);
+      }
+#pragma unroll
+      for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          bf[buf][op][n] = __builtin_bit_cast(half8, Bc[(op * 2 + h) * pitch + wc * (WN * 32) + n * 32 + i + tp]);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < NS) load(cur ^ 1, s + 1);
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        const half8 wh = af[cur][0][m] * (_Float16)(1.f / kH3Scale);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          acc[m][n] = h3_mfma(af[cur][0][m], bf[cur][0][n], acc[m][n]);   // (S wh) xh
+          acc[m][n] = h3_mfma(wh, bf[cur][1][n], acc[m][n]);              // wh (S xl)
+          acc[m][n] = h3_mfma(af[cur][1][m], bf[cur][0][n], acc[m][n]);   // (S wl) xh
+        }
+      }
+    }
+    if (kPipe) {
+      constexpr int R = 2 * WM + 2 * WN, M = 3 * WM * WN;
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (s + 1 < NS && j < R) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (s + 1 < NS && R > M) __builtin_amdgcn_sched_group_barrier(0x100, R - M, 0);
+      }
+    }
+  };
+  using Full = std::integral_constant<int, KKT>;
+  using Last = std::integral_constant<int, K - (NG - 1) * KKT>;
+  constexpr float inv = 1.f / kH3Scale;
+
+  // biases, once per launch, into LDS (as registers they cost 20 per lane for the whole launch: spills)
+  for (int c = tid; c < C; c += THREADS) {
+    bias_s[c] = a.b1 ? a.b1[c] : 0.f;
+    bias_s[C + c] = a.b2 ? a.b2[c] : 0.f;
+  }
+
+  // ---- first tile: its input chunk set 0 into Bs, its first weights into registers.  Loop invariant from here on:
+  // at the top of a tile Bs holds the tile's chunk set 0 (converted), ra its first weight stage.
+  set_input_tile(first);
+  fetch_b(0);
+  fetch_a(w1r, 0, 0);
+  commit_b();
+
+  for (int ti = 0; ti < count; ++ti) {
+    const int tile = first + ti;
+    cur_tile = tile;
+    const int n0 = tile * BN_OUT;
+    const bool has_next = ti + 1 < count;
+    if (ti > 0) derive_thread();
+    stamp(0);
+    // ================================================================ phase 1: Y1 = lrelu(c1(lrelu(x)) + b1)
+    zero_acc();
+    for (int chunk = 0; chunk < NCHUNK; chunk += NCS) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const bool last_stage = chunk + NCS >= NCHUNK && g == NG - 1;
+        __syncthreads();
+        if (g == 0 && chunk > 0) commit_b();           // chunk set 0 was committed by the previous tile (or the preamble)
+        commit_a();
+        __syncthreads();
+        if (chunk == 0 && g == 0) stamp(1);
+        if (!last_stage) fetch_a(w1r, g + 1 == NG ? chunk + NCS : chunk, g + 1 == NG ? 0 : (g + 1) * KKT);
+        else fetch_a(w2r, 0, 0);                       // first weights of c2 fly during the c1 epilogue
+        if (g == 0 && chunk + NCS < NCHUNK) {
+          fetch_b(chunk + NCS);
+        } else if (EARLY && g == 0 && has_next) {
+          // the tile's last input commit is behind us: the staging registers are free, tile t + 1's input leaves HBM now
+          // (a loaded round trip is ~5 us; requested at the c1 epilogue it arrived 2-4 us late for the small shapes)
+          set_input_tile(tile + 1);
+          fetch_b(0);
+        }
+        if (NG > 1 && g == NG - 1) compute(Last{}, Bs, WROW, 4 * WROW, g * KKT, a.dil);
+        else compute(Full{}, Bs, WROW, 4 * WROW, g * KKT, a.dil);
+      }
+    }
+    stamp(2);
+    if (!EARLY && has_next) {
+      set_input_tile(tile + 1);
+      fetch_b(0);
+    }
+    // c1 epilogue: bias, leaky_relu (the one ahead of c2), zero outside the sequence, split, into LDS
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int c_t = wr * (WM * 32) + m * 32;
+        const int j = wc * (WN * 32) + n * 32 + i;
+        const int pos1 = n0 - H2 + j;
+        const bool live = pos1 >= 0 && pos1 < len;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+          const int cg = c_t + 8 * g;
+          half4 hi, lo;
+          const float4 bq = *reinterpret_cast<const float4*>(bias_s + cg + 4 * h);
+          const float b4[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[m][n][4 * g + q] * inv + b4[q];
+            v = fmaxf(v, v * slope);
+            v = live ? v : 0.f;
+            ovf |= !(fabsf(v) < kH3ActLimit);
+            const _Float16 vh = (_Float16)v;
+            hi[q] = vh;
+            lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+          }
+          char* e_hi = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 0) * 2 + (g & 1)) * N1P + j) + 8 * h;
+          char* e_lo = reinterpret_cast<char*>(Y1 + (((cg >> 4) * 2 + 1) * 2 + (g & 1)) * N1P + j) + 8 * h;
+          *reinterpret_cast<half4*>(e_hi) = hi;
+          *reinterpret_cast<half4*>(e_lo) = lo;
+        }
+      }
+
+    // ================================================================ phase 2: y = c2(Y1) + b2 + x
+    zero_acc();
+    stamp(3);
+    // The residual words of the wide epilogue.  Column block n = 0 is requested EARLY (all taps resident: at the start of
+    // phase 2; otherwise with the first tap group of the last chunk set), blocks n >= 1 when the epilogue starts -- they
+    // land while block 0 is transposed and stored.  Half the registers of requesting everything early.
+    uint4 rv[WM][WN][4];
+    auto request_res = [&](int n) {
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        const int col0 = wc * (WN * 32) + n * 32 + lc;
+        const int pos0 = n0 + col0;
+        const bool ok = col0 < BN_OUT && pos0 < a.T;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+          rv[m][n][p] = h3_load4(xr, ok ? (co * a.cs + pos0) * 4 : kH3Oob);
+        }
+      }
+    };
+    if (EARLY && NG == 1) request_res(0);
+    for (int chunk = 0; chunk < NCHUNK; chunk += NCS) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const bool last_stage = chunk + NCS >= NCHUNK && g == NG - 1;
+        __syncthreads();
+        commit_a();
+        if (last_stage && has_next) commit_b();        // Bs is idle in phase 2: tile t + 1's chunk set 0 is ready before its tile starts
+        __syncthreads();
+        if (!last_stage) fetch_a(w2r, g + 1 == NG ? chunk + NCS : chunk, g + 1 == NG ? 0 : (g + 1) * KKT);
+        else if (has_next) fetch_a(w1r, 0, 0);       // tile t + 1's first weights
+        if (EARLY ? (NG > 1 && g == 0 && chunk + NCS >= NCHUNK) : last_stage) request_res(0);
+        if (NG > 1 && g == NG - 1) compute(Last{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
+        else compute(Full{}, Y1 + chunk * 4 * N1P, N1P, 4 * N1P, g * KKT, 1);
+      }
+    }
+    stamp(4);
+    {
+      constexpr int P = 36;                              // floats per staged row: 16-byte aligned, rows 4 banks apart
+      static_assert(THREADS / 64 * 32 * P * 4 <= NCHUNK * 4 * N1P * 16, "staging tiles must fit the Y1 region");
+      __syncthreads();                                   // every wave is done reading Y1: the staging tiles overlay it
+      float* stg = reinterpret_cast<float*>(lds) + wave * (32 * P);
+#pragma unroll
+      for (int n = 1; n < WN; ++n) request_res(n);
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * P + i] = acc[m][n][r] * inv;
+          __builtin_amdgcn_wave_barrier();
+          const int col0 = wc * (WN * 32) + n * 32 + lc;
+          const int pos0 = n0 + col0;
+          const bool ok = col0 < BN_OUT && pos0 < a.T;
+          float4 v[4], pv[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+            const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+            v[p] = *reinterpret_cast<const float4*>(stg + (lr + 8 * p) * P + lc);
+            pv[p] = (ok && a.acc2_mode != ACC2_NONE && a.acc2_mode != ACC2_SET) ? *reinterpret_cast<const float4*>(a.y2 + off)
+                                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (ok) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const int co = wr * (WM * 32) + m * 32 + lr + 8 * p;
+              const long off = (long)b * a.bs + (long)co * a.cs + pos0;
+              const float bb = bias_s[C + co];
+              const float4 rr = __builtin_bit_cast(float4, rv[m][n][p]);
+              float o[4] = {v[p].x + bb + rr.x, v[p].y + bb + rr.y, v[p].z + bb + rr.z, v[p].w + bb + rr.w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = pos0 + q < len ? o[q] : 0.f;
+              if (a.y) *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+              if (a.acc2_mode != ACC2_NONE) {
+                const float pp[4] = {pv[p].x, pv[p].y, pv[p].z, pv[p].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if (a.acc2_mode == ACC2_ADD) o[q] = pp[q] + o[q];
+                  else if (a.acc2_mode == ACC2_ADD_DIV) o[q] = (pp[q] + o[q]) / a.acc2_div;
+                }
+                *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o[0], o[1], o[2], o[3]);
+              }
+            }
+          }
+        }
+    }
+    stamp(5);
+  }
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
+}
+
 struct PairCfg {
   int C, K, n1, threads, variant, bn_out;
   bool wide;                     // wide epilogue: rows must be 16-byte aligned
   size_t lds;
   void (*kern)(const PairArgs);
+  bool persist = false;          // one workgroup per CU walks a range of tiles (grid = CUs, not tiles)
 };
 template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false, int RESPF = 0, bool OVL = false>
 constexpr PairCfg make_cfg() {
@@ -1163,6 +1578,13 @@ constexpr PairCfg make_cfg() {
   return {C, K, 32 * NT, 64 * WR * WC, V, RESPF == 3 ? ((32 * NT - (K - 1)) & ~3) : 32 * NT - (K - 1), RESPF == 3,
           (OVL ? (y1 > bs ? y1 : bs) + as : y1 + as + bs) * 16,
           resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM, RESPF, OVL>};
+}
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool EARLY = true, int V = 10>
+constexpr PairCfg make_persist() {
+  constexpr size_t y1 = (size_t)(C / 16) * 4 * (32 * NT + kPairPadY), as = (size_t)NCS * KKT * 4 * C,
+                   bs = (size_t)NCS * 4 * (32 * NT + kPairHalo);
+  return {C, K, 32 * NT, 64 * WR * WC, V, (32 * NT - (K - 1)) & ~3, true, (y1 + as + bs) * 16 + 2 * C * 4,
+          resblock_pair_persist_kernel<C, NT, WR, WC, K, KKT, NCS, EARLY>, true};
 }
 template <int C, int NT, int WR, int WC, int K, int G, int V, bool OVL = false>
 constexpr PairCfg make_adir() {
@@ -1217,6 +1639,25 @@ const PairCfg kPair[] = {
     make_sp<32, 16, 1, 8, 3, 3, 8>(),  make_sp<32, 16, 1, 8, 7, 4, 8>(),  make_sp<32, 16, 1, 8, 11, 4, 8>(),
     make_sp<64, 8, 2, 4, 3, 3, 8>(),   make_sp<64, 8, 2, 4, 7, 4, 8>(),   make_sp<64, 8, 2, 4, 11, 4, 8>(),
     make_sp<128, 6, 4, 3, 3, 3, 8>(),  make_sp<128, 6, 4, 3, 7, 3, 8>(),  make_sp<128, 6, 4, 3, 11, 3, 8>(),
+    // variant 9 (round 5): variant 2's small tiles (TWO workgroups per CU: one in its k-loops while the other is in its
+    // prologue / epilogue) with the wide epilogue -- for the small C x k shapes, whose tile life is half prologue + epilogue
+    make_cfg<32, 8, 1, 4, 3, 3, 2, 9, true, 3>(),   make_cfg<32, 8, 1, 4, 7, 7, 1, 9, true, 3>(),   make_cfg<32, 8, 1, 4, 11, 11, 1, 9, true, 3>(),
+    make_cfg<64, 4, 2, 2, 3, 3, 2, 9, true, 3>(),   make_cfg<64, 4, 2, 2, 7, 7, 1, 9, true, 3>(),   make_cfg<64, 4, 2, 2, 11, 4, 1, 9, true, 3>(),
+    make_cfg<128, 3, 2, 3, 3, 2, 1, 9, true, 3>(),  make_cfg<128, 3, 2, 3, 7, 2, 1, 9, true, 3>(),  make_cfg<128, 3, 2, 3, 11, 2, 1, 9, true, 3>(),
+    // variant 10 (round 5): PERSISTENT workgroups on variant 4's tiles -- the default for these shapes (RVCX_PAIR_PERSIST=0: variant 4).
+    // Measured per shape against variant 4 (tools/bench_pair.py, same box; profiles/pair_persist_r05.txt): k = 3 -11 ... -15 %,
+    // C = 32 -8 ... -12 %, C = 64 / 128 at k = 7 -4 ... -6 %, C = 64 k = 11 -3 %.  C = 128, k = 11 is NOT here: on 768 threads (168
+    // registers) the form spills inside its k-loops and loses 3 %; on 512 threads (variant 12) it loses 10 %.
+    // EARLY = true (input of tile t + 1 requested during the last chunk set of c1) is slower on every multi-stage shape: vector
+    // memory loads return IN ORDER, so the weight fetch of the next stage waits behind the ~5 us HBM round trip of the input tile.
+    make_persist<32, 16, 1, 8, 3, 3, 2, false>(),  make_persist<32, 16, 1, 8, 7, 7, 1, false>(),  make_persist<32, 16, 1, 8, 11, 11, 1, false>(),
+    make_persist<64, 8, 2, 4, 3, 3, 2, false>(),   make_persist<64, 8, 2, 4, 7, 7, 1, false>(),   make_persist<64, 8, 2, 4, 11, 11, 1, false>(),
+    make_persist<128, 6, 4, 3, 3, 3, 1, false>(),  make_persist<128, 4, 4, 2, 7, 7, 1, false>(),
+    // A/B forms: 11 = EARLY requests; C = 128, k = 11 on 768 threads.  12 = C = 128, k = 11 / k = 3 on 512 threads, N1 = 128
+    make_persist<32, 16, 1, 8, 3, 3, 2, true, 11>(),  make_persist<32, 16, 1, 8, 7, 7, 1, true, 11>(),  make_persist<32, 16, 1, 8, 11, 11, 1, true, 11>(),
+    make_persist<64, 8, 2, 4, 3, 3, 2, true, 11>(),   make_persist<64, 8, 2, 4, 7, 7, 1, true, 11>(),   make_persist<64, 8, 2, 4, 11, 11, 1, true, 11>(),
+    make_persist<128, 6, 4, 3, 11, 4, 1, false, 11>(),  make_persist<128, 4, 4, 2, 7, 7, 1, true, 11>(),
+    make_persist<128, 4, 4, 2, 11, 4, 1, false, 12>(),  make_persist<128, 4, 4, 2, 3, 3, 1, false, 12>(),
     // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
     make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
     make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),
@@ -1234,6 +1675,10 @@ const PairCfg* find_cfg(const PairArgs& a) {
   static const int variant = getenv("RVCX_PAIR_VARIANT") ? atoi(getenv("RVCX_PAIR_VARIANT")) : 0;
   static const bool c256 = !getenv("RVCX_PAIR_C256") || atoi(getenv("RVCX_PAIR_C256")) != 0;
   if (C == 256 && (!c256 || K != 3)) return nullptr;     // k = 7 / 11 at C = 256: the two launches are faster (bench_pair)
+  static const bool persist = !getenv("RVCX_PAIR_PERSIST") || atoi(getenv("RVCX_PAIR_PERSIST")) != 0;
+  if (variant == 0 && persist && pair_aligned(a))
+    for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
+      if (kPair[i].variant == 10 && kPair[i].C == C && kPair[i].K == K) return &kPair[i];
   const int want = variant != 0 ? variant : (pair_aligned(a) ? 4 : 0);
   if (want != 0)
     for (int i = kPairBase; i < (int)(sizeof(kPair) / sizeof(kPair[0])); ++i)
@@ -1290,6 +1735,14 @@ void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
   const PairCfg& c = *find_cfg(a);
   const int bn_out = c.bn_out;
   dim3 grid(cdiv(a.T, bn_out), 1, a.B);
+  if (c.persist) {
+    static const int ncu = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return std::max(8, n);
+    }();
+    grid.x = std::min<unsigned>(grid.x, (unsigned)ncu);
+  }
   static const int xcd = getenv("RVCX_PAIR_XCD") ? atoi(getenv("RVCX_PAIR_XCD")) : 1;
   PairArgs b = a;
   b.xcd_order = xcd;

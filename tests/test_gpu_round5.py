@@ -111,3 +111,28 @@ def test_raw_c_abi_calls_from_two_threads_queue_on_the_context_mutex():
             assert all(np.array_equal(o, solo[k]) for o in outs[k]) and len(outs[k]) == 6
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("B,Cin,T", [(1, 32, 4096), (2, 32, 1000), (1, 32, 20), (1, 64, 2052), (3, 16, 516)])
+def test_conv_post_shape_runs_the_cout1_kernel_and_matches_torch(ctx, B, Cin, T):
+    """NSF conv_post (nsf.py:142-144): leaky_relu(0.01) -> Conv1d(C, 1, 7, padding 3, no bias) -> tanh.  Round 5 gives
+    Cout = 1 layers a vector-FMA kernel (csrc/conv_fast.hip: conv_cout1_kernel, exact fp32) instead of a 32-row MFMA tile
+    with 31 rows of padding; per-item lengths zero the input beyond len and the output beyond len."""
+    import torch
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + T)
+    x = torch.randn(B, Cin, T, generator=gen)
+    w = torch.randn(1, Cin, 7, generator=gen) / (Cin * 7) ** 0.5
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), w, None, padding=3)).numpy()
+    got = ctx.conv1d(x.numpy(), w.numpy(), None, pad_left=3, pre_lrelu=0.01, act=4)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-6
+    if B > 1:
+        lens = np.array([T - 5 * (i + 1) - 2 for i in range(B)], np.int32)
+        xm = x.clone()
+        for i, n in enumerate(lens):
+            xm[i, :, n:] = 0
+        ref = torch.tanh(F.conv1d(F.leaky_relu(xm, 0.01), w, None, padding=3)).numpy()
+        for i, n in enumerate(lens):
+            ref[i, :, n:] = 0
+        got = ctx.conv1d(x.numpy(), w.numpy(), None, pad_left=3, pre_lrelu=0.01, act=4, lens_in=lens, lens_out=lens)
+        assert np.abs(got - ref).max() < 2e-6
