@@ -18,7 +18,32 @@ build/%.o: $(CSRC)/%.hip $(HDRS)
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
+# ---- host-side sanitizer build (CPU container only; never on the GPU box) ------------------------------------------
+# The HOST pass of every .hip file under AddressSanitizer + UBSan, linked against tools/hipstub (HIP runtime on host memory,
+# kernel launches are no-ops): build/asan/librvcx_asan.so.  tools/host_asan.sh builds it and runs tools/host_asan_driver.py.
+CLANGXX ?= /opt/rocm/lib/llvm/bin/clang++
+ASAN_FLAGS := --cuda-host-only -O1 -g -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-result -fsanitize=address,undefined \
+              -fno-sanitize-recover=undefined -fno-omit-frame-pointer
+ASAN_OBJS := $(patsubst $(CSRC)/%.hip,build/asan/%.o,$(SRCS))
+
+build/asan/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/asan
+	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
+
+build/asan/hipstub.o: tools/hipstub/hipstub.cpp
+	@mkdir -p build/asan
+	$(HIPCC) $(ASAN_FLAGS) -x hip -c $< -o $@
+
+# one dummy definition per translation unit's __hip_fatbin_<hash> (the device code objects a host-only pass does not have)
+build/asan/fatbins.c: $(ASAN_OBJS)
+	nm $(ASAN_OBJS) | awk '/ U __hip_fatbin_/ {print "char " $$2 "[64] = {0};"}' | sort -u > $@
+
+build/asan/librvcx_asan.so: $(ASAN_OBJS) build/asan/hipstub.o build/asan/fatbins.c
+	$(CLANGXX) -shared -fPIC -fsanitize=address,undefined -shared-libasan $(ASAN_OBJS) build/asan/hipstub.o build/asan/fatbins.c -o $@
+
+host-asan: build/asan/librvcx_asan.so
+
 clean:
 	rm -rf build $(OUT)
 
-.PHONY: all clean
+.PHONY: all clean host-asan

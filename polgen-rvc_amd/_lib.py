@@ -617,6 +617,8 @@ class Context:
         wt = C.c_double if is64 else C.c_float
         wp = (C.POINTER(wt) * B)(*[_p(w, wt) for w in wavs])
         caps = [self.out_capacity(model_id, w.shape[0], params) for w in wavs]
+        if any(c < 0 for c in caps):
+            raise RvcxError(f"convert_batch: no voice model with id {model_id} is resident in this context")
         outs = [np.empty(c, np.int16) for c in caps]
         op = (C.POINTER(C.c_int16) * B)(*[_p(o, C.c_int16) for o in outs])
         f32s, fp = None, None

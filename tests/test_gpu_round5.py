@@ -92,13 +92,13 @@ def test_raw_c_abi_calls_from_two_threads_queue_on_the_context_mutex():
         mid = c.load_synth(W.synth_cfg_struct(scfg, hcfg["embed_dim"]), S.synth_state(scfg, 1, input_dim=hcfg["embed_dim"]))
         params = _lib.Params(0.0, 50.0, 1100.0, 0.0, 0.33, 1.0, 0, 1, 6, 38, 41, 9)
         clips = [S.make_clip(70, 2.0), S.make_clip(71, 1.3)]
-        solo = [c.convert_batch(mid, [clips[k]], params)[0][0].copy() for k in range(2)]
+        solo = [c.convert_batch(mid, [clips[k]], params)[0].copy() for k in range(2)]
         outs, errs = [[], []], []
 
         def work(k):
             try:
                 for _ in range(6):
-                    outs[k].append(c.convert_batch(mid, [clips[k]], params)[0][0].copy())
+                    outs[k].append(c.convert_batch(mid, [clips[k]], params)[0].copy())
             except Exception as e:  # noqa: BLE001
                 errs.append(e)
         th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
@@ -108,6 +108,7 @@ def test_raw_c_abi_calls_from_two_threads_queue_on_the_context_mutex():
             t.join()
         assert not errs, errs
         for k in range(2):
+            assert solo[k].ndim == 1 and solo[k].shape[0] > 1000
             assert all(np.array_equal(o, solo[k]) for o in outs[k]) and len(outs[k]) == 6
     finally:
         c.close()
