@@ -785,6 +785,8 @@ class Context:
                 return f"conv_h3<{bm[i]},{bn[i]},{'linear' if c == 1 else 'stride2' if c == 2 else 'halo%d' % c}>"
             if kd[i] == 300001:
                 return "conv_cout1 (vector FMA, Cout=1)"
+            if kd[i] == 300002:
+                return "convt_thin (ConvTranspose1d k4 s2, streaming MFMA + fused noise conv)"
             if kd[i] >= 300000:
                 return "conv_cin1 (vector FMA, Cin=1)"
             if kd[i] >= 200000:

@@ -51,6 +51,17 @@ struct ConvArgs {
   int zero_wp = 0;               // >0: force the pad columns of a row-padded 2-D map to 0
   int acc2_mode = ACC2_NONE;
   float acc2_div = 1.f;
+  // OUT_SHUF1D only: the NSF noise conv of the stage (Conv1d(1, C, k = nz_k, stride nz_stride, padding nz_pad) over the
+  // harmonic source, nsf.py:128-129) evaluated inside the epilogue instead of being read back as `res`: adds
+  // nz_b[c] + sum_j nz_w[j * nz_wstride + c] * har[t * nz_stride + j - nz_pad] to output (c, t).  Only the thin
+  // ConvTranspose1d kernel (convt_thin.hip) implements it; launch_conv refuses the fields elsewhere.
+  const float* nz_har = nullptr;   // (B, nz_len_row) harmonic source
+  const float* nz_w = nullptr;     // packed Cin = 1 weights: tap j of channel c at nz_w[j * nz_wstride + c]
+  const float* nz_b = nullptr;
+  const int* nz_lens = nullptr;    // per-item valid source samples (null: nz_len)
+  int nz_k = 0, nz_stride = 1, nz_pad = 0, nz_wstride = 0;
+  long nz_bs = 0;
+  int nz_len = 0;
   // split-K scratch offered by the caller (per stream); the launcher decides whether to use it
   float* part = nullptr;
   long part_cap = 0;             // floats
@@ -129,6 +140,10 @@ void launch_conv(ConvArgs a, hipStream_t stream);   // picks kernel family + til
 int launch_conv_fast(ConvArgs& a, hipStream_t stream);    // stride-1 compile-time-tiled family; profile slot or -1
 void conv_fast_describe(ConvProfile* p);
 int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream);   // fp16x3 split kernels; slot or -1
+bool convt_thin_ok(const ConvArgs& a);                       // ConvTranspose1d(C -> C/2, k = 4, s = 2) on the thin kernel?
+void launch_convt_thin(const ConvArgs& a, hipStream_t stream);
+void convt_thin_init();
+constexpr int kConvtThinSlot = 61;
 bool conv_h3_enabled();      // RVCX_H3 on and the calling thread is not in an exact-fp32 rerun
 bool conv_h3_configured();   // RVCX_H3 on (what checkpoint loading looks at)
 bool conv_h3_split_ok(const ConvArgs& a);   // may this launch read / write pre-split activations?

@@ -476,6 +476,9 @@ void conv_fast_describe(ConvProfile* p) {
   p->bm[60] = 1;
   p->bn[60] = 1024;
   p->halo[60] = 300001;   // slot 60: conv_cout1_kernel
+  p->bm[kConvtThinSlot] = 128;
+  p->bn[kConvtThinSlot] = 32;
+  p->halo[kConvtThinSlot] = 300002;   // convt_thin_kernel
   for (int t = 0; t < kNumFast; ++t) {
     const int s = 8 + t;
     p->bm[s] = kFast[t].bm;
@@ -496,6 +499,11 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     RVCX_HIP(hipGetLastError());
     return 7;
   }
+  if (convt_thin_ok(a)) {
+    launch_convt_thin(a, stream);
+    return kConvtThinSlot;
+  }
+  RVCX_CHECK(!a.nz_har, "conv: a fused noise conv needs the thin ConvTranspose1d kernel (convt_thin.hip)");
   if (conv_cout1_ok(a)) {
     static const bool on = !getenv("RVCX_COUT1") || atoi(getenv("RVCX_COUT1")) != 0;
     if (on) {

@@ -213,6 +213,19 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   const long Tupp = (long)T * m.upp;
   float* har = A.alloc<float>((size_t)B * Tupp);
   std::vector<float*> nz(m.stages.size(), nullptr);
+  // Stages whose ConvTranspose1d runs on the streaming kernel (convt_thin.hip: k = 4, stride 2, C = 128 / 64 -- the two
+  // last stages of every RVC v2 decoder) evaluate their noise conv inside that kernel's epilogue from `har`: its output is
+  // never written to HBM (196 MB per stage and 30 s clip, written here and read back there).
+  std::vector<char> nz_fused(m.stages.size(), 0);
+  for (size_t i = 0; i < m.stages.size(); ++i) {
+    const auto& S = m.stages[i];
+    ConvArgs probe = convT1d_args(S.up, nullptr, nullptr, 1, 1, cf.up_rates[i]);
+    probe.pre_act = ACT_LRELU;
+    probe.pre_slope = 0.1f;
+    static const bool fuse_on = !getenv("RVCX_NOISE_FUSE") || atoi(getenv("RVCX_NOISE_FUSE")) != 0;
+    nz_fused[i] = fuse_on && S.noise.cin == 1 && S.noise.groups == 1 && S.noise.k >= 1 && S.noise.k <= 4 && S.noise.cout == S.ch &&
+                  convt_thin_ok(probe);
+  }
   {
     hipStream_t sn = c.serial ? s : c.aux[0];
     if (sn != s) {
@@ -225,6 +238,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     for (size_t i = 0; i < m.stages.size(); ++i) {
       const auto& S = m.stages[i];
       tt *= cf.up_rates[i];
+      if (nz_fused[i]) continue;
       nz[i] = A.alloc<float>((size_t)B * S.ch * tt);
       ConvArgs a = conv1d_args(S.noise, har, nz[i], B, (int)Tupp, (int)tt, S.noise_stride, 1, S.noise_pad);
       a.lens_in = lens_stage[m.stages.size()];
@@ -386,7 +400,20 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       a.pre_slope = 0.1f;
       a.lens_in = lin;
       a.lens_out = lout;
-      conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout_c, S.ch, (int)Tout_c);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
+      if (nz_fused[i]) {               // x = up(x) + noise_conv(har_source), the noise conv inside the epilogue
+        a.nz_har = har + (size_t)b0 * Tupp;
+        a.nz_bs = Tupp;
+        a.nz_w = S.noise.w;
+        a.nz_wstride = S.noise.cin_gp * S.noise.cout_gp;
+        a.nz_b = S.noise.bias;
+        a.nz_k = S.noise.k;
+        a.nz_stride = S.noise_stride;
+        a.nz_pad = S.noise_pad;
+        a.nz_len = own ? (int)((long)Td * m.upp) : (int)Tupp;
+        a.nz_lens = (lens_stage[m.stages.size()] && !own) ? lens_stage[m.stages.size()] + b0 : nullptr;
+      } else {
+        conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout_c, S.ch, (int)Tout_c);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
+      }
       c.conv(a);
       // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
       // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases

@@ -111,7 +111,10 @@ def test_conv1d_ragged_lengths(ctx):
 
 
 @pytest.mark.parametrize("case", [(1, 64, 50, 32, 24, 12, 6), (2, 80, 37, 40, 8, 4, 2), (1, 40, 29, 20, 7, 3, 2),
-                                  (1, 128, 100, 64, 16, 10, 3), (1, 64, 300, 32, 4, 2, 1)])
+                                  (1, 128, 100, 64, 16, 10, 3), (1, 64, 300, 32, 4, 2, 1),
+                                  # k = 4, stride 2, C = 64 / 128: the streaming kernel of round 5 (csrc/convt_thin.hip)
+                                  (2, 128, 1000, 64, 4, 2, 1), (1, 64, 33, 32, 4, 2, 1), (3, 128, 31, 64, 4, 2, 1),
+                                  (1, 64, 70001, 32, 4, 2, 1), (1, 128, 9000, 64, 4, 2, 1)])
 def test_convtranspose1d(ctx, case):
     B, Cin, Tin, Cout, K, s, p = case
     gen = torch.Generator().manual_seed(11)
