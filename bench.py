@@ -55,16 +55,18 @@ WORKER_DEADLINE_S = 3600.0   # launch_workers: the whole multi-rank run
 PEAK_FILE = "mfma_peak_r04.json"   # profiles/: measured split-fp16 ceiling on random operands (tools/mfma_peak.hip)
 
 
-def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False):
+def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False, outliers=False):
     """zero: this rank receives rank 0's folded weights by broadcast -- it loads shape-only placeholders (zeros, no
     random numbers drawn: the region layout depends on shapes only)."""
     if zero:
         with S.shapes_only():
-            return load_models(ctx, False, fcpe, also_40k, crepe)
+            return load_models(ctx, False, fcpe, also_40k, crepe, outliers)
 
     def z(state):
         return state
-    ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0)))
+    # outliers: the HuBERT with planted massive-activation units (synthetic.py: _plant_outliers) -- what ContentVec-shaped
+    # weights do to the fp16-range guard of the split kernels
+    ctx.load_hubert(W.hubert_cfg_struct(S.HUBERT_CFG_BASE), z(S.hubert_state(S.HUBERT_CFG_BASE, 0, outliers=outliers)))
     if crepe:
         ctx.load_crepe(z(S.crepe_state("full", 0)))
     elif fcpe:
@@ -220,6 +222,16 @@ def exact_fp32_child(steps, warmup):
     return out
 
 
+def outliers_child(steps, warmup):
+    """C2 again with a HuBERT that carries planted outlier units: FFN activations of 400-900 (inside the split kernels'
+    range: must stay on the fast path) and attention V heads of ~1200 in two layers (beyond fp16 range for K / V: the
+    guard pins exactly those two attention calls to the exact-fp32 kernel during warm-up; `fast_path` shows the counts)."""
+    out, _ = child_bench(["--steps", str(steps), "--warmup", str(max(3, warmup)), "--hubert-outliers"], {},
+                         {"workload": "c2 with outlier units planted in HuBERT (synthetic.hubert_state(outliers=True): FFN units "
+                                      "x200 in layers 2/6/10, V head 3 x400 in layers 4/8)"}, roofline=False)
+    return out
+
+
 def c3_child():
     """BASELINE configs[2] at its stated size: 64 x 30 s per step, index_rate 0.75 over 65 536 x 768."""
     out, d = child_bench(["--workload", "c3", "--steps", "3", "--warmup", "1"], {},
@@ -340,6 +352,8 @@ def main():
                     help="skip the exact_fp32 and c3 child benches of the default run")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default="")
+    ap.add_argument("--hubert-outliers", action="store_true",
+                    help="HuBERT with planted massive-activation units (what real ContentVec-shaped weights do to the range guard)")
     ap.add_argument("--verify-ranks", action="store_true",
                     help="every rank converts one probe clip after the weight broadcast; rank 0 reports whether all PCM digests agree")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing run (gloo): launcher, shard, timing")
@@ -363,9 +377,10 @@ def main():
         raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
     if a.dry_run:
         return dry_run(a, rank, world)
-    fp32 = c3_obj = c5_obj = None
-    if world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe:
+    fp32 = c3_obj = c5_obj = out_obj = None
+    if world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe and not a.hubert_outliers:
         fp32 = exact_fp32_child(a.steps, a.warmup)       # all before the first GPU call of this process
+        out_obj = outliers_child(a.steps, a.warmup)
         c3_obj = c3_child()
         c5_obj = c5_child()
         time.sleep(5.0)                                  # the children left the chip warm: let it idle before the headline loop
@@ -376,7 +391,7 @@ def main():
 
     # rank 0 parses/folds/packs the checkpoints; the folded weight regions go to the other GPUs over RCCL/xGMI
     t0 = time.perf_counter()
-    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5, crepe=crepe)
+    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5, crepe=crepe, outliers=a.hubert_outliers)
     mid = mids[0] if c5 else mids
     if c3:
         big = S.make_index(C3_INDEX_ROWS, 768, 0)
@@ -559,12 +574,14 @@ def main():
                "conv_tiles": prof}
         if fp32 is not None:
             res["exact_fp32"] = fp32
+        if out_obj is not None:
+            res["outliers"] = out_obj
         if c3_obj is not None:
             res["c3"] = c3_obj
         if c5_obj is not None:
             res["c5"] = c5_obj
         if fp32 is not None or c3_obj is not None:
-            res["order"] = "children (exact_fp32, c3, c5) ran first, each to completion; 5 s idle; then this process's warm-up and timed loop"
+            res["order"] = "children (exact_fp32, outliers, c3, c5) ran first, each to completion; 5 s idle; then this process's warm-up and timed loop"
         if not a.no_cpu_baseline and world == 1 and not fcpe:
             res["cpu_baseline"] = cpu_baseline()
         else:

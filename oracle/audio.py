@@ -11,6 +11,18 @@ samples per zero crossing, roll-off 0.9475937167399596, beta 14.769656459379492,
 samples, output length int(n * ratio)) from its published description.  The product's resampler (csrc/audio.hip) is
 tested against this restatement; neither is checked against soxr.
 
+STATED BOUND against the reference's resampler (tests/test_resample_spec.py measures every figure).  soxr's "HQ" recipe
+is public (soxr.c, soxr_quality_spec: 20-bit precision): pass-band flat to 0.9136 x Nyquist(out) = 7.31 kHz, stop-band
+from 1.0 x Nyquist(out) = 8 kHz at -120.4 dB, linear phase.  kaiser_best at 44.1 k / 48 k -> 16 k:
+  * a constant pass-band gain of +0.034 ... +0.036 dB (resampy steps through its table with int(scale * 512): 185 for
+    185.76), flat within +-0.02 dB of that up to 7.0 kHz; -0.4 dB at 7.3 kHz, -4 dB at 7.5 kHz (soxr_hq: still flat);
+  * alias rejection -55 ... -64 dB for 8 ... 9 kHz, below -67 dB from 10 kHz, below -78 dB from 20 kHz (soxr_hq: -120 dB);
+  * on the C2 benchmark signal rendered at 44.1 kHz, against a Kaiser FIR built to soxr_hq's targets: 3.1e-3 relative RMS
+    (-50 dB); 1.6e-3 (-56 dB) with the least-squares gain of 1.0027 divided out.
+So a request whose upload is not 16 kHz enters the networks ~0.3 % louder and with a 0.3 kHz narrower top octave than in
+the reference -- three orders of magnitude above the waveform parity the 16 kHz path is held to (1e-5), which is why
+parity is defined, tested and benchmarked on 16 kHz input (BASELINE.json: "synthetic 16 kHz mono clips").
+
 Only tests/ (and tools/) may import this module."""
 from __future__ import annotations
 

@@ -252,7 +252,50 @@ def rmvpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
 # ----------------------------------------------------------------------------
 # HuBERT base, fairseq 0.12.2 key names
 # ----------------------------------------------------------------------------
-def hubert_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
+# Real HuBERT / wav2vec2-base checkpoints are not O(1) everywhere: a handful of FFN units and attention value heads carry
+# "massive activations" -- hundreds to a few thousand against a bulk of order one (the published outlier-dimension
+# analyses of BERT-family and wav2vec2 / HuBERT encoders).  ``outliers=True`` plants that shape in the synthetic model,
+# function-preservingly (each scaled producer row is undone in its consumer's column), so the bulk statistics and every
+# downstream activation stay where the goldens expect them:
+#   * layers OUTLIER_FFN_LAYERS: OUTLIER_FFN_UNITS units of fc1 (weight row + bias) x 200, the matching fc2 columns / 200
+#     -> GELU outputs of several hundred to ~2000 enter fc2 (inside the split kernels' range, 6e4: must NOT be pinned);
+#   * layers OUTLIER_V_LAYERS: the v_proj rows (+ bias) of head OUTLIER_V_HEAD x 400, the out_proj columns of that head
+#     / 400 -> V values of 400 ... 1500, beyond the attention kernel's fp16 range for K / V (255): exactly these layers'
+#     attention calls must be pinned to the exact-fp32 kernel by the range guard, once, and stay pinned.
+OUTLIER_FFN_LAYERS, OUTLIER_FFN_UNITS, OUTLIER_FFN_GAIN = (2, 6, 10), 4, 200.0
+OUTLIER_V_LAYERS, OUTLIER_V_HEAD, OUTLIER_V_GAIN = (4, 8), 3, 400.0
+
+
+def _plant_outliers(t: Dict[str, np.ndarray], cfg: dict, seed: int) -> None:
+    E, Fd, L, H = cfg["embed_dim"], cfg["ffn_dim"], cfg["layers"], cfg["heads"]
+    d = E // H
+    for l in OUTLIER_FFN_LAYERS:
+        if l >= L:
+            continue
+        p = f"encoder.layers.{l}"
+        units = _rng(f"outlier.ffn.{l}", seed).choice(Fd, OUTLIER_FFN_UNITS, replace=False)
+        w1, b1, w2 = (np.array(t[p + ".fc1.weight"]), np.array(t[p + ".fc1.bias"]), np.array(t[p + ".fc2.weight"]))
+        g = np.float32(OUTLIER_FFN_GAIN)
+        w1[units] *= g
+        # a positive pre-activation keeps the unit in GELU's linear range (gelu(g x) = g gelu(x) only holds there): the
+        # planted unit then IS a large activation on every frame, as the published outlier units are
+        b1[units] = np.abs(b1[units]) * g + g
+        w2[:, units] /= g
+        t[p + ".fc1.weight"], t[p + ".fc1.bias"], t[p + ".fc2.weight"] = w1, b1, w2
+    for l in OUTLIER_V_LAYERS:
+        if l >= L:
+            continue
+        p = f"encoder.layers.{l}.self_attn"
+        rows = slice((OUTLIER_V_HEAD % H) * d, (OUTLIER_V_HEAD % H + 1) * d)
+        wv, bv, wo = np.array(t[p + ".v_proj.weight"]), np.array(t[p + ".v_proj.bias"]), np.array(t[p + ".out_proj.weight"])
+        g = np.float32(OUTLIER_V_GAIN)
+        wv[rows] *= g
+        bv[rows] *= g
+        wo[:, rows] /= g
+        t[p + ".v_proj.weight"], t[p + ".v_proj.bias"], t[p + ".out_proj.weight"] = wv, bv, wo
+
+
+def hubert_state(cfg: dict = None, seed: int = 0, outliers: bool = False) -> Dict[str, np.ndarray]:
     cfg = cfg or HUBERT_CFG_BASE
     T = _Table(seed + 31)
     C, E, Fd = cfg["conv_dim"], cfg["embed_dim"], cfg["ffn_dim"]
@@ -288,6 +331,8 @@ def hubert_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
     # present in real checkpoints, unused by the v2 path (pipeline.py:236 uses final_proj for v1 only)
     T.normal("mask_emb", (E,), 0.1)
     T.conv("final_proj", (cfg["final_dim"], E), gain=1.0)
+    if outliers and not _SHAPES_ONLY:
+        _plant_outliers(T.t, cfg, seed)
     return T.t
 
 

@@ -137,3 +137,32 @@ def test_conv_post_shape_runs_the_cout1_kernel_and_matches_torch(ctx, B, Cin, T)
             ref[i, :, n:] = 0
         got = ctx.conv1d(x.numpy(), w.numpy(), None, pad_left=3, pre_lrelu=0.01, act=4, lens_in=lens, lens_out=lens)
         assert np.abs(got - ref).max() < 2e-6
+
+
+def test_hubert_with_planted_outlier_units_pins_exactly_the_two_attention_layers(tmp_path):
+    """real ContentVec / HuBERT-base weights have massive-activation units.  synthetic.hubert_state(
+    outliers=True) plants them at published magnitudes: FFN units of 400-900 in layers 2 / 6 / 10 (inside the split
+    kernels' range of 6e4: nothing may be pinned for them) and a V head of ~1200 in layers 4 / 8 (beyond the attention
+    kernel's fp16 range for K / V, 255).  Expected: the layer-12 features match the golden of the HF twin on the same
+    weights (fixture hubert_base_1s_outliers, tools/gen_golden.py), exactly TWO layers end up pinned to the exact-fp32
+    kernels -- found during the first call, one repeated call per offender -- and the second call repeats nothing."""
+    from polgen_rvc_amd import _lib, synthetic as S, weights as W
+    from conftest import rms
+    d = np.load(os.path.join(GOLD, "hubert_base_1s_outliers.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    assert float(d["outlier_max_v"]) > 255 and 300 < float(d["outlier_max_ffn"]) < 6e4
+    c = _lib.Context(0)
+    try:
+        c.load_hubert(W.hubert_cfg_struct(cfg), S.hubert_state(cfg, int(d["seed"]), outliers=True))
+        assert c.fp32_layers() == 0
+        r0 = c.fp32_reruns()
+        got = c.hubert_features(d["wav"], cfg["embed_dim"], cfg["layers"])
+        e = rms(got - d["out"]) / rms(d["out"])
+        pinned, reruns = c.fp32_layers(), c.fp32_reruns() - r0
+        print(f"hubert with planted outliers: rel err {e:.3e}; layers pinned to fp32 {pinned}, repeated calls {reruns}")
+        assert e < 1e-4
+        assert pinned == len(S.OUTLIER_V_LAYERS) == 2 and reruns == 2
+        again = c.hubert_features(d["wav"], cfg["embed_dim"], cfg["layers"])
+        assert c.fp32_reruns() - r0 == 2 and c.fp32_layers() == 2 and np.array_equal(again, got)
+    finally:
+        c.close()

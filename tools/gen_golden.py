@@ -263,9 +263,9 @@ def gold_rmvpe_illcond(tag="illcond", cfg=None, clip=60, seconds=1.5, seed=4):
                         hidden=hid, f0=f0, unstable=bad.astype(np.int32))
 
 
-def gold_hubert(tag, cfg, seconds, seed):
+def gold_hubert(tag, cfg, seconds, seed, outliers=False):
     print(f"[hubert {tag}] {seconds}s  (HF twin; fairseq absent -> parity unpinned by the reference)")
-    sd = S.to_torch(S.hubert_state(cfg, seed))
+    sd = S.to_torch(S.hubert_state(cfg, seed, outliers=outliers))
     hf = hf_hubert(cfg, sd)
     wav = torch.from_numpy(S.make_clip(3 + seed, seconds)).unsqueeze(0)
     out = hf(wav, output_hidden_states=True)
@@ -274,9 +274,28 @@ def gold_hubert(tag, cfg, seconds, seed):
     e = report(f"layer{L}", out.hidden_states[L], mine)
     report("layer1", out.hidden_states[1], O_hubert.extract_features(sd, cfg, wav, 1))
     assert e < 2e-5, e
+    extra = {}
+    if outliers:
+        # the magnitudes the planted units really reach on this clip (HF twin's own activations), for the record and the test
+        acts = {}
+        hooks = []
+        for l in set(S.OUTLIER_FFN_LAYERS) | set(S.OUTLIER_V_LAYERS):
+            lay = hf.encoder.layers[l]
+            hooks.append(lay.feed_forward.intermediate_act_fn.register_forward_hook(
+                lambda m, i, o, l=l: acts.__setitem__(f"ffn{l}", float(o.abs().max()))) if hasattr(lay.feed_forward.intermediate_act_fn, "register_forward_hook") else None)
+            hooks.append(lay.attention.v_proj.register_forward_hook(lambda m, i, o, l=l: acts.__setitem__(f"v{l}", float(o.abs().max()))))
+            hooks.append(lay.feed_forward.intermediate_dense.register_forward_hook(
+                lambda m, i, o, l=l: acts.__setitem__(f"fc1_{l}", float(o.abs().max()))))
+        hf(wav)
+        for hk in hooks:
+            if hk is not None:
+                hk.remove()
+        print("   planted-outlier magnitudes:", {k: round(v, 1) for k, v in sorted(acts.items())})
+        extra = dict(outlier_max_v=max(v for k, v in acts.items() if k.startswith("v")),
+                     outlier_max_ffn=max(v for k, v in acts.items() if k.startswith("fc1_")))
     np.savez_compressed(os.path.join(GOLD, f"hubert_{tag}.npz"), seed=seed, cfg=json.dumps(cfg),
                         wav=wav.numpy(), out=out.hidden_states[L].numpy(),
-                        out_l1=out.hidden_states[1].numpy())
+                        out_l1=out.hidden_states[1].numpy(), **extra)
 
 
 def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0_min, f0_max, seed,
@@ -593,6 +612,8 @@ def main():
         "rmvpe_illcond": gold_rmvpe_illcond,
         "hubert_tiny": lambda: gold_hubert("tiny", S.HUBERT_CFG_TINY, 0.5, 1),
         "hubert_base": lambda: gold_hubert("base_1s", S.HUBERT_CFG_BASE, 1.0, 0),
+        # the same model with planted outlier units (synthetic.py: _plant_outliers): what real ContentVec-shaped weights do
+        "hubert_outliers": lambda: gold_hubert("base_1s_outliers", S.HUBERT_CFG_BASE, 1.0, 0, outliers=True),
         "pipe_tiny": lambda: gold_pipeline("tiny_single", tiny, (1, 6, 38, 41), 2.0, 11, 1, 0, 1.0, 0.33, 50, 1100),
         # CI's canonical argument set (test_cli.yml:43): -p -0.5 -rms 0.25 -pro 0.33 -f0min 1 -f0max 1100
         "pipe_tiny_ci": lambda: gold_pipeline("tiny_ciargs", tiny, (1, 6, 38, 41), 2.5, 12, 1, -0.5, 0.25, 0.33, 1, 1100),
