@@ -182,7 +182,7 @@ struct Ctx {
   hipEvent_t ev_src[2] = {nullptr, nullptr};   // NSF source branch (sine + noise convs) beside TextEncoder/flow
   Arena arena;
   Arena arena_f0;                 // RMVPE workspace: lives on stream2 across the main stream's arena resets
-  Arena arena_hub;                // HuBERT workspace: lives on HuBERT's stream (aux[0]), so micro-batch k+1's HuBERT runs beside k's decoder
+  Arena arena_hub;                // HuBERT workspace: its own arena because HuBERT k+1 is enqueued (on aux[0], behind decoder k's branch there) before the main arena of k is released
   WeightSlab slab;
   std::string last_error;
   double flops = 0.0;

@@ -402,7 +402,7 @@ __global__ __launch_bounds__((GruUnitGeom<NC, CPT>::THREADS)) void bigru_unit_ke
       } while (o.s.tag != 1);
       if (__float_as_uint(o.s.v) != xcc) same = 0;
     }
-    s_same = RVCX_GRU_PLAIN_PUBLISH ? same : 0;
+    s_same = (RVCX_GRU_PLAIN_PUBLISH && colocate != 2) ? same : 0;      // colocate == 2: the runtime switch RVCX_GRU_PLAIN_PUBLISH=0
   }
   __syncthreads();
   if (sfail) {             // a partner never started: the caller re-runs on the single-workgroup kernel
@@ -527,7 +527,14 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
     unsigned long long* xbuf = static_cast<unsigned long long*>(scratch);
     RVCX_HIP(hipMemsetAsync(scratch, 0, bigru_scratch_bytes(B), stream));
     static int colocate = -1;
-    if (colocate < 0) colocate = getenv("RVCX_GRU_COLOCATE") ? atoi(getenv("RVCX_GRU_COLOCATE")) : 1;
+    if (colocate < 0) {
+      colocate = getenv("RVCX_GRU_COLOCATE") ? atoi(getenv("RVCX_GRU_COLOCATE")) : 1;
+      // The plain (non write-through) publish of h_t inside one XCD relies on the partners' sc1 polls being served by that
+      // XCD's L2 -- observed behaviour of this driver / MTYPE, outside the HIP memory model (INTEGRATION.md "hardware
+      // assumptions").  If it ever stops holding, every call spins ~1.5 s per cluster and falls back (rvcx_gru_fallbacks
+      // counts it; tests assert 0): RVCX_GRU_PLAIN_PUBLISH=0 switches every cluster to the write-through store at run time.
+      if (colocate == 1 && getenv("RVCX_GRU_PLAIN_PUBLISH") && atoi(getenv("RVCX_GRU_PLAIN_PUBLISH")) == 0) colocate = 2;
+    }
     const int nq = 2 * B;
     const int grid = colocate ? 8 * nc * cdiv(nq, 8) : nc * nq;
     // RVCX_GRU_FORM: 0 = the round-3 kernel (4 rows x 32 columns per thread, scalar FMAs; it hosts the RVCX_GRU_B128

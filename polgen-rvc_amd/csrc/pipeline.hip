@@ -441,7 +441,17 @@ long bucket_length(long n, const rvcx_params& p, const Geometry& g) {
 int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p) {
   // 16: the BiGRU cluster kernel's co-residency bound (2 directions x 16 items x 4 workgroups = 128); C5 +3 %, C3 +1 % over 8
   static const int env_max = getenv("RVCX_MAX_BATCH") ? std::max(1, atoi(getenv("RVCX_MAX_BATCH"))) : 16;
-  static const size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 100) << 30;   // 64 x 30 s: micro-batches of 16 instead of 11 (+1 %); the GPU has 288 GB
+  // Activation budget: RVCX_ARENA_GB if set; else 100 GB (64 x 30 s: micro-batches of 16 instead of 11, +1 %) but never
+  // more than 70 % of what the device has FREE right now -- a second context on the same GPU, or a smaller GPU, must not
+  // turn the default into an out-of-memory error (the arena only ever grows: what this context already holds counts as free).
+  size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 100) << 30;
+  if (!getenv("RVCX_ARENA_GB")) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+      const size_t mine = c.arena.capacity() + c.arena_f0.capacity() + c.arena_hub.capacity();
+      budget = std::min(budget, (size_t)((double)(free_b + mine) * 0.7));
+    }
+  }
   const size_t per = convert_item_bytes(c, model_id, n, p) + f0_arena_bytes(c, p, 1, n + 32000L * p.x_pad);
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)env_max, budget / std::max<size_t>(per, 1)));
 }
@@ -888,8 +898,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     RVCX_CHECK(off <= fr[k & 1].feats_cap, "internal: HuBERT feature buffer smaller than the chunk plan");
   };
 
-  // ---- HuBERT of one micro-batch on its own stream and out of its own arena: it depends on the micro-batch's front
-  // end only, so for k >= 1 it runs beside the synthesizer of micro-batch k-1.
+  // ---- HuBERT of one micro-batch out of its own arena, on aux[0] -- the stream the decoder's second ResBlock branch uses.
+  // It depends on the micro-batch's front end only, but it is ENQUEUED behind synth_forward(k - 1): in a batched call
+  // HuBERT k queues behind decoder k - 1's last aux[0] branch, so the HuBERT / decoder overlap of rounds 2-3 (a stream of
+  // its own) is gone -- traded, with a measured net gain, for not paying the fifth stream's shared hardware queue (api.hip;
+  // DESIGN "Four streams, not five").  What still overlaps: HuBERT k beside the F0 model of k (front stream).
   std::vector<int> hub_ev0(mbs.size(), -1), hub_ev1(mbs.size(), -1);
   auto enqueue_hubert = [&](int k) {
     const MB& mb = mbs[k];

@@ -45,7 +45,7 @@ def test_c3_64x30s_with_index_equals_single_runs_and_reference(ctx, full):
     try:
         noise0 = _fixture_noise(scfg, int(d["chunk_lens"][0]), 48000, d["noise_seed"])
         p = _params(index_rate=float(d["index_rate"]))
-        reruns0 = ctx.fp32_reruns()
+        reruns0, fallbacks0 = ctx.fp32_reruns(), ctx.gru_fallbacks()
         mb = ctx.micro_batch(full, len(clip0), p)
         assert 2 <= mb <= 16 and 64 // mb >= 4
         pcm, f32 = ctx.convert_batch(full, clips, p, noises=[noise0] + [None] * 63, want_f32=True)
@@ -66,6 +66,10 @@ def test_c3_64x30s_with_index_equals_single_runs_and_reference(ctx, full):
         print(f"one at a time: {t_single:.0f} ms")
         assert all(np.isfinite(x).all() and rms(x) > 1e-3 for x in f32)
         assert ctx.fp32_reruns() == reruns0          # the split-fp16 kernels never left their range
+        # the BiGRU's plain-store publish inside one XCD is an observed hardware behaviour; if it ever breaks, every
+        # cluster spins into its time-out and the call silently falls back to the single-workgroup kernel -- a slowdown, not an
+        # error.  64 batched + 64 single C3-shaped conversions with zero fallbacks keep it a test failure instead.
+        assert ctx.gru_fallbacks() == fallbacks0
     finally:
         ctx.load_index(None)
 
