@@ -340,6 +340,11 @@ int rvcx_op_conv1d(rvcx_ctx*, const float* x, const float* w, const float* bias,
 int rvcx_op_resblock_pair(rvcx_ctx*, const float* x, const float* w1, const float* b1, const float* w2,
                           const float* b2, float* y, int B, int C, int T, int K, int dil, float slope, int fused,
                           const int32_t* lens);
+/* a whole ResBlock1 with kernel size 3 -- three steps x = x + c2_s(lrelu(c1_s(lrelu(x)) + b1_s)) + b2_s, c1_s dilated by
+ * dils[s] (1, 3, 5 in every RVC v2 decoder), rvc/lib/algorithm/residuals.py:15-62 -- in ONE kernel (csrc/resblock3.hip; C = 32 /
+ * 64, T a multiple of 4).  w1 / w2 (3, C, C, 3), b1 / b2 (3, C) or NULL.  Bit-identical to three rvcx_op_resblock_pair calls. */
+int rvcx_op_resblock3(rvcx_ctx*, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                      float* y, int B, int C, int T, const int32_t* dils, float slope, const int32_t* lens);
 /* micro-benchmark of one ResBlock1 step on device-resident random data (fused kernel or the two launches) */
 int rvcx_bench_resblock_pair(rvcx_ctx*, int B, int C, int T, int K, int dil, int fused, int iters,
                              float* ms_per_launch);

@@ -85,7 +85,7 @@ SYMBOLS = [
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
     "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
     "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm", "rvcx_device_info",
-    "rvcx_flac_encode_bound", "rvcx_flac_encode_s16", "rvcx_flac_info", "rvcx_flac_decode_s32", "rvcx_flac_last_error",
+    "rvcx_op_resblock3", "rvcx_flac_encode_bound", "rvcx_flac_encode_s16", "rvcx_flac_info", "rvcx_flac_decode_s32", "rvcx_flac_last_error",
 ]
 
 
@@ -276,6 +276,19 @@ class Context:
         self._ck(lib().rvcx_op_resblock_pair(self._h, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), B, Cc, T, K, dil,
                                              C.c_float(slope), 1 if fused else 0, _p(li, C.c_int32)),
                  "op_resblock_pair")
+        return y
+
+    def resblock3(self, x, w1, b1, w2, b2, dils=(1, 3, 5), slope=0.1, lens=None):
+        """a whole k = 3 ResBlock1 (three steps) in one kernel; w1 / w2 (3, C, C, 3), b1 / b2 (3, C) or None"""
+        x, w1, w2 = f32(x), f32(w1), f32(w2)
+        B, Cc, T = x.shape
+        y = np.empty_like(x)
+        b1 = None if b1 is None else f32(b1)
+        b2 = None if b2 is None else f32(b2)
+        d = i32(list(dils))
+        li = i32(lens)
+        self._ck(lib().rvcx_op_resblock3(self._h, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), B, Cc, T, _p(d, C.c_int32),
+                                         C.c_float(slope), _p(li, C.c_int32)), "op_resblock3")
         return y
 
     def bench_resblock_pair(self, B, Cc, T, K, dil=1, fused=True, iters=10):
@@ -778,6 +791,8 @@ class Context:
                 return "gemm_f32<64,64> (time-major Linear, exact fp32)"
             if kd[i] >= 600000:
                 return f"gemm_h3<{bm[i]},{bn[i]}> (time-major Linear)"
+            if kd[i] == 500003:
+                return "resblock3 (whole k=3 ResBlock: three fused steps, persistent)"
             if kd[i] >= 500000:
                 return f"resblock_pair<C={kd[i] - 500000},N1={bn[i]}> (c1 -> c2 -> +x fused)"
             if kd[i] >= 400000:

@@ -434,6 +434,48 @@ int rvcx_op_resblock_pair(rvcx_ctx* ctx, const float* x, const float* w1, const 
   API_END
 }
 
+int rvcx_op_resblock3(rvcx_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                      float* y, int B, int Cc, int T, const int32_t* dils, float slope, const int32_t* lens) {
+  API_BEGIN(ctx)
+  TEMP_REGION(C);
+  const size_t n = (size_t)B * Cc * T, wn = (size_t)Cc * Cc * 3;
+  C->arena.reserve(n * 4 * 3 + (64 << 20));
+  C->arena.reset();
+  ConvW L1[3], L2[3];
+  for (int s = 0; s < 3; ++s) {
+    L1[s] = make_conv(*C, w1 + s * wn, b1 ? b1 + (size_t)s * Cc : nullptr, Cc, Cc, 3, 1, true);
+    L2[s] = make_conv(*C, w2 + s * wn, b2 ? b2 + (size_t)s * Cc : nullptr, Cc, Cc, 3, 1, true);
+  }
+  float* dx = to_dev(*C, x, n);
+  float* dy = C->arena.alloc<float>(n);
+  RVCX_HIP(hipMemsetAsync(dy, 0xff, n * 4, C->stream));      // NaN fill: every element must be written
+  const int* dl = to_dev_i(*C, lens, B);
+  Block3Args a;
+  a.x = dx;
+  a.y = dy;
+  for (int s = 0; s < 3; ++s) {
+    a.w1[s] = (L1[s].w_h3 && *L1[s].h3_ok) ? L1[s].w_h3 : nullptr;
+    a.w2[s] = (L2[s].w_h3 && *L2[s].h3_ok) ? L2[s].w_h3 : nullptr;
+    a.b1[s] = L1[s].bias;
+    a.b2[s] = L2[s].bias;
+    a.dil[s] = dils[s];
+  }
+  a.ovf_layer = L1[0].ovf_word;
+  a.lens = dl;
+  a.B = B;
+  a.C = Cc;
+  a.T = T;
+  a.bs = (long)Cc * T;
+  a.cs = T;
+  a.slope = slope;
+  a.any_shape = true;
+  if (!resblock3_ok(a)) fail("resblock3: shape not supported by the whole-block kernel");
+  C->block3_on(a, C->stream);
+  to_host(*C, y, dy, n);
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_bench_resblock_pair(rvcx_ctx* ctx, int B, int Cc, int T, int K, int dil, int fused, int iters,
                              float* ms_per_launch) {
   REQUIRE_DEBUG(ctx, "rvcx_bench_resblock_pair")

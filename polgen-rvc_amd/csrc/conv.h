@@ -53,8 +53,8 @@ struct ConvArgs {
   float acc2_div = 1.f;
   // OUT_SHUF1D only: the NSF noise conv of the stage (Conv1d(1, C, k = nz_k, stride nz_stride, padding nz_pad) over the
   // harmonic source, nsf.py:128-129) evaluated inside the epilogue instead of being read back as `res`: adds
-  // nz_b[c] + sum_j nz_w[j * nz_wstride + c] * har[t * nz_stride + j - nz_pad] to output (c, t).  Only the thin
-  // ConvTranspose1d kernel (convt_thin.hip) implements it; launch_conv refuses the fields elsewhere.
+  // nz_b[c] + sum_j nz_w[j * nz_wstride + c] * har[t * nz_stride + j - nz_pad] to output (c, t).  The thin ConvTranspose1d
+  // kernel (convt_thin.hip, nz_k <= 4) and the shuffle-store epilogues of the tiled kernels (conv_device.h) implement it.
   const float* nz_har = nullptr;   // (B, nz_len_row) harmonic source
   const float* nz_w = nullptr;     // packed Cin = 1 weights: tap j of channel c at nz_w[j * nz_wstride + c]
   const float* nz_b = nullptr;
@@ -106,6 +106,35 @@ struct PairArgs {
   int seq = 0;
   long long* trace = nullptr;    // profiling (rvcx_bench_resblock_pair, RVCX_PAIR_TRACE): 8 s_memrealtime stamps per workgroup
 };
+// A whole ResBlock1 with kernel size 3 (three steps, dilations dil[0..2]) in one kernel (resblock3.hip)
+struct Block3Args {
+  const float* x = nullptr;      // (B, C, T), batch stride bs, channel stride cs
+  float* y = nullptr;            // block output or null when only y2 is wanted
+  float* y2 = nullptr;           // running mean over the ResBlocks of a stage (acc2_mode)
+  const void* w1[3] = {nullptr, nullptr, nullptr};   // fp16 hi/lo images of convs1[s] / convs2[s]
+  const void* w2[3] = {nullptr, nullptr, nullptr};
+  const float* b1[3] = {nullptr, nullptr, nullptr};
+  const float* b2[3] = {nullptr, nullptr, nullptr};
+  int dil[3] = {1, 3, 5};
+  const int* lens = nullptr;
+  int B = 1, C = 0, T = 0;
+  long bs = 0;
+  int cs = 0;
+  float slope = 0.1f;
+  int acc2_mode = ACC2_NONE;
+  float acc2_div = 1.f;
+  int xcd_order = 1;
+  bool any_shape = false;        // kernel-level tests: every shape the kernel supports, not only the ones the pipeline sends it
+  int* ovf = nullptr;
+  int* ovf_layer = nullptr;
+  int seq = 0;
+};
+bool resblock3_ok(const Block3Args& a);
+void launch_resblock3(const Block3Args& a, hipStream_t stream);
+void conv_launch_block3(const Block3Args& a, double flops, hipStream_t stream);   // + profile record (conv.hip)
+int resblock3_n1(int C);
+constexpr int kBlock3Slot = 62;
+
 // fp16 hi/lo split kernels hold activations as fp16 halves: |x| >= 65504 (attention K / V: >= 255) would become
 // inf.  Every split kernel checks what it converts, raises bit 1 of the context's device error word and stamps its
 // layer's own word with the launch sequence number.  The API entry point then pins the FIRST offending layer of the

@@ -196,6 +196,9 @@ void conv_profile_end(ConvProfile* out) {
   conv_fast_describe(out);
   conv_h3_describe(out);
   resblock_pair_describe(out);
+  out->bm[kBlock3Slot] = 64;
+  out->bn[kBlock3Slot] = resblock3_n1(64);
+  out->halo[kBlock3Slot] = 500003;
   gemm_describe(out);
   for (auto& r : g_prof) {
     RVCX_HIP(hipEventSynchronize(r.b));
@@ -227,6 +230,23 @@ void conv_launch_pair(const PairArgs& a, double flops, hipStream_t stream) {
   rec.cin = a.C; rec.cout = a.C; rec.k = a.k; rec.nout = a.T; rec.stride = a.dil; rec.B = a.B;
   RVCX_HIP(hipEventRecord(rec.a, stream));
   launch_resblock_pair(a, stream);
+  RVCX_HIP(hipEventRecord(rec.b, stream));
+  g_prof.push_back(rec);
+}
+
+void conv_launch_block3(const Block3Args& a, double flops, hipStream_t stream) {
+  if (!g_prof_on) {
+    launch_resblock3(a, stream);
+    return;
+  }
+  ProfRec rec;
+  RVCX_HIP(hipEventCreate(&rec.a));
+  RVCX_HIP(hipEventCreate(&rec.b));
+  rec.tile = kBlock3Slot;
+  rec.flops = flops;
+  rec.cin = a.C; rec.cout = a.C; rec.k = 3; rec.nout = a.T; rec.stride = 135; rec.B = a.B;
+  RVCX_HIP(hipEventRecord(rec.a, stream));
+  launch_resblock3(a, stream);
   RVCX_HIP(hipEventRecord(rec.b, stream));
   g_prof.push_back(rec);
 }

@@ -24,6 +24,21 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 
+// The stage's NSF noise conv evaluated in place of a residual read (ConvArgs::nz_*): Conv1d(1, C, k, stride, padding) of the
+// harmonic source at output (c, t), the conv_cin1 kernel's arithmetic (FMA chain over ascending taps, then the bias).
+__device__ __forceinline__ float noise_conv_at(const ConvArgs& a, int b, int c, int t) {
+  const int nz_len = a.nz_lens ? a.nz_lens[b] : a.nz_len;
+  const float* hb = a.nz_har + (long)b * a.nz_bs;
+  const long p0 = (long)t * a.nz_stride - a.nz_pad;
+  float n = 0.f;
+  for (int j = 0; j < a.nz_k; ++j) {
+    const long p = p0 + j;
+    const float hvv = (p >= 0 && p < nz_len) ? hb[p] : 0.f;
+    n = fmaf(a.nz_w[(long)j * a.nz_wstride + c], hvv, n);
+  }
+  return n + (a.nz_b ? a.nz_b[c] : 0.f);
+}
+
 // one output element: bias -> activation -> residual -> length mask -> store (by output mode)
 __device__ __forceinline__ void store_elem(const ConvArgs& a, int b, int cg, int nn, float v, int len_out) {
   if (a.bias) v += a.bias[cg];
@@ -47,6 +62,7 @@ __device__ __forceinline__ void store_elem(const ConvArgs& a, int b, int cg, int
     const int t = nn * a.sh_s + ph - a.sh_pad;
     if (t >= 0 && t < a.sh_tout) {
       if (a.res) v += a.res[(long)b * a.res_bs + (long)c * a.res_cs + t];
+      if (a.nz_har) v += noise_conv_at(a, b, c, t);
       if (t >= len_out) v = 0.f;
       a.y[(long)b * a.y_bs + (long)c * a.y_cs + t] = v;
     }
@@ -177,6 +193,7 @@ __device__ __forceinline__ void store_tile_shuf1d(const ConvArgs& a, int b, int 
       ok[q] = cg0 + q < a.Cout_g && tt[q] >= 0 && tt[q] < a.sh_tout;
       bv[q] = (a.bias && cg0 + q < a.Cout_g) ? a.bias[cg0 + q] : 0.f;
       rv[q] = (rb && ok[q]) ? rb[(long)c * a.res_cs + tt[q]] : 0.f;
+      if (a.nz_har && ok[q]) rv[q] += noise_conv_at(a, b, c, tt[q]);
       if (++ph == s) {
         ph = 0;
         ++c;

@@ -503,7 +503,7 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     launch_convt_thin(a, stream);
     return kConvtThinSlot;
   }
-  RVCX_CHECK(!a.nz_har, "conv: a fused noise conv needs the thin ConvTranspose1d kernel (convt_thin.hip)");
+  RVCX_CHECK(!a.nz_har || a.out_mode == OUT_SHUF1D, "conv: a fused noise conv needs a polyphase ConvTranspose1d launch");
   if (conv_cout1_ok(a)) {
     static const bool on = !getenv("RVCX_COUT1") || atoi(getenv("RVCX_COUT1")) != 0;
     if (on) {

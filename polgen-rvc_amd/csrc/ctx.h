@@ -231,6 +231,14 @@ struct Ctx {
     b.seq = ++launch_seq;
     conv_launch_pair(b, f, s);
   }
+  void block3_on(const Block3Args& a, hipStream_t s) {
+    const double f = 3.0 * 2.0 * 2.0 * a.B * (double)a.C * a.C * 3 * a.T;   // three steps of two convs, 2 M N K each
+    flops += f;
+    Block3Args b = a;
+    b.ovf = dev_err;
+    b.seq = ++launch_seq;
+    conv_launch_block3(b, f, s);
+  }
   void gemm_on(GemmArgs a, hipStream_t s) {
     const double f = 2.0 * (double)a.rows * a.cout * a.cin;
     flops += f;

@@ -1652,12 +1652,18 @@ const PairCfg kPair[] = {
     // memory loads return IN ORDER, so the weight fetch of the next stage waits behind the ~5 us HBM round trip of the input tile.
     make_persist<32, 16, 1, 8, 3, 3, 2, false>(),  make_persist<32, 16, 1, 8, 7, 7, 1, false>(),  make_persist<32, 16, 1, 8, 11, 11, 1, false>(),
     make_persist<64, 8, 2, 4, 3, 3, 2, false>(),   make_persist<64, 8, 2, 4, 7, 7, 1, false>(),   make_persist<64, 8, 2, 4, 11, 11, 1, false>(),
-    make_persist<128, 6, 4, 3, 3, 3, 1, false>(),  make_persist<128, 4, 4, 2, 7, 7, 1, false>(),
+    // C = 128: k = 3 on 768 threads (12 waves of 32 x 64); k = 7 and k = 11 on 512 threads with N1 = 192 -- eight waves of 32 x 96
+    // (WN = 3: eight fragment reads per nine product blocks), 220-235 registers: -6 ... -10 % / -3.5 % against the forms above them
+    make_persist<128, 6, 4, 3, 3, 3, 1, false>(),  make_persist<128, 6, 4, 2, 7, 4, 1, false>(),  make_persist<128, 6, 4, 2, 11, 4, 1, false>(),
     // A/B forms: 11 = EARLY requests; C = 128, k = 11 on 768 threads.  12 = C = 128, k = 11 / k = 3 on 512 threads, N1 = 128
     make_persist<32, 16, 1, 8, 3, 3, 2, true, 11>(),  make_persist<32, 16, 1, 8, 7, 7, 1, true, 11>(),  make_persist<32, 16, 1, 8, 11, 11, 1, true, 11>(),
     make_persist<64, 8, 2, 4, 3, 3, 2, true, 11>(),   make_persist<64, 8, 2, 4, 7, 7, 1, true, 11>(),   make_persist<64, 8, 2, 4, 11, 11, 1, true, 11>(),
-    make_persist<128, 6, 4, 3, 11, 4, 1, false, 11>(),  make_persist<128, 4, 4, 2, 7, 7, 1, true, 11>(),
+    make_persist<128, 6, 4, 3, 11, 4, 1, false, 11>(),  make_persist<128, 4, 4, 2, 7, 7, 1, false, 11>(),
     make_persist<128, 4, 4, 2, 11, 4, 1, false, 12>(),  make_persist<128, 4, 4, 2, 3, 3, 1, false, 12>(),
+    // variant 13 / 14 (round 5 A/B): C = 128 on 512 threads with N1 = 192 -- eight waves of 32 x 96 (WN = 3: eight fragment reads per
+    // nine product blocks, 256 registers per lane), persistent (13) and per-tile (14)
+    make_persist<128, 6, 4, 2, 3, 3, 1, false, 13>(),
+    make_cfg<128, 6, 4, 2, 3, 3, 1, 14, false, 3>(),  make_cfg<128, 6, 4, 2, 7, 4, 1, 14, false, 3>(),  make_cfg<128, 6, 4, 2, 11, 4, 1, 14, false, 3>(),
     // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
     make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
     make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),

@@ -223,8 +223,13 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     probe.pre_act = ACT_LRELU;
     probe.pre_slope = 0.1f;
     static const bool fuse_on = !getenv("RVCX_NOISE_FUSE") || atoi(getenv("RVCX_NOISE_FUSE")) != 0;
-    nz_fused[i] = fuse_on && S.noise.cin == 1 && S.noise.groups == 1 && S.noise.k >= 1 && S.noise.k <= 4 && S.noise.cout == S.ch &&
-                  convt_thin_ok(probe);
+    // k <= 4: the two last stages, on the streaming kernel.  The shuffle-store epilogues of the tiled kernels implement the
+    // fused taps too (RVCX_NOISE_FUSE_K=8 sends stage 1's 8-tap noise conv there), but measured it is a loss: 436 -> 1132 us
+    // for that launch -- eight dependent source loads per output element in an epilogue that was already store-bound
+    static const int fuse_max_k = getenv("RVCX_NOISE_FUSE_K") ? atoi(getenv("RVCX_NOISE_FUSE_K")) : 4;
+    nz_fused[i] = fuse_on && S.noise.cin == 1 && S.noise.groups == 1 && S.noise.k >= 1 && S.noise.cout == S.ch &&
+                  S.noise.k <= fuse_max_k;       // every ConvTranspose1d path implements the fused taps (conv_device.h, convt_thin.hip)
+    (void)probe;
   }
   {
     hipStream_t sn = c.serial ? s : c.aux[0];
@@ -429,6 +434,40 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
         const float* xin = xu;
         float* xc = xcb[j];
         float* xt = xtb[j];
+        // ---- the whole block in one kernel (resblock3.hip): kernel size 3 at C = 32 / 64 -- read x once, write the block's output once
+        if (k == 3) {
+          Block3Args ba;
+          ba.x = xu;
+          ba.y = nullptr;
+          ba.y2 = xs;
+          bool ok3 = true;
+          for (int mi = 0; mi < 3; ++mi) {
+            const auto &L1 = S.c1[j][mi], &L2 = S.c2[j][mi];
+            ba.w1[mi] = (L1.w_h3 && L1.h3_ok && *L1.h3_ok) ? L1.w_h3 : nullptr;
+            ba.w2[mi] = (L2.w_h3 && L2.h3_ok && *L2.h3_ok) ? L2.w_h3 : nullptr;
+            ba.b1[mi] = L1.bias;
+            ba.b2[mi] = L2.bias;
+            ba.dil[mi] = cf.res_dilations[j][mi];
+            ok3 = ok3 && L1.cin == S.ch && L1.cout == S.ch && L1.k == 3 && L2.cin == S.ch && L2.cout == S.ch && L2.k == 3;
+          }
+          ba.ovf_layer = S.c1[j][0].ovf_word;
+          ba.lens = lout;
+          ba.B = db;
+          ba.C = S.ch;
+          ba.T = (int)Tout;
+          ba.bs = (long)S.ch * Tout;
+          ba.cs = (int)Tout;
+          ba.slope = 0.1f;
+          ba.acc2_mode = j == 0 ? ACC2_SET : (j == nk - 1 ? ACC2_ADD_DIV : ACC2_ADD);
+          ba.acc2_div = (float)nk;
+          if (nk == 1) ba.acc2_mode = ACC2_SET;
+          if (ok3 && resblock3_ok(ba)) {
+            if (j > 0) RVCX_HIP(hipStreamWaitEvent(sj, c.ev_aux[j], 0));   // xs of block j-1 is complete
+            c.block3_on(ba, sj);
+            RVCX_HIP(hipEventRecord(c.ev_aux[j + 1], sj));
+            continue;
+          }
+        }
         for (int mi = 0; mi < 3; ++mi) {
           const int d = cf.res_dilations[j][mi];
           // ---- fused step (resblock.hip): c1 -> c2 -> + x in one kernel, xt never leaves the CU

@@ -166,3 +166,26 @@ def test_hubert_with_planted_outlier_units_pins_exactly_the_two_attention_layers
         assert c.fp32_reruns() - r0 == 2 and c.fp32_layers() == 2 and np.array_equal(again, got)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("C,T,B", [(32, 5000, 1), (32, 488 * 3, 1), (32, 100, 1), (64, 4100, 1), (64, 168 * 2 + 4, 2), (32, 2048, 3)])
+def test_resblock3_equals_three_fused_steps(ctx, C, T, B):
+    """the three dilation steps (d = 1, 3, 5) of a kernel-size-3 ResBlock1 (residuals.py:15-62) in ONE
+    kernel (csrc/resblock3.hip) -- bit-identical to three launches of the fused single step (and so to the six conv
+    launches), with per-item lengths, for tiles at both ends of the sequence and sequences shorter than one tile."""
+    g = np.random.Generator(np.random.PCG64(C * 7 + T))
+    x = g.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (g.standard_normal((3, C, C, 3)) / np.sqrt(3 * C)).astype(np.float32)
+    w2 = (g.standard_normal((3, C, C, 3)) / np.sqrt(3 * C)).astype(np.float32)
+    b1 = (0.1 * g.standard_normal((3, C))).astype(np.float32)
+    b2 = (0.1 * g.standard_normal((3, C))).astype(np.float32)
+    lens = None if B == 1 else np.array([T - 4 * (7 * i + 3) for i in range(B)], np.int32)
+    ref = x
+    for s, d in enumerate((1, 3, 5)):
+        ref = ctx.resblock_pair(ref, w1[s], b1[s], w2[s], b2[s], dil=d, slope=0.1, fused=True, lens=lens)
+    got = ctx.resblock3(x, w1, b1, w2, b2, dils=(1, 3, 5), slope=0.1, lens=lens)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max():.3e}"
+    if lens is not None:
+        for i, n in enumerate(lens):
+            assert not got[i, :, n:].any() and got[i, :, :n].any()
