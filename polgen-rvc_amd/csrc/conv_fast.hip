@@ -312,8 +312,9 @@ __global__ void conv_splitk_finish_kernel(const ConvArgs a) {
   }
 }
 
-// Cin = 1 convolutions (NSF noise convs k = 2*stride, HuBERT conv0 k10 s5): an FIR per output channel,
-// bound by the output write -- plain vector FMAs, 16 output channels per thread, weights broadcast from LDS.
+// Cin = 1 convolutions (NSF noise convs k = 2*stride, HuBERT conv0 k10 s5; round 5: the RMVPE U-Net's first 3 x 3 conv on
+// the row-padded mel map, taps (kk / kw) rowpitch + (kk % kw) dil): an FIR per output channel, bound by the output write --
+// plain vector FMAs, 16 output channels per thread, weights broadcast from LDS.
 constexpr int kCin1MaxK = 192;
 __global__ __launch_bounds__(256) void conv_cin1_kernel(const ConvArgs a) {
   __shared__ float ws[kCin1MaxK * 16];
@@ -330,13 +331,14 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const ConvArgs a) {
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
   const float* xb = a.x + (long)b * a.x_bs;
   const int p0 = nn * a.stride - a.pad;
+  const int kw = a.kw, rowpitch = a.rowpitch;
   float acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
   const int last = max(len_in - 1, 0);
 #pragma unroll 4
   for (int kk = 0; kk < K; ++kk) {
-    const int pos = p0 + kk * a.dil;
+    const int pos = kw == K ? p0 + kk * a.dil : p0 + (kk / kw) * rowpitch + (kk % kw) * a.dil;
     float xv = xb[min(max(pos, 0), last)];                 // always in range: no branch around the load
     xv = (pos >= 0 && pos < len_in) ? xv : 0.f;
     if (a.pre_act == ACT_LRELU) xv = xv > 0.f ? xv : xv * a.pre_slope;
@@ -494,7 +496,7 @@ void launch_splitk_finish(const ConvArgs& a, hipStream_t stream) {
 }
 
 int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
-  if (a.Cin_g == 1 && a.groups == 1 && a.kw == a.ksize && a.ksize <= kCin1MaxK) {
+  if (a.Cin_g == 1 && a.groups == 1 && a.ksize <= kCin1MaxK && a.kw >= 1 && a.ksize % a.kw == 0) {
     hipLaunchKernelGGL(conv_cin1_kernel, dim3(cdiv(a.Nout, 256), cdiv(a.Cout_g, 16), a.B), dim3(256), 0, stream, a);
     RVCX_HIP(hipGetLastError());
     return 7;
