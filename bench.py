@@ -50,7 +50,7 @@ C3_BATCH = 64
 C3_INDEX_ROWS = 65536
 C5_UTTERANCES = 256
 CPU_SAMPLE_SECONDS = 30.0    # the clip the metric is quoted on (attention is O(T^2): a shorter sample would flatter the CPU)
-PMC_FILES = ("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json")     # newest first
+PMC_FILES = ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json")     # newest first
 WORKER_DEADLINE_S = 3600.0   # launch_workers: the whole multi-rank run
 PEAK_FILE = "mfma_peak_r04.json"   # profiles/: measured split-fp16 ceiling on random operands (tools/mfma_peak.hip)
 
@@ -150,10 +150,10 @@ def pmc_traffic(tile_name):
     src = f"{rel} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, RVCX_SERIAL=1)"
     mp = re.match(r"resblock_pair<C=(\d+),N1=(\d+)>", tile_name)
     if mp:
-        want = f"resblock_pair_kernel<{mp.group(1)},"
+        want = (f"resblock_pair_kernel<{mp.group(1)},", f"resblock_pair_persist_kernel<{mp.group(1)},")
         tot_b, tot_n = 0.0, 0
         for k, v in kernels.items():          # the (C, k) instantiations of one channel count share the profile slot
-            if want in k:
+            if want[0] in k or want[1] in k:
                 tot_b += v["hbm_bytes_per_launch"] * v["launches"]
                 tot_n += v["launches"]
         return (tot_b / tot_n, src) if tot_n else (None, None)
