@@ -800,6 +800,8 @@ class Context:
                 return f"conv_h3<{bm[i]},{bn[i]},{'linear' if c == 1 else 'stride2' if c == 2 else 'halo%d' % c}>"
             if kd[i] == 300001:
                 return "conv_cout1 (vector FMA, Cout=1)"
+            if kd[i] == 300003:
+                return "conv_deep<64,32> (long K, few positions: split-K inside the workgroup)"
             if kd[i] == 300002:
                 return "convt_thin (ConvTranspose1d k4 s2, streaming MFMA + fused noise conv)"
             if kd[i] >= 300000:

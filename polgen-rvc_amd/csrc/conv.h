@@ -173,6 +173,9 @@ bool convt_thin_ok(const ConvArgs& a);                       // ConvTranspose1d(
 void launch_convt_thin(const ConvArgs& a, hipStream_t stream);
 void convt_thin_init();
 constexpr int kConvtThinSlot = 61;
+bool conv_deep_ok(const ConvArgs& a);                        // long K, few positions per item: split-K inside the workgroup (conv_deep.hip)
+void launch_conv_deep(const ConvArgs& a, hipStream_t stream);
+constexpr int kConvDeepSlot = 63;
 bool conv_h3_enabled();      // RVCX_H3 on and the calling thread is not in an exact-fp32 rerun
 bool conv_h3_configured();   // RVCX_H3 on (what checkpoint loading looks at)
 bool conv_h3_split_ok(const ConvArgs& a);   // may this launch read / write pre-split activations?

@@ -481,6 +481,9 @@ void conv_fast_describe(ConvProfile* p) {
   p->bm[kConvtThinSlot] = 128;
   p->bn[kConvtThinSlot] = 32;
   p->halo[kConvtThinSlot] = 300002;   // convt_thin_kernel
+  p->bm[kConvDeepSlot] = 64;
+  p->bn[kConvDeepSlot] = 32;
+  p->halo[kConvDeepSlot] = 300003;    // conv_deep_kernel
   for (int t = 0; t < kNumFast; ++t) {
     const int s = 8 + t;
     p->bm[s] = kFast[t].bm;
@@ -525,6 +528,10 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     off_max = std::max(off_max, o);
   }
   const int halo = off_max - off_min;
+  if (conv_deep_ok(a)) {
+    launch_conv_deep(a, stream);
+    return kConvDeepSlot;
+  }
   {
     const int slot = launch_conv_h3(a, halo, off_min, stream);
     if (slot >= 0) return slot;

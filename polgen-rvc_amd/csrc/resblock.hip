@@ -1570,6 +1570,7 @@ struct PairCfg {
   size_t lds;
   void (*kern)(const PairArgs);
   bool persist = false;          // one workgroup per CU walks a range of tiles (grid = CUs, not tiles)
+  int per_cu = 1;                // persistent workgroups per CU (small tiles: two, so that one's VALU phases meet the other's loops)
 };
 template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, int V = 0, bool TRIM = false, int RESPF = 0, bool OVL = false>
 constexpr PairCfg make_cfg() {
@@ -1579,12 +1580,12 @@ constexpr PairCfg make_cfg() {
           (OVL ? (y1 > bs ? y1 : bs) + as : y1 + as + bs) * 16,
           resblock_pair_kernel<C, NT, WR, WC, K, KKT, NCS, TRIM, RESPF, OVL>};
 }
-template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool EARLY = true, int V = 10>
+template <int C, int NT, int WR, int WC, int K, int KKT, int NCS, bool EARLY = true, int V = 10, int PER_CU = 1>
 constexpr PairCfg make_persist() {
   constexpr size_t y1 = (size_t)(C / 16) * 4 * (32 * NT + kPairPadY), as = (size_t)NCS * KKT * 4 * C,
                    bs = (size_t)NCS * 4 * (32 * NT + kPairHalo);
   return {C, K, 32 * NT, 64 * WR * WC, V, (32 * NT - (K - 1)) & ~3, true, (y1 + as + bs) * 16 + 2 * C * 4,
-          resblock_pair_persist_kernel<C, NT, WR, WC, K, KKT, NCS, EARLY>, true};
+          resblock_pair_persist_kernel<C, NT, WR, WC, K, KKT, NCS, EARLY>, true, PER_CU};
 }
 template <int C, int NT, int WR, int WC, int K, int G, int V, bool OVL = false>
 constexpr PairCfg make_adir() {
@@ -1660,6 +1661,9 @@ const PairCfg kPair[] = {
     make_persist<64, 8, 2, 4, 3, 3, 2, true, 11>(),   make_persist<64, 8, 2, 4, 7, 7, 1, true, 11>(),   make_persist<64, 8, 2, 4, 11, 11, 1, true, 11>(),
     make_persist<128, 6, 4, 3, 11, 4, 1, false, 11>(),  make_persist<128, 4, 4, 2, 7, 7, 1, false, 11>(),
     make_persist<128, 4, 4, 2, 11, 4, 1, false, 12>(),  make_persist<128, 4, 4, 2, 3, 3, 1, false, 12>(),
+    // variant 15 (round 5 A/B): persistent AND two workgroups per CU -- half-width tiles on four waves (<= 80 KB of LDS each)
+    make_persist<32, 8, 1, 4, 3, 3, 2, false, 15, 2>(),  make_persist<32, 8, 1, 4, 7, 7, 1, false, 15, 2>(),  make_persist<32, 8, 1, 4, 11, 11, 1, false, 15, 2>(),
+    make_persist<64, 4, 2, 2, 3, 3, 2, false, 15, 2>(),  make_persist<64, 4, 2, 2, 7, 7, 1, false, 15, 2>(),  make_persist<64, 4, 2, 2, 11, 4, 1, false, 15, 2>(),
     // variant 13 / 14 (round 5 A/B): C = 128 on 512 threads with N1 = 192 -- eight waves of 32 x 96 (WN = 3: eight fragment reads per
     // nine product blocks, 256 registers per lane), persistent (13) and per-tile (14)
     make_persist<128, 6, 4, 2, 3, 3, 1, false, 13>(),
@@ -1747,7 +1751,7 @@ void launch_resblock_pair(const PairArgs& a, hipStream_t stream) {
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
       return std::max(8, n);
     }();
-    grid.x = std::min<unsigned>(grid.x, (unsigned)ncu);
+    grid.x = std::min<unsigned>(grid.x, (unsigned)(ncu * c.per_cu));
   }
   static const int xcd = getenv("RVCX_PAIR_XCD") ? atoi(getenv("RVCX_PAIR_XCD")) : 1;
   PairArgs b = a;

@@ -68,3 +68,11 @@ def test_bigru_forms_and_the_cross_xcd_hand_off_pass_the_f0_goldens(env):
 def test_fp32_hand_off_between_layers_passes_the_hubert_and_f0_goldens():
     """RVCX_NO_SPLIT=1: no pre-split fp16 hand-off (HuBERT extractor, U-Net blocks): consumers convert fp32 themselves."""
     _run_mode({"RVCX_NO_SPLIT": "1"}, "test_gpu_rmvpe_hubert.py", "hubert or rmvpe", "passed")
+
+
+def test_in_workgroup_split_k_convs_pass_the_f0_goldens():
+    """RVCX_CONV_DEEP=1: the deep U-Net levels (3 x 3 convs and the 2 x 2 polyphase ConvTranspose2d with 128 - 512 channels on
+    <= 8192 positions) on conv_deep_kernel -- the waves of a workgroup split K, partial tiles meet in LDS, no finish launch
+    (csrc/conv_deep.hip; off by default: measured no faster).  Same goldens, kernel-level conv tests included."""
+    _run_mode({"RVCX_CONV_DEEP": "1"}, "test_gpu_rmvpe_hubert.py", "rmvpe", "passed")
+    _run_mode({"RVCX_CONV_DEEP": "1"}, "test_gpu_conv.py", "conv2d3x3 or convtranspose2d", "passed")
