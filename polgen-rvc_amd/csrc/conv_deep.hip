@@ -27,7 +27,9 @@ namespace rvcx {
 namespace {
 
 // W waves; kG k-steps per request; MB 32-row blocks of output channels per workgroup (tile 32 MB x 32)
-template <int W, int kG, int MB>
+// DB: double-buffered requests (one group in flight while one is computed); false: request a group of kG steps, wait, compute it
+// -- a wave then pays one operand round trip per kG steps, and the other waves of the CU fill its wait
+template <int W, int kG, int MB, bool DB = true>
 __global__ __launch_bounds__(64 * W) void conv_deep_kernel(const ConvArgs a) {
   extern __shared__ float red[];                  // [W][MB][16][64] partial accumulators
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,8 +55,8 @@ __global__ __launch_bounds__(64 * W) void conv_deep_kernel(const ConvArgs a) {
   constexpr float inv = 1.f / kH3Scale;
   bool ovf = false;
 
-  float rawb[2][kG][8];
-  uint4 rawa[2][kG][MB][2];                       // [buf][step][m][op]
+  float rawb[DB ? 2 : 1][kG][8];
+  uint4 rawa[DB ? 2 : 1][kG][MB][2];              // [buf][step][m][op]
   // requests are issued for consecutive steps: (chunk, tap row, tap column) of the next step to request are counters
   int rs = s_begin, rchunk = s_begin / a.ksize, rkk = s_begin - rchunk * a.ksize, rky = rkk / a.kw, rkx = rkk - rky * a.kw;
   auto request = [&](auto buf_tag) {
@@ -120,12 +122,19 @@ __global__ __launch_bounds__(64 * W) void conv_deep_kernel(const ConvArgs a) {
   using B1 = std::integral_constant<int, 1>;
   // groups of kG steps, double-buffered: request the next group, compute the current one ("everything but the request
   // just issued": the wait the compiler can count); steps past the wave's range load nothing and add zeros
-  request(B0{});
-  for (int s = s_begin; s < s_end; s += 2 * kG) {
-    request(B1{});
-    compute(B0{});
+  if constexpr (DB) {
     request(B0{});
-    compute(B1{});
+    for (int s = s_begin; s < s_end; s += 2 * kG) {
+      request(B1{});
+      compute(B0{});
+      request(B0{});
+      compute(B1{});
+    }
+  } else {
+    for (int s = s_begin; s < s_end; s += kG) {
+      request(B0{});
+      compute(B0{});
+    }
   }
   if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
   // ---- the W partial tiles meet in LDS
@@ -151,8 +160,11 @@ __global__ __launch_bounds__(64 * W) void conv_deep_kernel(const ConvArgs a) {
 bool conv_deep_ok(const ConvArgs& a) {
   // OFF by default: measured (round 5, tools/bench_deep.py and the C2 bench, one box) it does not break the floor it was
   // built against -- 512 -> 512 on 624 positions 41 -> 48 us, 256 -> 256 on 2080 31 -> 24, 128 -> 128 on 7488 33 -> 31; F0 stage
-  // 8.46 -> 8.61 ms.  A wave's chain of 9 - 18 dependent operand round trips costs what the tile kernel's stage chain plus its
-  // finish launch cost.  RVCX_CONV_DEEP=1 turns it on (tests/test_gpu_modes.py keeps it correct).
+  // 8.46 -> 8.61 ms.  Cutting the dependent round trips per wave from 18 to 3 (forms 2 / 3: six or four k-steps per request)
+  // made it SLOWER (59 / 37 / 30 us), which names the real bound: L2 -> CU operand traffic.  With N = 624 positions no tiling
+  // has both enough workgroups and enough reuse -- a 64 x 32 tile without LDS sharing re-reads 2 x 590 KB of operands per
+  // workgroup (380 MB per conv), the 64 x 64 LDS tile 190 MB: 20 - 40 us at the ~10 TB/s the L2s deliver, whatever the schedule.
+  // RVCX_CONV_DEEP=1 turns it on (tests/test_gpu_modes.py keeps it correct).
   static const bool on = getenv("RVCX_CONV_DEEP") && atoi(getenv("RVCX_CONV_DEEP")) != 0;
   static const int max_n = getenv("RVCX_CONV_DEEP_N") ? atoi(getenv("RVCX_CONV_DEEP_N")) : 8192;
   if (!on || !a.w_h3 || !conv_h3_enabled()) return false;
@@ -180,6 +192,12 @@ void launch_conv_deep(const ConvArgs& a, hipStream_t stream) {
                                    16 * 1 * 16 * 64 * 4));
       RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    8 * 2 * 16 * 64 * 4));
+      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<16, 6, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   16 * 1 * 16 * 64 * 4));
+      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<16, 4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   16 * 1 * 16 * 64 * 4));
+      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<8, 5, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   8 * 1 * 16 * 64 * 4));
       done |= 1ull << (dev & 63);
     }
   }
@@ -187,7 +205,12 @@ void launch_conv_deep(const ConvArgs& a, hipStream_t stream) {
   dim3 grid(cdiv(a.Nout, 32), a.Cout_gp / 64, a.B);
   static const int form = getenv("RVCX_CONV_DEEP_FORM") ? atoi(getenv("RVCX_CONV_DEEP_FORM")) : 0;
   // 16 waves when every wave still gets >= 8 k-steps, else 8 (a function of the layer's shape only)
-  if (KS >= 128 && form == 1) {          // 32 x 32 tiles: twice the workgroups (the 512-channel level: 320 instead of 160), two steps per request
+  if (form == 2 || form == 3) {             // batch requests: 6 (or 4) steps per round trip, 32 x 32 tiles
+    grid.y = a.Cout_gp / 32;
+    if (KS < 128) hipLaunchKernelGGL((conv_deep_kernel<8, 5, 1, false>), grid, dim3(512), 8 * 1 * 16 * 64 * 4, stream, a);
+    else if (form == 2) hipLaunchKernelGGL((conv_deep_kernel<16, 6, 1, false>), grid, dim3(1024), 16 * 1 * 16 * 64 * 4, stream, a);
+    else hipLaunchKernelGGL((conv_deep_kernel<16, 4, 1, false>), grid, dim3(1024), 16 * 1 * 16 * 64 * 4, stream, a);
+  } else if (KS >= 128 && form == 1) {          // 32 x 32 tiles: twice the workgroups (the 512-channel level: 320 instead of 160), two steps per request
     grid.y = a.Cout_gp / 32;
     hipLaunchKernelGGL((conv_deep_kernel<16, 2, 1>), grid, dim3(1024), 16 * 1 * 16 * 64 * 4, stream, a);
   } else if (KS >= 128) {
