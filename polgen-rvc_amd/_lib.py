@@ -122,8 +122,19 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_device_info_cache = {}
+
+
 def device_info(device: int = 0):
-    """(name, total bytes) of GPU `device`, or (None, None) when no HIP device is visible"""
+    """(name, total bytes) of GPU `device`, or (None, None) when no HIP device is visible (asked once per device: Config()
+    is built per request by the reference's callers)"""
+    if device in _device_info_cache:
+        return _device_info_cache[device]
+    _device_info_cache[device] = _device_info(device)
+    return _device_info_cache[device]
+
+
+def _device_info(device: int = 0):
     name = C.create_string_buffer(256)
     total = C.c_int64(0)
     if lib().rvcx_device_info(int(device), name, 256, C.byref(total)) != 0:

@@ -259,6 +259,65 @@ def test_resident_asset_cache_is_keyed_by_path_and_mtime(tmp_path, monkeypatch):
     I.clear_cache()
 
 
+def test_mirror_holds_the_context_lock_around_a_request_sequence(tmp_path, monkeypatch):
+    """VERDICT r4 item 3, the host half (no GPU needed): VC.pipeline is a SEQUENCE of calls on the shared context -- make the
+    request's index resident, then convert with it.  Two threads with two different index files on one (fake) context: the
+    per-context lock the mirror holds (infer/pipeline.py: _with_ctx_lock) must keep every convert paired with its own
+    thread's index, however the scheduler interleaves them; the loaders take context lock then table lock in that order."""
+    import threading
+    import time
+    from polgen_rvc_amd.infer import infer as I, pipeline as P, _state
+
+    class Ctx(_FakeCtx):
+        def __init__(self):
+            super().__init__()
+            self.resident, self.pairs, self.rmvpe_loaded = None, [], True
+            self.busy = 0
+            self.overlap = False
+
+        def load_index(self, big):
+            self.resident = None if big is None else float(big[0, 0])
+            time.sleep(0.002)                       # a window for the other thread to slip in
+
+        def convert_batch(self, model_id, clips, p, noise, want_f32=False, inp_f0=None, crepe_dither=None):
+            self.busy += 1
+            self.overlap |= self.busy > 1
+            time.sleep(0.001)
+            self.pairs.append((float(clips[0][0]), self.resident, p.index_rate))
+            self.busy -= 1
+            return [np.zeros(4, np.int16)]
+
+    ctx = Ctx()
+    monkeypatch.setitem(_state._CTX, 0, ctx)
+    monkeypatch.setattr(_state, "_INDEX_RESIDENT", {})
+    monkeypatch.setattr(P, "_INDEX_RESIDENT", _state._INDEX_RESIDENT)
+    net_g, hub = I.SynthHandle(ctx, 0, []), I.HubertHandle(ctx, {})
+    net_g.__class__.__del__ = lambda self: None
+    paths = []
+    for k in range(2):
+        path = tmp_path / f"idx{k}.npy"
+        np.save(path, np.full((16, 8), float(k + 1), np.float32))
+        paths.append(str(path))
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(25):
+                vc = P.VC(4800, I.Config())
+                vc.pipeline(hub, net_g, 0, np.full(100, float(k + 1)), "x.wav", 0.0, "rmvpe+", paths[k], 0.5, 1, 3, 4800, 0,
+                            1.0, "v2", 0.33, 128, None)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert len(ctx.pairs) == 50 and not ctx.overlap
+    assert all(clip == resident and rate == 0.5 for clip, resident, rate in ctx.pairs), ctx.pairs[:6]
+
+
 def test_load_audio_and_convert_to_stereo_host_side(tmp_path):
     """my_utils.py:5-16 / voice_conversion.py:45-51 without a rate change (the resampler itself is a GPU kernel:
     tests/test_gpu_audio.py): PCM scaling, mono mean, mono -> stereo doubling at the ORIGINAL rate, PCM_16 output, and a
