@@ -1,4 +1,6 @@
-"""Round 5 (GPU): the shared context under threads, the fast-path counters."""
+"""Round 5 (GPU): the shared context under threads; the Cout = 1 kernel of conv_post against torch; HuBERT
+with planted outlier units against the HF twin's golden and the range guard's counters (item 4); the whole-block k = 3 ResBlock
+kernel against three fused steps, bit for bit (item 6)."""
 import json
 import os
 import threading
