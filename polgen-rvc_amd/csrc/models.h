@@ -36,6 +36,10 @@ struct SynthModel {
     ConvT1dW up;
     ConvW noise;
     int noise_stride = 1, noise_pad = 0;
+    // round 5: a long noise FIR (stage 0: k = 80, stride 40) re-indexed like the STFT -- a dense k = 3 conv over the
+    // hop-major transposed source X2[c][q] = har[stride q + c] (c < stride, zero rows up to `noise_dense_cin`); cin 0 = unused
+    ConvW noise_dense;
+    int noise_dense_cin = 0;
     int ch = 0;
     ConvW c1[4][3], c2[4][3];
   };

@@ -129,6 +129,23 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
     S.noise = load_conv(c, t, "dec.noise_convs." + std::to_string(i));
     S.noise_stride = sf0;
     S.noise_pad = sf0 > 1 ? sf0 / 2 : 0;
+    if (sf0 >= 16 && S.noise.k == 2 * sf0 && S.noise.cin == 1) {
+      // y[co][q] = sum_j w[co][j] har[sf0 q + j - sf0/2]: with j - sf0/2 = sf0 (m - 1) + c (c in [0, sf0), m in {0, 1, 2}) this
+      // is a dense conv over q with three taps and sf0 input channels -- on the matrix cores instead of an 80-tap FIR whose
+      // loads are 40 samples apart between neighbouring lanes (224 us per clip, 3 ms per 16-item micro-batch)
+      const std::vector<float> w1 = t.f32("dec.noise_convs." + std::to_string(i) + ".weight");     // (co, 1, 2 sf0)
+      const std::vector<float> b1 = t.f32("dec.noise_convs." + std::to_string(i) + ".bias");
+      const int sp = (sf0 + 15) / 16 * 16, kn = 2 * sf0, half = sf0 / 2;
+      std::vector<float> w2((size_t)co * sp * 3, 0.f);
+      for (int o = 0; o < co; ++o)
+        for (int c2 = 0; c2 < sf0; ++c2)
+          for (int m2 = 0; m2 < 3; ++m2) {
+            const int j = sf0 * (m2 - 1) + c2 + half;
+            if (j >= 0 && j < kn) w2[((size_t)o * sp + c2) * 3 + m2] = w1[(size_t)o * kn + j];
+          }
+      S.noise_dense = make_conv(c, w2.data(), b1.data(), co, sp, 3, 1, true);
+      S.noise_dense_cin = sp;
+    }
     S.ch = co;
     for (int j = 0; j < cfg.n_resblocks; ++j)
       for (int m = 0; m < 3; ++m) {
@@ -148,7 +165,7 @@ size_t synth_arena_bytes(const SynthModel& m, int B, int T) {
   const auto& cf = m.cfg;
   size_t enc = (size_t)B * T * (size_t)(cf.input_dim + 8 * cf.hidden_channels + 2 * cf.filter_channels +
                                         4 * cf.inter_channels + 64 + (8 * 98 + 2 * 96 + 8) * cf.n_heads);
-  size_t dec = (size_t)B * T * m.upp * 3;  // har, noise, out
+  size_t dec = (size_t)B * T * m.upp * 5;  // har, noise, out, the hop-major copy of har for the dense noise conv (1.2x)
   size_t mx = 0, sum = (size_t)B * T * cf.up_initial_channel;
   long tt = T;
   for (size_t i = 0; i < m.stages.size(); ++i) {
@@ -245,6 +262,18 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       tt *= cf.up_rates[i];
       if (nz_fused[i]) continue;
       nz[i] = A.alloc<float>((size_t)B * S.ch * tt);
+      static const bool dense_on = !getenv("RVCX_NOISE_DENSE") || atoi(getenv("RVCX_NOISE_DENSE")) != 0;
+      if (dense_on && S.noise_dense_cin > 0 && Tupp == tt * S.noise_stride) {
+        // hop-major transpose of the source (zero beyond an item's length already: sine_source_kernel), then the dense conv
+        const int sp = S.noise_dense_cin, st = S.noise_stride;
+        float* x2 = A.alloc<float>((size_t)B * sp * tt);
+        RVCX_HIP(hipMemsetAsync(x2, 0, (size_t)B * sp * tt * sizeof(float), sn));
+        for (int b = 0; b < B; ++b) launch_transpose(har + (size_t)b * Tupp, x2 + (size_t)b * sp * tt, 1, (int)tt, st, sn);
+        ConvArgs a = conv1d_args(S.noise_dense, x2, nz[i], B, (int)tt, (int)tt, 1, 1, 1);
+        a.lens_out = lens_stage[i + 1];
+        c.conv_on(a, sn);
+        continue;
+      }
       ConvArgs a = conv1d_args(S.noise, har, nz[i], B, (int)Tupp, (int)tt, S.noise_stride, 1, S.noise_pad);
       a.lens_in = lens_stage[m.stages.size()];
       a.lens_out = lens_stage[i + 1];
