@@ -23,7 +23,8 @@ print(f"B={B} {sec:.0f} s: HuBERT wall best {min(ts)*1e3:.2f} ms ({min(ts)*1e3/B
 ctx.conv_profile_begin()
 ctx.hubert_features(wav, 768, 12)
 prof = ctx.conv_profile_end()
-rows = [r.split(",") for r in ctx.conv_profile_csv().strip().splitlines()[1:]]
+import csv
+rows = list(csv.reader(ctx.conv_profile_csv().strip().splitlines()[1:]))    # tile names hold commas: quoted
 acc = collections.OrderedDict()
 for r in rows:
     key = (r[2], r[3], r[4], r[5], r[6], r[0])

@@ -23,7 +23,8 @@ print(f"B={B} {sec:.0f} s: F0 model wall best {min(ts)*1e3:.2f} ms ({min(ts)*1e3
 ctx.conv_profile_begin()
 ctx.rmvpe_f0(wav)
 prof = ctx.conv_profile_end()
-rows = [r.split(",") for r in ctx.conv_profile_csv().strip().splitlines()[1:]]
+import csv
+rows = list(csv.reader(ctx.conv_profile_csv().strip().splitlines()[1:]))    # tile names hold commas: quoted
 # tile,B,cin,cout,k,stride,nout,gflop,ms,tflops
 acc = collections.OrderedDict()
 for r in rows:
