@@ -1640,11 +1640,8 @@ const PairCfg kPair[] = {
     make_sp<32, 16, 1, 8, 3, 3, 8>(),  make_sp<32, 16, 1, 8, 7, 4, 8>(),  make_sp<32, 16, 1, 8, 11, 4, 8>(),
     make_sp<64, 8, 2, 4, 3, 3, 8>(),   make_sp<64, 8, 2, 4, 7, 4, 8>(),   make_sp<64, 8, 2, 4, 11, 4, 8>(),
     make_sp<128, 6, 4, 3, 3, 3, 8>(),  make_sp<128, 6, 4, 3, 7, 3, 8>(),  make_sp<128, 6, 4, 3, 11, 3, 8>(),
-    // variant 9 (round 5): variant 2's small tiles (TWO workgroups per CU: one in its k-loops while the other is in its
-    // prologue / epilogue) with the wide epilogue -- for the small C x k shapes, whose tile life is half prologue + epilogue
-    make_cfg<32, 8, 1, 4, 3, 3, 2, 9, true, 3>(),   make_cfg<32, 8, 1, 4, 7, 7, 1, 9, true, 3>(),   make_cfg<32, 8, 1, 4, 11, 11, 1, 9, true, 3>(),
-    make_cfg<64, 4, 2, 2, 3, 3, 2, 9, true, 3>(),   make_cfg<64, 4, 2, 2, 7, 7, 1, 9, true, 3>(),   make_cfg<64, 4, 2, 2, 11, 4, 1, 9, true, 3>(),
-    make_cfg<128, 3, 2, 3, 3, 2, 1, 9, true, 3>(),  make_cfg<128, 3, 2, 3, 7, 2, 1, 9, true, 3>(),  make_cfg<128, 3, 2, 3, 11, 2, 1, 9, true, 3>(),
+    // (variant 9, round 5: variant 2's small tiles -- two workgroups per CU -- with the wide epilogue: -6 ... -8 % at C <= 64 / k = 3,
+    // +50 % at C = 128; superseded by the persistent form and removed)
     // variant 10 (round 5): PERSISTENT workgroups on variant 4's tiles -- the default for these shapes (RVCX_PAIR_PERSIST=0: variant 4).
     // Measured per shape against variant 4 (tools/bench_pair.py, same box; profiles/pair_persist_r05.txt): k = 3 -11 ... -15 %,
     // C = 32 -8 ... -12 %, C = 64 / 128 at k = 7 -4 ... -6 %, C = 64 k = 11 -3 %.  C = 128, k = 11 is NOT here: on 768 threads (168
@@ -1656,18 +1653,13 @@ const PairCfg kPair[] = {
     // C = 128: k = 3 on 768 threads (12 waves of 32 x 64); k = 7 and k = 11 on 512 threads with N1 = 192 -- eight waves of 32 x 96
     // (WN = 3: eight fragment reads per nine product blocks), 220-235 registers: -6 ... -10 % / -3.5 % against the forms above them
     make_persist<128, 6, 4, 3, 3, 3, 1, false>(),  make_persist<128, 6, 4, 2, 7, 4, 1, false>(),  make_persist<128, 6, 4, 2, 11, 4, 1, false>(),
-    // A/B forms: 11 = EARLY requests; C = 128, k = 11 on 768 threads.  12 = C = 128, k = 11 / k = 3 on 512 threads, N1 = 128
+    // A/B forms: 11 = EARLY requests; C = 128, k = 11 on 768 threads.  (12 = C = 128 on 512 threads with N1 = 128: +10 %, removed)
     make_persist<32, 16, 1, 8, 3, 3, 2, true, 11>(),  make_persist<32, 16, 1, 8, 7, 7, 1, true, 11>(),  make_persist<32, 16, 1, 8, 11, 11, 1, true, 11>(),
     make_persist<64, 8, 2, 4, 3, 3, 2, true, 11>(),   make_persist<64, 8, 2, 4, 7, 7, 1, true, 11>(),   make_persist<64, 8, 2, 4, 11, 11, 1, true, 11>(),
     make_persist<128, 6, 4, 3, 11, 4, 1, false, 11>(),  make_persist<128, 4, 4, 2, 7, 7, 1, false, 11>(),
-    make_persist<128, 4, 4, 2, 11, 4, 1, false, 12>(),  make_persist<128, 4, 4, 2, 3, 3, 1, false, 12>(),
-    // variant 15 (round 5 A/B): persistent AND two workgroups per CU -- half-width tiles on four waves (<= 80 KB of LDS each)
-    make_persist<32, 8, 1, 4, 3, 3, 2, false, 15, 2>(),  make_persist<32, 8, 1, 4, 7, 7, 1, false, 15, 2>(),  make_persist<32, 8, 1, 4, 11, 11, 1, false, 15, 2>(),
-    make_persist<64, 4, 2, 2, 3, 3, 2, false, 15, 2>(),  make_persist<64, 4, 2, 2, 7, 7, 1, false, 15, 2>(),  make_persist<64, 4, 2, 2, 11, 4, 1, false, 15, 2>(),
-    // variant 13 / 14 (round 5 A/B): C = 128 on 512 threads with N1 = 192 -- eight waves of 32 x 96 (WN = 3: eight fragment reads per
-    // nine product blocks, 256 registers per lane), persistent (13) and per-tile (14)
+    // (variant 15, round 5: persistent AND two workgroups per CU on half-width tiles: slower on all six C <= 64 shapes, removed)
+    // variant 13 (round 5 A/B): C = 128, k = 3 on the 512-thread N1 = 192 tile that k = 7 / 11 use by default (slower at k = 3: 0.292 vs 0.278 ms)
     make_persist<128, 6, 4, 2, 3, 3, 1, false, 13>(),
-    make_cfg<128, 6, 4, 2, 3, 3, 1, 14, false, 3>(),  make_cfg<128, 6, 4, 2, 7, 4, 1, 14, false, 3>(),  make_cfg<128, 6, 4, 2, 11, 4, 1, 14, false, 3>(),
     // RVCX_PAIR_VARIANT=3: the round-2 form (residual fetched eight values at a time inside the epilogue), for A/B runs
     make_cfg<32, 16, 1, 8, 3, 3, 2, 3>(),  make_cfg<32, 16, 1, 8, 7, 7, 1, 3>(),  make_cfg<32, 16, 1, 8, 11, 11, 1, 3>(),
     make_cfg<64, 8, 2, 4, 3, 3, 2, 3>(),   make_cfg<64, 8, 2, 4, 7, 7, 1, 3>(),   make_cfg<64, 8, 2, 4, 11, 11, 1, 3>(),

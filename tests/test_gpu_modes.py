@@ -46,13 +46,19 @@ def test_channel_first_linear_mode_passes_the_reference_goldens():
     _run_mode({"RVCX_GEMM": "0"})
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "5", "6", "7", "8"])
+@pytest.mark.parametrize("variant", ["1", "2", "5", "6", "7", "8", "11", "13"])
 def test_alternative_fused_resblock_tiles_are_bit_identical_too(variant):
     """RVCX_PAIR_VARIANT selects other forms of the fused ResBlock step (2: small tiles, two workgroups per CU; 5: 8 waves
     of 64 x 64 on 256-position tiles with the input tile overlaid on Y1; 6 / 7: weights straight from L2 into registers,
-    barrier-free c2 loop; 8: split-phase staging on LDS counters, no s_barrier in the k-loops -- round-4 experiments): the k-order is the same, so each must equal the two conv
+    barrier-free c2 loop; 8: split-phase staging on LDS counters, no s_barrier in the k-loops -- round-4 experiments; 11 / 13: round 5's persistent form with EARLY requests / the 512-thread N1 = 192 tile at k = 3): the k-order is the same, so each must equal the two conv
     launches bit for bit and torch within fp32 rounding."""
     _run_mode({"RVCX_PAIR_VARIANT": variant}, "test_gpu_conv.py", "fused_resblock", "10 passed")
+
+
+def test_per_tile_fused_step_of_round_4_is_bit_identical_too():
+    """RVCX_PAIR_PERSIST=0: one workgroup per tile with the wide epilogue (round 4's default, now the fallback of the persistent
+    form and the form of C = 256)."""
+    _run_mode({"RVCX_PAIR_PERSIST": "0"}, "test_gpu_conv.py", "fused_resblock", "10 passed")
 
 
 @pytest.mark.parametrize("env", [{"RVCX_GRU_FORM": "0"}, {"RVCX_GRU_FORM": "1"}, {"RVCX_GRU_COLOCATE": "0"},
