@@ -581,9 +581,15 @@ __global__ void reflect_pad_kernel(const float* x, float* y, int n, int p, long 
     const long b = idx / np2;
     const long o = idx - b * np2;
     const int nb = ns ? ns[b] : n;
+    // numpy's "reflect" for ANY pad width (np.pad reflects repeatedly when p >= n; VC.pipeline pads a 0.4 s clip by 1 s,
+    // pipeline.py:348): the source index is the triangle wave of period 2 (n - 1)
     int j = (int)o - p;
     if (j < 0) j = -j;
-    if (j >= nb) j = 2 * (nb - 1) - j;
+    if (j >= nb) {
+      const int per = nb > 1 ? 2 * (nb - 1) : 1;
+      j %= per;
+      if (j >= nb) j = per - j;
+    }
     y[b * y_bs + o] = o < nb + 2 * p ? x[b * x_bs + j] : 0.f;
   }
 }

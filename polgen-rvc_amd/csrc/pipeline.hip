@@ -583,7 +583,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   bool any_f64 = false, any_noise = false;
   for (int i = 0; i < NB;) {
     const long n = ios[order[i]].n;
-    RVCX_CHECK(n > g.t_pad, "convert: clip shorter than the reflect padding");
+    RVCX_CHECK(n > 18, "convert: the clip must be longer than the zero-phase filter's edge padding (18 samples; scipy's filtfilt raises for it too)");
     const long nd = bucket_length(n, p, g);
     const int cap = convert_micro_batch(c, model_id, nd, p);
     int j = i;
@@ -857,11 +857,16 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
         RVCX_CHECK(Th > 0 && T > 0, "convert: chunk too short");
         // a cut may land within x_pad seconds of the clip's end: the reference then trims that chunk's output to
         // nothing (audio1[t_pad_tgt:-t_pad_tgt], pipeline.py:441-447) but still runs it -- so do we
-        RVCX_CHECK((long)T * M.upp >= 2 * g.t_pad_tgt, "convert: chunk shorter than its padding");
+        RVCX_CHECK((long)T * M.upp >= 2 * g.t_pad_tgt,
+                   "convert: the clip is shorter than what the trim of the x_pad padding removes (the reference's "
+                   "audio1[t_pad_tgt:-t_pad_tgt] is empty there and np.abs(audio_opt).max() raises)");
         P.jobs.push_back({b, (int)ci, ch.s, ch.e, ch.f0_off, out_off, noise_off, Th, T});
         out_off += (long)T * M.upp - 2 * g.t_pad_tgt;
         noise_off += (long)T * (inter + M.upp);
       }
+      RVCX_CHECK(out_off > 0,
+                 "convert: nothing is left of the clip after the trim of the x_pad padding (the reference's "
+                 "np.abs(audio_opt).max() raises on the empty array; at x_pad = 1 a clip needs 400 samples)");
       RVCX_CHECK(out_off <= u.cap, "convert: output capacity exceeded");
       RVCX_CHECK(!u.noise || noise_off <= u.noise_cap, "convert: parity noise buffer shorter than the chunk plan needs");
       u.out_n = out_off;

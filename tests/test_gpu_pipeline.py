@@ -69,7 +69,7 @@ def test_highpass_matches_scipy(ctx):
     assert np.abs(got - ref).max() < 1e-6
 
 
-@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked"])
+@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short"])
 def test_pipeline_vs_reference_golden(ctx, tag):
     from polgen_rvc_amd import synthetic as S
     from polgen_rvc_amd.infer import infer as I

@@ -159,3 +159,29 @@ def test_the_longest_member_of_a_class_takes_both_paths_to_the_same_bits(ctx):
     # the full-length clip alone really took the mask-free path: a batch of two of them is not ragged either
     two = ctx.convert_batch(mid, [clips[0], clips[0]], p)
     assert ctx.last_micro_batches() == [2] and np.array_equal(two[0], pcm[0])
+
+
+def test_clips_shorter_than_the_reflect_padding(ctx):
+    """``np.pad(audio, (t_pad, t_pad), mode="reflect")`` (pipeline.py:348) reflects repeatedly when the clip is shorter than
+    the 1 s padding, so the reference converts a 400-sample clip (the golden ``pipeline_tiny_short`` pins 0.4 s against the
+    reference itself).  Clips of 400 samples ... 1.2 s in ONE call: every one equals its single run bit for bit and has
+    the reference's length.  Below 400 samples the trim ``audio1[t_pad_tgt:-t_pad_tgt]`` (pipeline.py:441-447) leaves nothing
+    and the reference dies in ``np.abs(audio_opt).max()``; below 19 scipy's filtfilt raises: refused here with the reason."""
+    from polgen_rvc_amd import _lib
+    mid = _load(ctx, 6)
+    p = _params()
+    lens = [400, 480, 1999, 6400, 15999, 16000, 16001, 19200]
+    clips = [_clip(200 + i, n) for i, n in enumerate(lens)]
+    pcm, f32 = ctx.convert_batch(mid, clips, p, want_f32=True)
+    upp = ctx.synth_upp(mid)
+    for i, (n, c) in enumerate(zip(lens, clips)):
+        a_pcm, a_f32 = ctx.convert_batch(mid, [c], _params(seed=5 + i), want_f32=True)
+        # one chunk: min(p_len, 2 * HuBERT frames) frames, 2 * (x_pad * 100) of them trimmed (pipeline.py:253-256,441-447)
+        frames = min((n + 32000) // 160, 2 * ((n + 32000 - 400) // 320 + 1))
+        assert len(pcm[i]) == (frames - 200) * upp > 0, (n, len(pcm[i]))
+        assert np.array_equal(a_f32[0], f32[i]) and np.array_equal(a_pcm[0], pcm[i]), n
+        assert np.isfinite(f32[i]).all()
+    for n, why in ((399, "padding"), (161, "padding"), (19, "padding"), (18, "18 samples")):
+        with pytest.raises(_lib.RvcxError, match=why):
+            ctx.convert_batch(mid, [clips[-1][:n]], p)
+    assert len(ctx.convert_batch(mid, [clips[-1][:400]], p)[0]) == 2 * upp      # the context is usable after a refusal

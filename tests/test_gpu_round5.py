@@ -191,3 +191,4 @@ def test_resblock3_equals_three_fused_steps(ctx, C, T, B):
     if lens is not None:
         for i, n in enumerate(lens):
             assert not got[i, :, n:].any() and got[i, :, :n].any()
+

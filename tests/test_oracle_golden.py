@@ -61,7 +61,7 @@ def test_hubert_oracle_vs_hf_twin(tag):
     assert rms(out - d["out"]) / rms(d["out"]) < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked"])
+@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short"])
 def test_pipeline_oracle_vs_reference(tag):
     from oracle import pipeline as OP
     S = _S()

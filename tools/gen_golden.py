@@ -617,6 +617,8 @@ def main():
         "pipe_tiny": lambda: gold_pipeline("tiny_single", tiny, (1, 6, 38, 41), 2.0, 11, 1, 0, 1.0, 0.33, 50, 1100),
         # CI's canonical argument set (test_cli.yml:43): -p -0.5 -rms 0.25 -pro 0.33 -f0min 1 -f0max 1100
         "pipe_tiny_ci": lambda: gold_pipeline("tiny_ciargs", tiny, (1, 6, 38, 41), 2.5, 12, 1, -0.5, 0.25, 0.33, 1, 1100),
+        # a clip SHORTER than the 1 s reflect padding: np.pad reflects repeatedly (pipeline.py:348 on 0.4 s of audio)
+        "pipe_tiny_short": lambda: gold_pipeline("tiny_short", tiny, (1, 6, 38, 41), 0.4, 15, 1, 0, 1.0, 0.33, 50, 1100),
         # small geometry to force the multi-chunk branch (pipeline.py:381-415)
         "fcpe_tiny": lambda: gold_fcpe("tiny", S.FCPE_CFG_TINY, 1.2, 21, 1, 0.0),
         "fcpe_full": lambda: gold_fcpe("full_2s", S.FCPE_CFG_FULL, 2.0, 22, 0, -3.0, stride=2),
