@@ -139,6 +139,34 @@ def test_pipeline_float_waveform_vs_oracle(ctx):
     assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= FULL_PCM_BAR
 
 
+
+@pytest.mark.parametrize("n,env", [(400, 0.5), (2500, 0.25), (7999, 0.5), (15999, 0.0)])
+def test_short_clip_with_volume_envelope_vs_oracle(ctx, n, env):
+    """Clips shorter than the reflect padding through the RMS envelope (pipeline.py:449-452: ``librosa.feature.rms`` frames
+    of ONE second hopped by half a second -- a 400-sample clip has a single frame on each side, which ``F.interpolate``
+    stretches to a constant): float waveform and PCM against the CPU oracle, which the golden ``pipeline_tiny_ciargs`` pins to
+    the reference for this branch and ``pipeline_tiny_short`` for the short padding."""
+    from oracle import pipeline as OP
+    from polgen_rvc_amd import synthetic as S
+    from polgen_rvc_amd.infer import infer as I
+    cfgs = (S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY)
+    hub, cpt = _setup(ctx, cfgs, 4)
+    cpt, version, net_g, tgt_sr, vc = I.get_vc("cuda:0", False, I.Config(), None, cpt=cpt)
+    audio = S.make_clip(33, 1.1)[:n].copy()
+    models = OP.Models(S.to_torch(S.hubert_state(cfgs[0], 4)), cfgs[0], S.to_torch(S.rmvpe_state(cfgs[1], 4)),
+                       cfgs[1], S.to_torch(cpt["weight"]), cfgs[2])
+    opcm, parts = OP.pipeline(models, OP.Geometry(tgt_sr, 1, 6, 38, 41), audio, 2.0, 0, None, 0.0, env, 0.33, 50,
+                              1100, seed=11, return_parts=True)
+    noise = np.concatenate([np.concatenate([z.numpy().ravel(), s.numpy().ravel()]) for z, s in parts["noises"]])
+    pcm, f32 = vc.pipeline(hub, net_g, 0, audio, "x.wav", 2.0, "rmvpe+", None, 0, 1, 3, tgt_sr, 0, env, "v2", 0.33,
+                           128, None, 50, 1100, noise=noise, return_f32=True)
+    assert pcm.shape == opcm.shape and len(parts["plan"]) == 1
+    e = rms(f32 - parts["audio_f32"])
+    print(f"n {n} env {env}: float rms err {e:.3e} (rms {rms(parts['audio_f32']):.3f})")
+    assert e < TINY_RMS_BAR * max(1.0, rms(parts["audio_f32"])), e
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= FULL_PCM_BAR
+
+
 def test_unknown_f0_method_raises(ctx):
     from polgen_rvc_amd.infer.pipeline import VC
     from polgen_rvc_amd.infer import infer as I
