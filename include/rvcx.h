@@ -363,6 +363,13 @@ int rvcx_op_convtranspose1d(rvcx_ctx*, const float* x, const float* w, const flo
 /* Conv2d 3x3 pad 1 (+bias, act, res) on (B,Cin,H,W) */
 int rvcx_op_conv2d3x3(rvcx_ctx*, const float* x, const float* w, const float* bias, const float* res,
                       float* y, int B, int Cin, int H, int W, int Cout, int act);
+/* One ConvBlockRes of the F0 model's U-Net (RMVPE.py:140-175, BatchNorm already folded into w / b by the caller):
+ * y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2) + (wsc ? conv1x1(x, wsc) + bsc : x), through the model's own block
+ * path (split hand-off between the two convs on large maps).  rows (B ints or NULL): valid rows of each item -- the rows
+ * below are zero in x and come back zero (what a shorter member of a ragged batch sees). */
+int rvcx_op_convblock2d(rvcx_ctx*, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* wsc, const float* bsc, float* y, int B, int Cin, int Cout, int H, int W,
+                        const int32_t* rows);
 /* ConvTranspose2d 3x3 stride 2 pad 1 output_padding 1: (B,Cin,H,W) -> (B,Cout,2H,2W), w (Cin,Cout,3,3) */
 int rvcx_op_convtranspose2d(rvcx_ctx*, const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int H, int W, int Cout, int act);

@@ -81,7 +81,7 @@ SYMBOLS = [
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_bucket_length", "rvcx_last_micro_batches", "rvcx_noise_len",
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
-    "rvcx_op_conv2d3x3", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
+    "rvcx_op_conv2d3x3", "rvcx_op_convblock2d", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
     "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
     "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm", "rvcx_device_info",
@@ -345,6 +345,21 @@ class Context:
         res = None if res is None else f32(res)
         self._ck(lib().rvcx_op_conv2d3x3(self._h, _p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, H, W, Cout,
                                          act), "op_conv2d3x3")
+        return y
+
+    def convblock2d(self, x, w1, b1, w2, b2, wsc=None, bsc=None, rows=None):
+        """one ConvBlockRes (RMVPE.py:140-175, BN folded by the caller) through the F0 model's own block path"""
+        x, w1, w2 = f32(x), f32(w1), f32(w2)
+        B, Cin, H, W = x.shape
+        Cout = w1.shape[0]
+        y = np.empty((B, Cout, H, W), np.float32)
+        b1 = None if b1 is None else f32(b1)
+        b2 = None if b2 is None else f32(b2)
+        wsc = None if wsc is None else f32(wsc)
+        bsc = None if bsc is None else f32(bsc)
+        ri = i32(rows)
+        self._ck(lib().rvcx_op_convblock2d(self._h, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(wsc), _p(bsc), _p(y), B, Cin,
+                                           Cout, H, W, _p(ri, C.c_int32)), "op_convblock2d")
         return y
 
     def convtranspose2d(self, x, w, bias=None, act=0):
@@ -813,6 +828,8 @@ class Context:
                 return "conv_cout1 (vector FMA, Cout=1)"
             if kd[i] == 300003:
                 return "conv_deep<64,32> (long K, few positions: split-K inside the workgroup)"
+            if kd[i] == 300004:
+                return "conv3_thin (3x3, C=16/32: streaming MFMA, B operand from global, DPP-shifted taps)"
             if kd[i] == 300002:
                 return "convt_thin (ConvTranspose1d k4 s2, streaming MFMA + fused noise conv)"
             if kd[i] >= 300000:

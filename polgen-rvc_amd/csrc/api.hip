@@ -697,6 +697,41 @@ int rvcx_op_conv2d3x3(rvcx_ctx* ctx, const float* x, const float* w, const float
   API_END
 }
 
+int rvcx_op_convblock2d(rvcx_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* wsc, const float* bsc, float* y, int B, int Cin, int Cout, int H, int W,
+                        const int32_t* rows) {
+  API_BEGIN(ctx)
+  TEMP_REGION(C);
+  RVCX_CHECK(wsc || Cin == Cout, "op_convblock2d: Cin != Cout needs the 1x1 shortcut");
+  const int Wp = W + 2;
+  const size_t nx = (size_t)B * Cin * H * Wp, ny = (size_t)B * Cout * H * Wp;
+  C->arena.reserve((nx + 3 * ny) * 4 + (64 << 20));
+  C->arena.reset();
+  ConvW c1 = make_conv(*C, w1, b1, Cout, Cin, 9, 1), c2 = make_conv(*C, w2, b2, Cout, Cout, 9, 1), sc;
+  if (wsc) sc = make_conv(*C, wsc, bsc, Cout, Cin, 1, 1);
+  std::vector<float> xp = pad_rows(x, (size_t)B * Cin, H, W);
+  if (rows)                                       // what the model guarantees: nothing but zeros below an item's last row
+    for (int b = 0; b < B; ++b) {
+      RVCX_CHECK(rows[b] >= 0 && rows[b] <= H, "op_convblock2d: rows outside [0, H]");
+      for (int c = 0; c < Cin; ++c)
+        std::fill(xp.begin() + (((size_t)b * Cin + c) * H + rows[b]) * Wp, xp.begin() + (((size_t)b * Cin + c) + 1) * H * Wp, 0.f);
+    }
+  float* dx = to_dev(*C, xp.data(), nx);
+  float* dy = C->arena.alloc<float>(ny);
+  float* t1 = C->arena.alloc<float>(ny);
+  float* t2 = C->arena.alloc<float>(ny);
+  RVCX_HIP(hipMemsetAsync(dy, 0xff, ny * 4, C->stream));  // NaN fill: every element must be written
+  RVCX_HIP(hipMemsetAsync(t1, 0xff, ny * 4, C->stream));
+  rvcx::rmvpe_block_op(*C, c1, c2, wsc ? &sc : nullptr, dx, dy, t1, t2, B, H, Wp, rows, C->stream);
+  std::vector<float> yp(ny);
+  to_host(*C, yp.data(), dy, ny);
+  for (size_t r = 0; r < (size_t)B * Cout * H; ++r)
+    if (yp[r * Wp] != 0.f || yp[r * Wp + Wp - 1] != 0.f) fail("convblock2d: pad column not zero");
+  unpad_rows(yp, y, (size_t)B * Cout, H, W);
+  C->arena.reset();
+  API_END
+}
+
 int rvcx_op_convtranspose2d(rvcx_ctx* ctx, const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int H, int W, int Cout, int act) {
   API_BEGIN(ctx)

@@ -173,6 +173,9 @@ bool convt_thin_ok(const ConvArgs& a);                       // ConvTranspose1d(
 void launch_convt_thin(const ConvArgs& a, hipStream_t stream);
 void convt_thin_init();
 constexpr int kConvtThinSlot = 61;
+bool conv3_thin_ok(const ConvArgs& a);                       // 3x3, C = 16 / 32, many positions: the streaming kernel (conv3_thin.hip)?
+void launch_conv3_thin(const ConvArgs& a, hipStream_t stream);
+constexpr int kConv3ThinSlot = 59;
 bool conv_deep_ok(const ConvArgs& a);                        // long K, few positions per item: split-K inside the workgroup (conv_deep.hip)
 void launch_conv_deep(const ConvArgs& a, hipStream_t stream);
 constexpr int kConvDeepSlot = 63;

@@ -481,6 +481,9 @@ void conv_fast_describe(ConvProfile* p) {
   p->bm[kConvtThinSlot] = 128;
   p->bn[kConvtThinSlot] = 32;
   p->halo[kConvtThinSlot] = 300002;   // convt_thin_kernel
+  p->bm[kConv3ThinSlot] = 32;
+  p->bn[kConv3ThinSlot] = 30;
+  p->halo[kConv3ThinSlot] = 300004;   // conv3_thin_kernel
   p->bm[kConvDeepSlot] = 64;
   p->bn[kConvDeepSlot] = 32;
   p->halo[kConvDeepSlot] = 300003;    // conv_deep_kernel
@@ -528,6 +531,10 @@ int launch_conv_fast(ConvArgs& a, hipStream_t stream) {
     off_max = std::max(off_max, o);
   }
   const int halo = off_max - off_min;
+  if (conv3_thin_ok(a)) {
+    launch_conv3_thin(a, stream);
+    return kConv3ThinSlot;
+  }
   if (conv_deep_ok(a)) {
     launch_conv_deep(a, stream);
     return kConvDeepSlot;

@@ -51,4 +51,40 @@ __device__ __forceinline__ f32x16 h3_mfma(half8 a, half8 b, f32x16 c) {
 }
 constexpr int kH3Oob = 0x7ffffff0;
 
+// c1 -> c2 hand-off of a ResBlock: the activated outputs are stored already split (see ConvArgs::y_split).  A lane owns
+// rows (r&3) + 8(r>>2) + 4 hl of a 32x32 tile: register group g = r>>2 is the 4 channels q = 4 hl .. 4 hl + 3 of
+// element (chunk = (c0 + 8 g)/16, h = g & 1) -- one 8-byte store for the hi halves and one for the scaled lo halves.
+__device__ __forceinline__ void store_tile_split(const ConvArgs& a, int b, int c0, int nn, int hl, const f32x16& t,
+                                                 int len_out) {
+  if (nn >= a.Nout) return;
+  bool live = nn < len_out;
+  if (a.zero_wp > 0) {                               // pad columns of a row-padded 2-D map stay zero
+    const int col = nn % a.zero_wp;
+    live = live && col != 0 && col != a.zero_wp - 1;
+  }
+  char* base = static_cast<char*>(a.y_split) + (long)b * a.y_bs * 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int cg = c0 + 8 * g;                       // first channel of the 8-channel element this group belongs to
+    if (cg + 4 * hl < a.Cout_g) {
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      half4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = t[4 * g + q] + (a.bias ? a.bias[cg + 4 * hl + q] : 0.f);
+        v = apply_act(v, a.act, a.act_slope);
+        v = live ? v : 0.f;
+        if (!(fabsf(v) < kH3ActLimit)) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);   // never taken on sane data
+        const _Float16 vh = (_Float16)v;
+        hi[q] = vh;
+        lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+      }
+      const long e_hi = ((long)((cg >> 4) * 2 + 0) * 2 + (g & 1)) * a.y_cs + nn;
+      const long e_lo = ((long)((cg >> 4) * 2 + 1) * 2 + (g & 1)) * a.y_cs + nn;
+      *reinterpret_cast<half4*>(base + e_hi * 16 + 8 * hl) = hi;
+      *reinterpret_cast<half4*>(base + e_lo * 16 + 8 * hl) = lo;
+    }
+  }
+}
+
 }  // namespace rvcx

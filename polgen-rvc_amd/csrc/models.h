@@ -101,6 +101,8 @@ size_t rmvpe_arena_bytes(const RmvpeModel& m, int B, int64_t n);
 // launches) are enqueued: the pipeline enqueues HuBERT there, so that neither branch waits for the host
 // ns_host (optional, B ints): a ragged batch -- item b holds ns_host[b] <= n samples in its row of n; its f0 row has
 // 1 + ns_host[b]/160 valid frames and is bit-identical to what the call returns for that item alone in a row of n
+void rmvpe_block_op(Ctx& c, const ConvW& c1, const ConvW& c2, const ConvW* sc, const float* x, float* y, float* tmp1,
+                    float* tmp2, int B, int H, int Wp, const int* rows, hipStream_t s);
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
                    float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out = nullptr,
                    const std::function<void()>* after_shallow = nullptr, const int* ns_host = nullptr);

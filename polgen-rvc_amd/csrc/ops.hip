@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512) void groupnorm_gelu_kernel(const float* __rest
 
 // The apply pass when the consumer is a split-fp16 conv tile reading pre-split input (ConvArgs::x_split): a thread owns 8
 // channels of one frame and stores them as one 16-byte element of fp16 hi parts and one of scaled lo parts,
-// XS[c/16][op][(c%16)/8][t][8] -- the layout and the arithmetic of store_tile_split (conv_h3.hip).
+// XS[c/16][op][(c%16)/8][t][8] -- the layout and the arithmetic of store_tile_split (h3_device.h).
 __global__ __launch_bounds__(256) void groupnorm_gelu_split_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, void* __restrict__ ys, int C,

@@ -249,6 +249,30 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
 }
 }  // namespace
 
+// One ConvBlockRes on device maps (parity tests of the block path: the split hand-off, per-item row counts): x / y are
+// (B, C, H, Wp) row-padded maps, rows[b] (host, or null) the valid rows of item b, tmp1 / tmp2 two maps of y's size
+void rmvpe_block_op(Ctx& c, const ConvW& c1, const ConvW& c2, const ConvW* sc, const float* x, float* y, float* tmp1,
+                    float* tmp2, int B, int H, int Wp, const int* rows, hipStream_t s) {
+  RmvpeModel::Block blk;
+  blk.c1 = c1;
+  blk.c2 = c2;
+  blk.cin = c1.cin;
+  blk.cout = c1.cout;
+  if (sc) {
+    blk.sc = *sc;
+    blk.has_sc = true;
+  }
+  const int* d_len = nullptr;
+  if (rows) {
+    std::vector<int> v(B);
+    for (int b = 0; b < B; ++b) v[b] = rows[b] * Wp;
+    d_len = dev_ints_many(c.arena, {v}, s)[0];
+  }
+  Map2 xm{const_cast<float*>(x), (long)blk.cin * H * Wp, blk.cin, H, Wp};
+  Map2 ym{y, (long)blk.cout * H * Wp, blk.cout, H, Wp};
+  run_block(c, blk, xm, ym, tmp1, tmp2, B, s, d_len);
+}
+
 void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64_t n, float thred, float f0_min,
                    float f0_max, float* f0, float* hidden, hipStream_t s, float* mel_out,
                    const std::function<void()>* after_shallow, const int* ns_host) {

@@ -292,3 +292,62 @@ def test_split_k_shapes_in_a_batch_equal_their_single_runs(ctx, shape):
     for i in (0, 3, 7):
         alone = ctx.conv1d(x[i:i + 1].numpy(), w.numpy(), b.numpy(), stride=stride, pad_left=pad, Tout=ref.shape[2])
         assert np.array_equal(alone[0], batch[i]), (shape, i)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 16, 16, 404, 128), (2, 32, 32, 320, 64), (1, 32, 16, 300, 128), (3, 16, 16, 170, 128)])
+def test_streaming_3x3_kernel_equals_the_tiled_one(ctx, B, Cin, Cout, H, W):
+    """conv3_thin.hip (shallow U-Net levels: C = 16 / 32, > 20 000 positions) against torch fp32, and bit-identical to the
+    conv_h3 tile it replaces (forced through the override): same k-order, same epilogue; the op NaN-checks the pad columns."""
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias, padding=1)) + res
+    ctx.conv_profile_begin()
+    got = ctx.conv2d3x3(x.numpy(), w.numpy(), bias.numpy(), res=res.numpy(), act=2)
+    names = [r["tile"] for r in ctx.conv_profile_end()]
+    assert any(n.startswith("conv3_thin") for n in names), names
+    try:
+        ctx.conv_override(103, -1, -1)
+        tiled = ctx.conv2d3x3(x.numpy(), w.numpy(), bias.numpy(), res=res.numpy(), act=2)
+    finally:
+        ctx.conv_override(-1, -1, -1)
+    e = rms(got - ref.numpy()) / rms(ref.numpy())
+    print(f"B={B} {Cin}->{Cout} {H}x{W}: vs torch {e:.2e}; equal to the tiled kernel: {np.array_equal(got, tiled)}")
+    assert e < 2e-6
+    assert np.array_equal(got, tiled)
+
+
+@pytest.mark.parametrize("B,C,H,W,ragged", [(1, 16, 404, 128, False), (3, 16, 200, 128, True), (2, 32, 320, 64, True),
+                                            (1, 32, 320, 64, False)])
+def test_convblockres_through_the_models_block_path(ctx, B, C, H, W, ragged):
+    """One ConvBlockRes (RMVPE.py:140-175) through the F0 model's own block path -- the first conv hands its output over in
+    split fp16 form, the second adds the residual; per-item row counts as in a ragged micro-batch -- against torch fp32 per
+    item at its own height, and bit-identical with the streaming kernel (default) and the tiled one (forced)."""
+    g = torch.Generator().manual_seed(B * 77 + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b1, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    rows = np.array([H, H // 2 + 3, 5][:B], np.int32) if ragged else None
+    ref = torch.zeros(B, C, H, W)
+    for b in range(B):
+        hb = int(rows[b]) if ragged else H
+        xb = x[b:b + 1, :, :hb]
+        t = F.relu(F.conv2d(xb, w1, b1, padding=1))
+        ref[b, :, :hb] = F.relu(F.conv2d(t, w2, b2, padding=1)) + xb
+    ctx.conv_profile_begin()
+    got = ctx.convblock2d(x.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), rows=rows)
+    names = [r["tile"] for r in ctx.conv_profile_end()]
+    assert sum(n.startswith("conv3_thin") for n in names) >= 1, names
+    try:
+        ctx.conv_override(103, -1, -1)
+        tiled = ctx.convblock2d(x.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), rows=rows)
+    finally:
+        ctx.conv_override(-1, -1, -1)
+    assert np.isfinite(got).all()
+    e = rms(got - ref.numpy()) / rms(ref.numpy())
+    print(f"B={B} C={C} {H}x{W} ragged={ragged}: vs torch {e:.2e}; equal to the tiled kernels: {np.array_equal(got, tiled)}")
+    assert e < 2e-6
+    assert np.array_equal(got, tiled)
