@@ -353,6 +353,10 @@ const H3Cfg kH3[] = {
     // one wave per SIMD a k-step costs ~0.25 us of dependent LDS-read -> MFMA latency, five times its matrix time.
 };
 constexpr int kNumH3 = sizeof(kH3) / sizeof(kH3[0]);
+// profile slots: tiles 0 .. 10 -> 39 .. 49 (50 .. 63 belong to the fused steps, the Linear tiles and the streaming kernels),
+// later tiles -> 28 .. 38 (8 .. 27: the fp32 conv_fast family)
+constexpr int h3_slot(int t) { return t < 11 ? 39 + t : 28 + (t - 11); }
+static_assert(kNumH3 <= 22, "conv_h3: out of profile slots");
 }  // namespace
 
 thread_local bool g_force_fp32 = false;
@@ -373,10 +377,11 @@ bool conv_h3_configured() {
 }
 
 void conv_h3_describe(ConvProfile* p) {
-  for (int t = 0; t < kNumH3 && 39 + t < ConvProfile::kMaxTiles; ++t) {
-    p->bm[39 + t] = kH3[t].bm;
-    p->bn[39 + t] = kH3[t].bn;
-    p->halo[39 + t] = 400000 + (kH3[t].lin ? 1 : (kH3[t].stride == 2 ? 2 : kH3[t].halo));
+  for (int t = 0; t < kNumH3; ++t) {
+    const int s = h3_slot(t);
+    p->bm[s] = kH3[t].bm;
+    p->bn[s] = kH3[t].bn;
+    p->halo[s] = 400000 + (kH3[t].lin ? 1 : (kH3[t].stride == 2 ? 2 : kH3[t].halo));
   }
 }
 
@@ -483,7 +488,7 @@ int launch_conv_h3(ConvArgs& a, int halo, int off_min, hipStream_t stream) {
   hipLaunchKernelGGL(a.x_split ? F.kern_xs : F.kern, grid, dim3(256), 0, stream, a);
   if (S > 1) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());
-  return 39 + best;   // profile slots 39.. (conv_h3_describe)
+  return h3_slot(best);   // profile slots (conv_h3_describe)
 }
 
 }  // namespace rvcx
