@@ -244,6 +244,12 @@ struct Ctx {
     flops += f;
     a.ovf = dev_err;
     a.seq = ++launch_seq;
+    {   // the stream's split-K scratch (conv_on): K-split launches of long-K layers
+      const int si = (s == stream2) ? 1 : (s == aux[0] ? 2 : (s == aux[1] ? 3 : 0));
+      if (!splitk_buf[si]) RVCX_HIP(hipMalloc(&splitk_buf[si], kSplitKFloats * splitk_items * sizeof(float)));
+      a.part = splitk_buf[si];
+      a.part_cap = kSplitKFloats * splitk_items;
+    }
     conv_launch_gemm(a, f, s);
   }
   void conv(const ConvArgs& a) { conv_on(a, stream); }

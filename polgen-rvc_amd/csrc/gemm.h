@@ -27,6 +27,8 @@ struct GemmArgs {
   int T = 1;                     // rows per batch item
   int cin = 0, cin_p = 0, cout = 0, cout_p = 0;
   int act = ACT_NONE;            // ACT_NONE / ACT_RELU / ACT_GELU
+  float* part = nullptr;         // K-split scratch offered by the caller (launch_gemm decides): kGemmSeg x rows x cout floats
+  long part_cap = 0;             // floats
   int* ovf = nullptr;            // device error word (conv.h)
   int* ovf_next = nullptr;       // overflow word of the layer that CONSUMES ys: this kernel writes its split input
   int seq = 0;

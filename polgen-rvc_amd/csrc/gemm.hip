@@ -34,6 +34,42 @@ constexpr int kBnMax = 128;
 // One 32 x 32 accumulator tile -> the requested outputs.  Lane (j = lane & 31, hl = lane >> 5) owns row r0 + j and the
 // channels c0 + 8 g + 4 hl + q (g, q = 0..3): four runs of 4 consecutive channels = one 16-byte store per run (fp32
 // time-major) or one 8-byte hi + one 8-byte lo store (split form).
+// four consecutive channels c .. c + 3 of one row: bias, activation, residual, length mask, the requested outputs
+__device__ __forceinline__ void gemm_store4(const GemmArgs& a, int c, long row, bool live, float (&v)[4], bool& ovf) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] += (a.bias ? a.bias[c + q] : 0.f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act, 0.f);
+  if (a.res) {
+    const float4 r = *reinterpret_cast<const float4*>(a.res + row * a.ld_res + c);
+    v[0] += r.x;
+    v[1] += r.y;
+    v[2] += r.z;
+    v[3] += r.w;
+  }
+  if (!live) v[0] = v[1] = v[2] = v[3] = 0.f;
+  if (a.y) *reinterpret_cast<float4*>(a.y + row * a.ld_y + c) = make_float4(v[0], v[1], v[2], v[3]);
+  if (a.y_cf) {                                    // channel-first (B, cout, T): what the attention kernels read
+    float* yc = a.y_cf + (row / a.T) * a.cf_bs + (long)c * a.T + row % a.T;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yc[(long)q * a.T] = v[q];
+  }
+  if (a.ys) {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    half4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ovf |= !(fabsf(v[q]) < kH3ActLimit);
+      const _Float16 vh = (_Float16)v[q];
+      hi[q] = vh;
+      lo[q] = (_Float16)((v[q] - (float)vh) * kH3Scale);
+    }
+    char* e = static_cast<char*>(a.ys) + row * a.ld_ys + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+    *reinterpret_cast<half4*>(e) = hi;
+    *reinterpret_cast<half4*>(e + 32) = lo;
+  }
+}
+
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int c0, long row, int hl, const f32x16& t, bool& ovf) {
   if (row >= a.rows) return;
   const bool live = !a.lens || (int)(row % a.T) < a.lens[row / a.T];
@@ -43,41 +79,28 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int c0, long 
     if (c >= a.cout) continue;                       // cout is a multiple of 4 (checked by the launcher)
     float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = t[4 * g + q] + (a.bias ? a.bias[c + q] : 0.f);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], a.act, 0.f);
-    if (a.res) {
-      const float4 r = *reinterpret_cast<const float4*>(a.res + row * a.ld_res + c);
-      v[0] += r.x;
-      v[1] += r.y;
-      v[2] += r.z;
-      v[3] += r.w;
-    }
-    if (!live) v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (a.y) *reinterpret_cast<float4*>(a.y + row * a.ld_y + c) = make_float4(v[0], v[1], v[2], v[3]);
-    if (a.y_cf) {                                    // channel-first (B, cout, T): what the attention kernels read
-      float* yc = a.y_cf + (row / a.T) * a.cf_bs + (long)c * a.T + row % a.T;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) yc[(long)q * a.T] = v[q];
-    }
-    if (a.ys) {
-      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-      half4 hi, lo;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        ovf |= !(fabsf(v[q]) < kH3ActLimit);
-        const _Float16 vh = (_Float16)v[q];
-        hi[q] = vh;
-        lo[q] = (_Float16)((v[q] - (float)vh) * kH3Scale);
-      }
-      char* e = static_cast<char*>(a.ys) + row * a.ld_ys + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
-      *reinterpret_cast<half4*>(e) = hi;
-      *reinterpret_cast<half4*>(e + 32) = lo;
-    }
+    for (int q = 0; q < 4; ++q) v[q] = t[4 * g + q];
+    gemm_store4(a, c, row, live, v, ovf);
   }
 }
 
-template <int BM, int BN>
+// K-split launches (NSEG workgroups per tile, blockIdx.z = segment): the raw segment sums, part[seg][row][cout]
+__device__ __forceinline__ void gemm_store_part(const GemmArgs& a, int seg, int c0, long row, int hl, const f32x16& t) {
+  if (row >= a.rows) return;
+  float* pb = a.part + ((long)seg * a.rows + row) * a.cout;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = c0 + 8 * g + 4 * hl;
+    if (c < a.cout) *reinterpret_cast<float4*>(pb + c) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+  }
+}
+
+// NSEG: the K range is summed in NSEG equal segments, each from zero, and the segment sums are added left to right --
+// the CANONICAL order of a long-K layer (launch_gemm: K >= 2048), whatever the tile and whether the segments are computed
+// by one workgroup (SPLIT = false: a second accumulator set) or by NSEG workgroups (SPLIT = true: blockIdx.z = segment,
+// raw sums to GemmArgs::part, gemm_finish_kernel adds them in the same order): a batched call, which never splits, still
+// equals its single runs bit for bit.
+template <int BM, int BN, int NSEG = 1, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
   constexpr int WM = BM / 64, WN = BN / 64;            // 4 waves as 2 x 2
   constexpr int BNP = BN + 1;                           // odd pitch (in 16-byte elements): conflict-free commits
@@ -94,7 +117,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
   const int co0 = blockIdx.y * BM;
   const long n0 = (long)blockIdx.x * BN;
   const int nchunk = a.cin_p / 16;
-  const int nst = (nchunk + kKC - 1) / kKC;
+  const int nst_all = (nchunk + kKC - 1) / kKC;
+  const int seg_len = nst_all / NSEG;                    // stages per segment (the launcher guarantees an even count)
+  const int st0 = SPLIT ? (int)blockIdx.z * seg_len : 0; // this workgroup's first stage
+  const int nst = SPLIT ? seg_len : nst_all;
   const H3Rsrc wres = h3_rsrc(a.w_h3, nchunk * 4 * a.cout_p * 16);
   // rows of this tile as one buffer: an offset past the last valid byte reads zeros (rows beyond `rows`, chunks
   // beyond cin_p)
@@ -125,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
   // its own load latency): a stage is fetched two iterations before it is committed to LDS.
   uint4 ra[2][NA], rb[2][NB];
   auto fetch = [&](int st, uint4 (&qa)[NA], uint4 (&qb)[NB]) {
-    const int c0 = st * kKC;
+    const int c0 = (st0 + st) * kKC;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int ch = c0 + a_cl[j];
@@ -205,12 +231,44 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
     commit(0, ra[0], rb[0]);
     fetch(2, ra[0], rb[0]);
     lds_barrier();
-    for (int st = 0; st < nst; st += 2) {
-      iter(st, ra[1], rb[1]);
-      iter(st + 1, ra[0], rb[0]);        // st + 1 == nst on an odd stage count: nothing to multiply, see iter
+    if constexpr (NSEG > 1 && !SPLIT) {
+      f32x16 tot[WM][WN];
+      for (int st = 0; st < nst; st += 2) {
+        iter(st, ra[1], rb[1]);
+        iter(st + 1, ra[0], rb[0]);
+        if ((st + 2) % seg_len == 0) {     // a segment ends here (seg_len is even): fold its sum, start the next from zero
+          const bool first = st + 2 == seg_len;
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                tot[m][n][r] = first ? acc[m][n][r] : tot[m][n][r] + acc[m][n][r];
+                acc[m][n][r] = 0.f;
+              }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = tot[m][n];
+    } else {
+      for (int st = 0; st < nst; st += 2) {
+        iter(st, ra[1], rb[1]);
+        iter(st + 1, ra[0], rb[0]);        // st + 1 == nst on an odd stage count: nothing to multiply, see iter
+      }
     }
   }
 
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+        gemm_store_part(a, (int)blockIdx.z, co0 + wr * (WM * 32) + m * 32, n0 + wc * (WN * 32) + n * 32 + i, h, acc[m][n]);
+    return;
+  }
   constexpr float inv = 1.f / kH3Scale;
   bool ovf = false;
 #pragma unroll
@@ -221,6 +279,35 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] *= inv;
       gemm_store_tile(a, co0 + wr * (WM * 32) + m * 32, n0 + wc * (WN * 32) + n * 32 + i, h, acc[m][n], ovf);
     }
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
+}
+
+// the second half of a K-split launch: segment sums added left to right (the canonical order, see gemm_h3_kernel), then the
+// epilogue of the tile kernel.  One thread per (row, four channels).
+template <int NSEG>
+__global__ __launch_bounds__(256) void gemm_finish_kernel(const GemmArgs a) {
+  const int c4n = a.cout / 4;
+  const long total = a.rows * c4n;
+  bool ovf = false;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / c4n;
+    const int c = (int)(e - row * c4n) * 4;
+    float4 p[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) p[sg] = *reinterpret_cast<const float4*>(a.part + ((long)sg * a.rows + row) * a.cout + c);
+    float v[4] = {p[0].x, p[0].y, p[0].z, p[0].w};
+#pragma unroll
+    for (int sg = 1; sg < NSEG; ++sg) {
+      v[0] += p[sg].x;
+      v[1] += p[sg].y;
+      v[2] += p[sg].z;
+      v[3] += p[sg].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= 1.f / kH3Scale;
+    const bool live = !a.lens || (int)(row % a.T) < a.lens[row / a.T];
+    gemm_store4(a, c, row, live, v, ovf);
+  }
   if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
 }
 
@@ -270,14 +357,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs a) {
   if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
 }
 
+constexpr int kNumGemmTiles = 4;
+constexpr int kGemmSeg = 4;              // segments of a long-K layer's canonical summation order
 struct GemmCfg {
   int bm, bn;
   size_t lds;
   void (*kern)(const GemmArgs);
+  void (*kern_seg)(const GemmArgs);     // the same tile, K summed in kGemmSeg segments by one workgroup
+  void (*kern_split)(const GemmArgs);   // one segment per workgroup (blockIdx.z)
 };
 template <int BM, int BN>
 constexpr GemmCfg gemm_cfg() {
-  return {BM, BN, (size_t)2 * kKC * 4 * (BM + BN + 1) * 16, gemm_h3_kernel<BM, BN>};
+    return {BM, BN, (size_t)2 * kKC * 4 * (BM + BN + 1) * 16, gemm_h3_kernel<BM, BN>, gemm_h3_kernel<BM, BN, kGemmSeg, false>,
+            gemm_h3_kernel<BM, BN, kGemmSeg, true>};
 }
 const GemmCfg kGemm[] = {gemm_cfg<128, 128>(), gemm_cfg<64, 128>(), gemm_cfg<128, 64>(), gemm_cfg<64, 64>()};
 constexpr int kNumGemm = sizeof(kGemm) / sizeof(kGemm[0]);
@@ -310,8 +402,9 @@ void gemm_init() {      // per DEVICE: a second-GPU context of the same process 
   std::lock_guard<std::mutex> g(mu);
   if ((done >> (dev & 63)) & 1) return;
   for (const auto& c : kGemm)
-    RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)c.lds));
+    for (auto k : {c.kern, c.kern_seg, c.kern_split})
+      if (k)
+        RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds));
   done |= 1ull << (dev & 63);
 }
 
@@ -328,13 +421,44 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     // output tiles of 32 x 32 for 1024 SIMDs at B = 1 -- so what counts is how many workgroups share a CU (they hide
     // each other's load latency), not operand reuse; the large tile only pays once every CU holds two of them.
     auto blocks = [&](int t) { return (long)cdiv(a.cout_p, kGemm[t].bm) * cdiv64(a.rows, kGemm[t].bn); };
+    // Long-K layers (HuBERT fc2: K = 3072) sum K in kGemmSeg segments -- a function of the LAYER's shape only, so every launch
+    // of the layer has the same bits.  At B = 1 such a launch is 300 workgroups walking 96 dependent stages (62 us at 15 %
+    // matrix-pipe duty); when the chip is underfilled the segments go to separate workgroups (K-split) + a finish pass.
+    const int nchunk = a.cin_p / 16, nst = (nchunk + kKC - 1) / kKC;
+    static const int seg_mode = getenv("RVCX_GEMM_KSEG") ? atoi(getenv("RVCX_GEMM_KSEG")) : 1;   // 0 off, 1 auto, 2 never split, 3 always split
+    const bool seg = seg_mode != 0 && nchunk >= 128 && nst % (2 * kGemmSeg) == 0;
     int best = 3;                                          // 64 x 64
-    if (blocks(0) >= 512) best = 0;                        // 128 x 128
+    if (blocks(0) >= 512) best = 0;                        // 128 x 128 (its segmented form: 248 VGPRs, still two waves per SIMD)
     else if (blocks(1) >= 384) best = 1;                   // 64 x 128
-    if (forced >= 0) best = forced;
+    if (forced >= 0 && !(seg && !kGemm[forced].kern_seg)) best = forced;
+    gemm_init();
+    if (seg) {
+      const bool fits = a.part && (long)kGemmSeg * a.rows * a.cout <= a.part_cap;
+      const int force = g_conv_override.splitk;           // tests (rvcx_conv_override): 1 never, >= 2 always
+      const bool split = fits && force != 1 && (force >= 2 || seg_mode == 3 || (seg_mode == 1 && blocks(best) < 512));
+      if (split) {      // the tile of the K-split form: the largest whose four-fold grid still covers the chip
+        static const int split_tile = getenv("RVCX_GEMM_SPLIT_TILE") ? atoi(getenv("RVCX_GEMM_SPLIT_TILE")) : -1;
+        // fc2 of a 30 s clip (tools/bench_gemm.py): 128 x 64 46.5 us, 128 x 128 51, 64 x 64 55, 64 x 128 56 (one workgroup per tile: 62 - 69)
+        best = kGemmSeg * blocks(2) >= 256 ? 2 : 3;
+        if (split_tile >= 0 && split_tile < kNumGemmTiles) best = split_tile;
+        if (forced >= 0) best = forced;
+      }
+      const GemmCfg& F = kGemm[best];
+      if (split) {
+        dim3 grid((unsigned)cdiv64(a.rows, F.bn), cdiv(a.cout_p, F.bm), kGemmSeg);
+        hipLaunchKernelGGL(F.kern_split, grid, dim3(256), F.lds, stream, a);
+        const long total = a.rows * (a.cout / 4);
+        hipLaunchKernelGGL(gemm_finish_kernel<kGemmSeg>, dim3((unsigned)std::min<long>(cdiv64(total, 256), 4096)), dim3(256), 0,
+                           stream, a);
+      } else {
+        dim3 grid((unsigned)cdiv64(a.rows, F.bn), cdiv(a.cout_p, F.bm), 1);
+        hipLaunchKernelGGL(F.kern_seg, grid, dim3(256), F.lds, stream, a);
+      }
+      RVCX_HIP(hipGetLastError());
+      return kGemmSlot0 + best;
+    }
     const GemmCfg& F = kGemm[best];
     dim3 grid((unsigned)cdiv64(a.rows, F.bn), cdiv(a.cout_p, F.bm), 1);
-    gemm_init();
     hipLaunchKernelGGL(F.kern, grid, dim3(256), F.lds, stream, a);
     RVCX_HIP(hipGetLastError());
     return kGemmSlot0 + best;

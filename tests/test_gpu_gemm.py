@@ -91,3 +91,32 @@ def test_layernorm_tm_vs_torch(ctx, rows, C):
     assert e < 1e-6, e
     if ysp is not None:
         assert np.abs(ysp - y).max() <= 2.0 ** -20 * np.abs(y).max()
+
+
+@pytest.mark.parametrize("B,T,cin,cout,act,use_res", [(1, 1599, 3072, 768, 0, True), (2, 100, 2048, 256, 3, False),
+                                                      (1, 40, 4096, 64, 0, True), (3, 700, 3072, 768, 0, True)])
+def test_long_k_layers_sum_in_segments_split_or_not(ctx, B, T, cin, cout, act, use_res):
+    """K >= 2048 (HuBERT fc2): the canonical order is four K segments, each summed from zero, added left to right.  One
+    workgroup per tile with a second accumulator set (what a batch runs) and four workgroups per tile + the finish pass (what an
+    underfilled single-utterance launch runs) give the same bits -- every output form -- and the torch result."""
+    from polgen_rvc_amd import _lib
+    g = np.random.Generator(np.random.PCG64(B * 100 + T + cin))
+    x = g.standard_normal((B, cin, T)).astype(np.float32)
+    w = (g.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32)
+    bias = g.standard_normal(cout).astype(np.float32)
+    res = g.standard_normal((B * T, cout)).astype(np.float32) if use_res else None
+    ref = _ref(x, w, bias, res, act)
+    try:
+        _lib.Context.conv_override(splitk=1)
+        one = ctx.gemm_tm(x, w, bias, res, act)
+        _lib.Context.conv_override(splitk=2)
+        four = ctx.gemm_tm(x, w, bias, res, act)
+    finally:
+        _lib.Context.conv_override()
+    auto = ctx.gemm_tm(x, w, bias, res, act)
+    e = rms(one[0] - ref) / rms(ref)
+    print(f"gemm_tm long K {B}x{T} {cin}->{cout}: rel err {e:.2e}")
+    assert np.isfinite(one[0]).all() and e < 2e-6
+    for a_, b_, c_ in zip(one, four, auto):
+        if a_ is not None:
+            assert np.array_equal(a_, b_) and np.array_equal(a_, c_)

@@ -25,4 +25,13 @@ if __name__ == "__main__":
             ms, tf = ctx.bench_gemm(rows, cin, cout, iters)
             tot_auto += ms
             print(line + f"auto {ms * 1e3:6.1f} us {tf:5.0f} TF/s ({tf / 833.3 * 100:4.1f} %)", flush=True)
+        # the long-K layer (fc2): K summed in four segments by one workgroup per tile (splitk=1) or by four (splitk=2)
+        for sk, what in ((1, "one workgroup per tile"), (2, "K-split x4 + finish")):
+            line = f"B={B} fc2 {what:24s}: "
+            for t, tn in enumerate(TILES):
+                _lib.Context.conv_override(tile=200 + t, splitk=sk)
+                ms, tf = ctx.bench_gemm(rows, 3072, 768, iters)
+                line += f"{tn} {ms * 1e3:6.1f} us | "
+            _lib.Context.conv_override()
+            print(line, flush=True)
         print(f"B={B}: one layer's four GEMMs {tot_auto * 1e3:.1f} us; x 12 layers = {tot_auto * 12:.2f} ms")
