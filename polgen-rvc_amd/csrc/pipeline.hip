@@ -825,7 +825,8 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   // HuBERT's stream: the decoder's first auxiliary stream, idle while the front end runs (no fifth stream: api.hip).
   // RVCX_HUBERT_ON=main: the main stream
   static const bool hub_on_main = getenv("RVCX_HUBERT_ON") && std::string(getenv("RVCX_HUBERT_ON")) == "main";
-  hipStream_t sh = (c.serial || hub_on_main) ? s : c.aux[0];
+  static const bool hub_on_aux1 = getenv("RVCX_HUBERT_ON") && std::string(getenv("RVCX_HUBERT_ON")) == "aux1";
+  hipStream_t sh = (c.serial || hub_on_main) ? s : (hub_on_aux1 ? c.aux[1] : c.aux[0]);
 
   // ---- chunk jobs of a micro-batch, grouped by chunk length (order of first appearance); group gi's HuBERT
   // features live at fr[k & 1].feats + feats_off[gi]
