@@ -13,6 +13,7 @@
 //    L2 (~7 us).
 //  * bigru_kernel: one workgroup per (direction, item), W_hh streamed from L2 every step.  Used when
 //    the cluster grid would not be co-resident (large batches) -- the cluster kernel spins.
+#include <mutex>
 #include "conv.h"
 #include "ops.h"
 #include <cstdio>
@@ -542,7 +543,29 @@ void launch_bigru(const float* gi, const float* whh_t, const float* bhh, float* 
     static const int form = getenv("RVCX_GRU_FORM") ? atoi(getenv("RVCX_GRU_FORM")) : 2;
     const int drop = g_gru_drop_member;
     g_gru_drop_member = 0;
-    if (nc == 4 && form == 1)
+    // RVCX_GRU_EXCL_KB: dynamic LDS (KB) requested on top of the kernel's own 6 KB, so that no LDS-using workgroup of another
+    // stream fits on a cluster member's CU.  HuBERT's tiles run beside the recurrence of a single clip and shared its 8 CUs:
+    // the step went from 1.02 us alone to ~1.37 us there (F0 branch 8.5 ms); with the members alone on their CUs the branch
+    // takes 7.95 ms and HuBERT, on 248 CUs, the same 4.6 (100 KB still lets a 33 KB GEMM tile in: no effect).  B <= 2 only:
+    // the latency-bound case (a batch's recurrences are many clusters and throughput-bound).  0 = off.
+    static const int excl_kb = getenv("RVCX_GRU_EXCL_KB") ? atoi(getenv("RVCX_GRU_EXCL_KB")) : 140;
+    const size_t dyn = (excl_kb > 0 && B <= 2) ? (size_t)excl_kb * 1024 : 0;
+    if (dyn) {
+      static std::mutex mu;
+      static uint64_t done = 0;
+      int dev = 0;
+      RVCX_HIP(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> g(mu);
+      if (!((done >> (dev & 63)) & 1)) {
+        RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bigru_unit_kernel<4, 32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        done |= 1ull << (dev & 63);
+      }
+    }
+    if (nc == 4 && form == 2 && dyn)
+      hipLaunchKernelGGL((bigru_unit_kernel<4, 32>), dim3(grid), dim3(GruUnitGeom<4, 32>::THREADS), dyn, stream, gi, whh_t, bhh,
+                         y, xbuf, err, T, nq, colocate, lens, drop);
+    else if (nc == 4 && form == 1)
       hipLaunchKernelGGL((bigru_unit_kernel<4, 64>), dim3(grid), dim3(GruUnitGeom<4, 64>::THREADS), 0, stream, gi, whh_t, bhh,
                          y, xbuf, err, T, nq, colocate, lens, drop);
     else if (nc == 4 && form == 2)
