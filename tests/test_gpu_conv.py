@@ -351,3 +351,24 @@ def test_convblockres_through_the_models_block_path(ctx, B, C, H, W, ragged):
     print(f"B={B} C={C} {H}x{W} ragged={ragged}: vs torch {e:.2e}; equal to the tiled kernels: {np.array_equal(got, tiled)}")
     assert e < 2e-6
     assert np.array_equal(got, tiled)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 32, 16, 404, 128), (2, 64, 32, 330, 64), (1, 1, 16, 300, 128)])
+def test_convblockres_with_the_1x1_shortcut(ctx, B, Cin, Cout, H, W):
+    """The first block of a U-Net level changes the channel count: ConvBlockRes adds ``shortcut(x)`` (a 1 x 1 conv,
+    RMVPE.py:158-175) instead of x.  32 -> 16 is the decoder's level 0 (the streaming kernel's Cin = 32 / Cout = 16 form feeds
+    the split hand-off), 1 -> 16 the encoder's first block (the Cin = 1 FIR kernel)."""
+    g = torch.Generator().manual_seed(B * 31 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    w2 = torch.randn(Cout, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5
+    wsc = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b1, b2, bsc = (torch.randn(Cout, generator=g) for _ in range(3))
+    t = F.relu(F.conv2d(x, w1, b1, padding=1))
+    ref = F.relu(F.conv2d(t, w2, b2, padding=1)) + F.conv2d(x, wsc, bsc)
+    got = ctx.convblock2d(x.numpy(), w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), wsc=wsc.numpy().reshape(Cout, Cin),
+                          bsc=bsc.numpy())
+    # (no bit comparison with a forced tile here: the override would also take the 1 x 1 shortcut off its split-fp16 tile)
+    e = rms(got - ref.numpy()) / rms(ref.numpy())
+    print(f"B={B} {Cin}->{Cout} {H}x{W}: vs torch {e:.2e}")
+    assert np.isfinite(got).all() and e < 2e-6
