@@ -50,8 +50,11 @@ C3_BATCH = 64
 C3_INDEX_ROWS = 65536
 C5_UTTERANCES = 256
 CPU_SAMPLE_SECONDS = 30.0    # the clip the metric is quoted on (attention is O(T^2): a shorter sample would flatter the CPU)
-PMC_FILES = ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json")     # newest first
+PMC_FILES = ("pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json")     # newest first
 WORKER_DEADLINE_S = 3600.0   # launch_workers: the whole multi-rank run
+# algorithmic HBM bytes of one launch of the dominant kernel (fused ResBlock step, NSF stage 2 of a 32 s chunk at 48 k:
+# C = 128 channels x 383 760 positions x 4 B, read x once + write y once); DESIGN.md "Algorithmic work per unit"
+DOM_ALGO_BYTES_PER_LAUNCH = 2 * 128 * 383760 * 4
 PEAK_FILE = "mfma_peak_r04.json"   # profiles/: measured split-fp16 ceiling on random operands (tools/mfma_peak.hip)
 
 
@@ -377,7 +380,7 @@ def main():
         raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
     if a.dry_run:
         return dry_run(a, rank, world)
-    fp32 = c3_obj = c5_obj = out_obj = None
+    fp32 = c3_obj = c5_obj = out_obj = dec_out_obj = long_obj = None
     if world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe and not a.hubert_outliers:
         fp32 = exact_fp32_child(a.steps, a.warmup)       # all before the first GPU call of this process
         out_obj = outliers_child(a.steps, a.warmup)
@@ -586,8 +589,34 @@ def main():
                                      dict(roofline["most_time"], bound="mfma", peak=roofline["peak"], unit="TFLOP/s",
                                           dominant_by="time in the serial profile step"))),
                "conv_tiles": prof}
+        # ---- driver-visible peers: the driver keeps `config` whole and reduces the rich child objects
+        # below to their names, so the scalar every reader needs from each of them is repeated here
+        cfgd = res["config"]
+
+        def _val(o, *path):
+            for k in path:
+                o = o.get(k) if isinstance(o, dict) else None
+            return o
+        cfgd["exact_fp32_value"] = _val(fp32, "value")
+        cfgd["exact_fp32_roofline_frac"] = _val(fp32, "roofline", "frac")
+        cfgd["sustained_value"] = _val(sustained, "value")
+        cfgd["outliers_value"] = _val(out_obj, "value")
+        cfgd["decoder_outliers_value"] = _val(dec_out_obj, "value")
+        cfgd["decoder_outliers_fp32_layers"] = _val(dec_out_obj, "fast_path", "fp32_layers")
+        cfgd["c3_value"] = _val(c3_obj, "value")
+        cfgd["c3_roofline_frac"] = _val(c3_obj, "roofline", "frac")
+        cfgd["c5_value"] = _val(c5_obj, "value")
+        cfgd["long_clip_value"] = _val(long_obj, "value")
+        cfgd["roofline_traffic_ratio"] = (None if roofline is None or not roofline.get("traffic") else
+                                          roofline["traffic"] / DOM_ALGO_BYTES_PER_LAUNCH)
+        cfgd["roofline_traffic_ratio_note"] = ("PMC bytes per launch of the dominant kernel / its algorithmic bytes "
+                                               "(read x + write y of a C=128 stage-2 step: 2 x 196.5 MB)")
         if fp32 is not None:
             res["exact_fp32"] = fp32
+        if dec_out_obj is not None:
+            res["decoder_outliers"] = dec_out_obj
+        if long_obj is not None:
+            res["long_clip"] = long_obj
         if out_obj is not None:
             res["outliers"] = out_obj
         if c3_obj is not None:

@@ -290,7 +290,9 @@ int rvcx_last_timing(rvcx_ctx*, float* ms9);
  * every conv launch on the library stream; begin=0 stops and returns, per tile configuration
  * (kind: -1 generic strided kernel, halo*10 for the stride-1
  * family, 100000/100001 its Linear variants), the launch count, algorithmic FLOPs (2*M*N*K of the unpadded problem) and the
- * summed kernel milliseconds, plus the tile shape (bm x bn). */
+ * summed kernel milliseconds, plus the tile shape (bm x bn).
+ * The profile is PROCESS-wide: the two hooks serialise against each other, but launches of any other context of the
+ * process that run while a profile is open are recorded into it -- profile with one context active. */
 int rvcx_conv_profile(rvcx_ctx*, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
                       int32_t* bn, int32_t* kind, int cap);
 /* per-launch table (CSV text: tile,B,cin,cout,k,stride,nout,gflop,ms,tflops) of the last profile */

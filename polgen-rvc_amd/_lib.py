@@ -162,9 +162,9 @@ def flac_decode(data: bytes):
     frames, ch, sr, bits = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
     if lib().rvcx_flac_info(buf.ctypes.data, buf.shape[0], C.byref(frames), C.byref(ch), C.byref(sr), C.byref(bits)) != 0:
         raise RvcxError((lib().rvcx_flac_last_error() or b"").decode())
-    total = int(frames.value)
-    if total == 0:          # unknown length in STREAMINFO (streamed files): an upper bound from the byte count
-        total = max(1, buf.shape[0]) * 8
+    # rvcx_flac_info counts the frames itself when STREAMINFO leaves the total at 0 (streamed encodes) and refuses totals
+    # that are implausible for the byte count, so this allocation is exact and bounded by the stream's size
+    total = max(1, int(frames.value))
     out = np.empty((total, ch.value), np.int32)
     n = lib().rvcx_flac_decode_s32(buf.ctypes.data, buf.shape[0], out.ctypes.data, out.size)
     if n < 0:
@@ -827,7 +827,7 @@ class Context:
             if kd[i] == 300001:
                 return "conv_cout1 (vector FMA, Cout=1)"
             if kd[i] == 300003:
-                return "conv_deep<64,32> (long K, few positions: split-K inside the workgroup)"
+                return "conv_ws<64,320> (weight-stationary tile: a stage = one 16-channel chunk x all taps; K segments + finish)"
             if kd[i] == 300004:
                 return "conv3_thin (3x3, C=16/32: streaming MFMA, B operand from global, DPP-shifted taps)"
             if kd[i] == 300002:

@@ -82,6 +82,7 @@ static int api_call(rvcx_ctx* ctxp, bool repeat, F&& body) {
   try {
     if (!C) fail("null context");
     RVCX_HIP(hipSetDevice(C->device));
+    if (!repeat) C->arena_budget = 0;     // loads / unloads change what is free: convert_micro_batch probes again
     const int last = repeat ? kMaxAttempts - 1 : 0;
     bool gru_plain = false;
     for (int attempt = 0; attempt <= last; ++attempt) {
@@ -131,7 +132,10 @@ static bool debug_hooks_enabled() {
 #define REQUIRE_DEBUG(ctxp, name)                                                             \
   if (!debug_hooks_enabled()) {                                                               \
     g_last_error = name ": debug / tuning hook refused (start the process with RVCX_DEBUG=1)"; \
-    if ((ctxp) != nullptr) ((rvcx_ctx*)(ctxp))->c.last_error = g_last_error;                        \
+    if ((ctxp) != nullptr) {                                                                  \
+      CtxLock dbg_guard_ = lock_ctx((rvcx_ctx*)(ctxp));                                       \
+      ((rvcx_ctx*)(ctxp))->c.last_error = g_last_error;                                       \
+    }                                                                                         \
     return -2;                                                                                \
   }
 
@@ -458,7 +462,7 @@ int rvcx_op_resblock3(rvcx_ctx* ctx, const float* x, const float* w1, const floa
     a.w2[s] = (L2[s].w_h3 && *L2[s].h3_ok) ? L2[s].w_h3 : nullptr;
     a.b1[s] = L1[s].bias;
     a.b2[s] = L2[s].bias;
-    a.dil[s] = dils[s];
+    a.dil[s] = dils ? dils[s] : 2 * s + 1;       // NULL: ResBlock1's own dilations (1, 3, 5), residuals.py:15-62
   }
   a.ovf_layer = L1[0].ovf_word;
   a.lens = dl;
@@ -1700,8 +1704,13 @@ int rvcx_vc(rvcx_ctx* ctx, int model_id, const float* audio0, int64_t n, const i
   API_END
 }
 
+// The per-launch profile is PROCESS-wide state (conv.hip): the two hooks below serialise against each other on one mutex, but
+// launches of ANOTHER context that run while a profile is open are recorded into it too (rvcx.h says so).
+static std::mutex g_profile_mu;
+
 int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops, double* ms, int32_t* bm,
                       int32_t* bn, int32_t* kind, int cap) {
+  std::lock_guard<std::mutex> prof_guard(g_profile_mu);
   API_BEGIN_ONCE(ctx)
   C->serial = begin != 0 || C->serial_env;
   if (begin) {
@@ -1721,7 +1730,10 @@ int rvcx_conv_profile(rvcx_ctx* ctx, int begin, int64_t* launches, double* flops
   API_END
 }
 
-const char* rvcx_conv_profile_csv(rvcx_ctx*) { return conv_profile_csv(); }
+const char* rvcx_conv_profile_csv(rvcx_ctx*) {
+  std::lock_guard<std::mutex> g(g_profile_mu);
+  return conv_profile_csv();
+}
 
 int rvcx_last_timing(rvcx_ctx* ctx, float* ms9) {
   CtxLock ctx_guard_ = lock_ctx(ctx);

@@ -1,22 +1,31 @@
-// Convs with a long K and few output positions -- the deep levels of the RMVPE U-Net (rvc/lib/predictors/RMVPE.py:140-320:
-// 3 x 3 convs with 128 / 256 / 512 channels on 7488 / 2080 / 624 positions, ~60 launches per clip) and their 2 x 2
-// polyphase ConvTranspose2d -- with the split-K INSIDE the workgroup.
+// conv_ws: a WEIGHT-STATIONARY large-tile form of the split-fp16 conv for the layers the 64 x 64 tile serves worst --
+// the deep levels of the RMVPE U-Net (rvc/lib/predictors/RMVPE.py:140-320: 3 x 3 convs with 64 ... 512 channels on 28 288 ...
+// 624 positions and their 2 x 2 polyphase ConvTranspose2d, ~90 launches per clip, each on a 24 - 41 us floor whatever its
+// shape) -- round 6, replaces round 5's conv_deep_kernel (split-K across the waves of a 64 x 32 tile, both operands
+// straight from global memory: measured slower, it re-read 380 MB of operands per conv through the L2 -> CU path).
 //
-// On the general tile (conv_h3<64,64>) every one of these launches cost 24 - 41 us whatever its shape and split-K factor
-// (round 4: "the floor"): a workgroup is a serial chain of load -> LDS -> barrier -> MFMA stages, the K = 1152 ... 4608
-// reduction is spread over 8 workgroups per output tile that meet again in a second launch (conv_splitk_finish_kernel:
-// 70 launches of 8 us per clip), and at B = 1 there are too few positions to hide any of it.  Here a workgroup of W = 8 or 16
-// waves owns a 64 x 32 output tile and the WAVES split K: wave w walks its own contiguous range of (chunk, tap) k-steps,
-// loading both MFMA operands straight from global memory into registers (weights: the fragment-ordered hi/lo image, 16
-// bytes per lane; input: eight coalesced dword loads per lane, converted in registers) -- no LDS staging, no barrier in the
-// k-loop, requests one group of k-steps ahead (the pattern the wait-count insertion handles: convt_thin.hip).  The W
-// partial tiles meet in LDS, are summed in a fixed order (wave 0, 1, ...: deterministic, and the same for every batch size:
-// W depends on the layer's shape only) and leave through the common epilogue (bias, activation, residual, length and
-// pad-column masks, shuffle stores).  One launch per conv, no partial-sum slabs in HBM.
+// What bounded those launches (LABNOTES "Round 5", conv_h3.hip's tile table): a 64 x 64 output tile needs (64 + 64) x K
+// operand values, so a K = 4608 conv over 624 positions moves 190 MB from L2 to the CUs for 2.9 GFLOP; a wave owns ONE 32 x 32
+// accumulator, i.e. four LDS fragment reads and three DEPENDENT MFMAs per k-step (1.33 reads per MFMA: LDS-bound, and with one
+// wave per SIMD every k-step is a serial read -> MFMA -> MFMA -> MFMA chain); a stage is 12 MFMAs between two barriers.
+// Here a workgroup owns 64 output channels x 320 positions (four waves as 2 x 2, a wave = 32 channels x FIVE 32-position
+// blocks): per k-step two weight-fragment reads + ten input-fragment reads feed fifteen MFMAs on five independent
+// accumulators (0.8 reads per MFMA); a stage is one 16-channel chunk x ALL taps (135 MFMAs per wave at 3 x 3) in a
+// double-buffered LDS ring, one barrier per stage, the next stage's operands requested before the stage's MFMAs start.
+// Operand traffic per conv falls 6x (weights once per 320 positions instead of once per 64).
+//
+// K is cut into S segments of nchunk / S chunks -- S a function of the layer's SHAPE only (never of the batch size: the
+// summation order is part of the result): each segment is accumulated from zero, the segment sums are added left to
+// right.  A launch that fills the chip without it (a batch) walks the S segments inside one workgroup (FUSED: a second
+// accumulator set, the common epilogue, no second launch); an underfilled one (a single clip) gives them to S workgroups
+// (blockIdx.z) and conv_splitk_finish_kernel adds the slabs in the same order: bit-identical, so a batched conversion
+// still equals its single runs.  The k-order inside a segment (chunk-major, taps ascending, hh / hl / lh per tap) is
+// conv_h3's: with equal segment bounds the two kernels agree bit for bit (tests/test_gpu_round6.py).
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "conv.h"
 #include "conv_device.h"
@@ -26,159 +35,275 @@ namespace rvcx {
 
 namespace {
 
-// W waves; kG k-steps per request; MB 32-row blocks of output channels per workgroup (tile 32 MB x 32)
-// DB: double-buffered requests (one group in flight while one is computed); false: request a group of kG steps, wait, compute it
-// -- a wave then pays one operand round trip per kG steps, and the other waves of the CU fill its wait
-template <int W, int kG, int MB, bool DB = true>
-__global__ __launch_bounds__(64 * W) void conv_deep_kernel(const ConvArgs a) {
-  extern __shared__ float red[];                  // [W][MB][16][64] partial accumulators
-  const int tid = threadIdx.x, lane = tid & 63;
-#if defined(__HIP_DEVICE_COMPILE__)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the k-step bookkeeping stays on the scalar unit
-#else
-  const int wave = tid >> 6;
-#endif
+constexpr int kWsBM = 64, kWsNB = 5, kWsBN = 2 * kWsNB * 32;     // 64 x 320
+constexpr int kWsMaxHalo = 96;
+
+// compile-time loop over the accumulator blocks: a `#pragma unroll` loop around the inlined epilogues is silently left
+// rolled (-Wno-pass-failed), the accumulators are then indexed at run time and live in scratch (LABNOTES, round 5)
+template <typename F, int... N>
+__device__ __forceinline__ void ws_for_blocks(std::integer_sequence<int, N...>, F&& f) {
+  (f(std::integral_constant<int, N>{}), ...);
+}
+
+// KS: taps (compile time: the stage loop is straight-line); MODE 0: one K segment per workgroup (blockIdx.z), raw sums to the
+// split-K slabs; 1: one workgroup per tile, a single segment (S = 1) + epilogue; 2: one workgroup walks the S segments
+// (a second accumulator set) + epilogue
+template <int KS, int MODE>
+__global__ __launch_bounds__(256, 1) void conv_ws_kernel(const ConvArgs a) {
+  constexpr bool FUSED = MODE != 0, MULTI = MODE == 2;
+  extern __shared__ uint4 ws_lds[];
+  constexpr int NB = kWsNB, BN = kWsBN;
+  constexpr int A_ST = KS * 4 * kWsBM;                 // 16-byte elements of one weight stage: [tap][op {S wh, S wl}][h][co]
+  const int wrow = BN + a.wrow;                        // input-tile columns (halo = a.wrow <= kWsMaxHalo)
+  const int B_ST = 4 * wrow;                           // [op {hi, S lo}][h][p]
+  // (LDS is always addressed as ws_lds[offset]: a pointer table would be a generic-address-space initialiser)
+  auto a_base = [&](int buf) { return buf * A_ST; };
+  auto b_base = [&](int buf) { return 2 * A_ST + buf * B_ST; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z;
-  const int n0 = blockIdx.x * 32, co0 = blockIdx.y * (32 * MB);
+  const int bz = blockIdx.z;
+  const int b = FUSED ? bz : bz / a.splitk, ks = FUSED ? 0 : bz - b * a.splitk;
+  const int co0 = blockIdx.y * kWsBM, n0 = blockIdx.x * BN;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Tin;
   const int len_out = a.lens_out ? a.lens_out[b] : 0x7fffffff;
-  const bool dead = n0 >= len_out && a.out_mode == OUT_NORMAL;     // every output of the tile is masked: nothing to compute
+  const bool dead = (a.out_mode == OUT_SHUF1D ? n0 * a.sh_s - a.sh_pad : n0) >= len_out;
   const int nchunk = a.Cin_gp / 16;
-  const int KS = a.ksize * nchunk;                // k-steps of the layer, step s = chunk * ksize + tap
-  const int per = (KS + W - 1) / W;
-  const int s_begin = wave * per, s_end = min(KS, s_begin + per);
-  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_gp * a.x_cs * 4);
-  const H3Rsrc wr = h3_rsrc(a.w_h3, a.ksize * nchunk * 4 * a.Cout_gp * 16);
+  const int in_base = n0 + a.off_min;
+  const int pre_act = a.pre_act;
+  const float pre_slope = a.pre_slope;
+  const H3Rsrc xr = h3_rsrc(a.x + (long)b * a.x_bs, a.Cin_g * a.x_cs * 4);
+  const H3Rsrc wres = h3_rsrc(a.w_h3, KS * nchunk * 4 * a.Cout_gp * 16);
+  const int slab = 4 * a.Cout_gp * 16;                 // bytes of one (tap, chunk) weight slab
   const int xrow = a.x_cs * 4;
-  const int slab = 4 * a.Cout_gp * 16;            // bytes of one (tap, chunk) weight slab: [op][h][co] 16-byte elements
-  constexpr float inv = 1.f / kH3Scale;
-  bool ovf = false;
 
-  float rawb[DB ? 2 : 1][kG][8];
-  uint4 rawa[DB ? 2 : 1][kG][MB][2];              // [buf][step][m][op]
-  // requests are issued for consecutive steps: (chunk, tap row, tap column) of the next step to request are counters
-  int rs = s_begin, rchunk = s_begin / a.ksize, rkk = s_begin - rchunk * a.ksize, rky = rkk / a.kw, rkx = rkk - rky * a.kw;
-  auto request = [&](auto buf_tag) {
-    constexpr int buf = decltype(buf_tag)::value;
+  // weights: thread t stages element (op*2 + h = t / 64, co = t % 64) of every tap
+  const int a_off = co0 + (tid & 63) < a.Cout_gp ? ((tid >> 6) * a.Cout_gp + co0 + (tid & 63)) * 16 : kH3Oob;
+  // input: task t = tid + 256 j -> (h, p): 8 channels of one position
+  constexpr int NBT = (2 * (BN + kWsMaxHalo) + 255) / 256;
+  int b_off[NBT], b_row[NBT];
 #pragma unroll
-    for (int g = 0; g < kG; ++g) {
-      const int s = rs;
-      const bool live = s < s_end && !dead;
-      const int chunk = rchunk, kk = rkk;
-      const int pos = n0 + i + rky * a.rowpitch + rkx * a.dil - a.pad;
-      ++rs;
-      ++rkk;
-      if (++rkx == a.kw) {
-        rkx = 0;
-        ++rky;
-      }
-      if (rkk == a.ksize) {
-        rkk = rky = rkx = 0;
-        ++rchunk;
-      }
-      const bool okx = live && pos >= 0 && pos < len_in;
-      const int xb = (chunk * 16 + 8 * h) * xrow + pos * 4;
+  for (int j = 0; j < NBT; ++j) {
+    const int t = tid + 256 * j;
+    const int hh = t / wrow, p = t - hh * wrow;
+    const int pos = in_base + p;
+    b_row[j] = hh * 8;
+    b_off[j] = (t < 2 * wrow && pos >= 0 && pos < len_in) ? pos * 4 : kH3Oob;
+  }
+  // tap offsets inside the staged tile
+  int tp[KS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rawb[buf][g][j] = h3_load1(xr, okx ? xb + j * xrow : kH3Oob);
-      const int wb = (kk * nchunk + chunk) * slab + (h * a.Cout_gp + co0 + i) * 16;
+  for (int kk = 0; kk < KS; ++kk) tp[kk] = (kk / a.kw) * a.rowpitch + (kk % a.kw) * a.dil - a.pad - a.off_min;
+
+  uint4 ra[KS];
+  float rb[NBT][8];
+  bool ovf = false;
+  auto fetch = [&](int chunk) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
+    for (int kk = 0; kk < KS; ++kk) ra[kk] = h3_load4(wres, a_off != kH3Oob ? (kk * nchunk + chunk) * slab + a_off : kH3Oob);
 #pragma unroll
-        for (int op = 0; op < 2; ++op)
-          rawa[buf][g][m][op] = h3_load4(wr, live ? wb + (op * 2 * a.Cout_gp + m * 32) * 16 : kH3Oob);
+    for (int j = 0; j < NBT; ++j) {
+      const int row0 = (chunk * 16 + b_row[j]) * xrow;     // rows >= Cin_g read as 0 (beyond num_records)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rb[j][q] = h3_load1(xr, b_off[j] == kH3Oob ? kH3Oob : row0 + q * xrow + b_off[j]);
     }
   };
-  f32x16 acc[MB];
+  auto commit = [&](int buf) {
 #pragma unroll
-  for (int m = 0; m < MB; ++m)
+    for (int kk = 0; kk < KS; ++kk) ws_lds[a_base(buf) + kk * 256 + tid] = ra[kk];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-  auto compute = [&](auto buf_tag) {
-    constexpr int buf = decltype(buf_tag)::value;
+    for (int j = 0; j < NBT; ++j) {
+      const int t = tid + 256 * j;
+      if (t < 2 * wrow) {
+        half8 hi, lo;
 #pragma unroll
-    for (int g = 0; g < kG; ++g) {
-      half8 xh, xl;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = rawb[buf][g][j];
-        ovf |= !(fabsf(v) < kH3ActLimit);
-        const _Float16 vh = (_Float16)v;
-        xh[j] = vh;
-        xl[j] = (_Float16)((v - (float)vh) * kH3Scale);
-      }
-#pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const half8 whs = __builtin_bit_cast(half8, rawa[buf][g][m][0]);
-        const half8 wls = __builtin_bit_cast(half8, rawa[buf][g][m][1]);
-        const half8 wh = whs * (_Float16)inv;
-        acc[m] = h3_mfma(whs, xh, acc[m]);        // (S wh) xh
-        acc[m] = h3_mfma(wh, xl, acc[m]);         // wh (S xl)
-        acc[m] = h3_mfma(wls, xh, acc[m]);        // (S wl) xh
+        for (int q = 0; q < 8; ++q) {
+          float v = rb[j][q];
+          if (pre_act == ACT_LRELU) v = v > 0.f ? v : v * pre_slope;
+          ovf |= !(fabsf(v) < kH3ActLimit);
+          const _Float16 vh = (_Float16)v;
+          hi[q] = vh;
+          lo[q] = (_Float16)((v - (float)vh) * kH3Scale);
+        }
+        const int hh = t / wrow, p = t - hh * wrow;
+        ws_lds[b_base(buf) + hh * wrow + p] = __builtin_bit_cast(uint4, hi);
+        ws_lds[b_base(buf) + (2 + hh) * wrow + p] = __builtin_bit_cast(uint4, lo);
       }
     }
   };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  // groups of kG steps, double-buffered: request the next group, compute the current one ("everything but the request
-  // just issued": the wait the compiler can count); steps past the wave's range load nothing and add zeros
-  if constexpr (DB) {
-    request(B0{});
-    for (int s = s_begin; s < s_end; s += 2 * kG) {
-      request(B1{});
-      compute(B0{});
-      request(B0{});
-      compute(B1{});
+  auto lds_barrier = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+  };
+
+  f32x16 acc[NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  };
+  zero_acc();
+  auto compute = [&](int buf) {
+    const uint4* Ab = ws_lds + a_base(buf);
+    const uint4* Bb = ws_lds + b_base(buf);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const half8 af0 = __builtin_bit_cast(half8, Ab[(kk * 4 + 0 + h) * kWsBM + wr * 32 + i]);
+      const half8 af2 = __builtin_bit_cast(half8, Ab[(kk * 4 + 2 + h) * kWsBM + wr * 32 + i]);
+      const half8 af1 = af0 * (_Float16)(1.f / kH3Scale);
+      half8 bf0[NB], bf1[NB];
+      const int col = wc * (NB * 32) + i + tp[kk];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        bf0[n] = __builtin_bit_cast(half8, Bb[h * wrow + col + n * 32]);
+        bf1[n] = __builtin_bit_cast(half8, Bb[(2 + h) * wrow + col + n * 32]);
+      }
+      // per accumulator the order is conv_h3's (hh, hl, lh); across the five accumulators the MFMAs are independent
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] = h3_mfma(af0, bf0[n], acc[n]);   // (S wh) xh
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] = h3_mfma(af1, bf1[n], acc[n]);   // wh (S xl)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] = h3_mfma(af2, bf0[n], acc[n]);   // (S wl) xh
     }
-  } else {
-    for (int s = s_begin; s < s_end; s += kG) {
-      request(B0{});
-      compute(B0{});
+  };
+
+  // segment bounds exactly as conv_h3's split-K: segment s = chunks [s nchunk / S, (s + 1) nchunk / S)
+  const int S = MODE == 1 ? 1 : a.splitk;
+  const int c_begin = FUSED ? 0 : ks * nchunk / S, c_end = FUSED ? nchunk : (ks + 1) * nchunk / S;
+  f32x16 tot[MULTI ? NB : 1];      // the running sum of the finished segments, from zero like the finish kernel's
+#pragma unroll
+  for (int n = 0; n < (MULTI ? NB : 1); ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[n][r] = 0.f;
+  if (!dead) {
+    fetch(c_begin);
+    commit(0);
+    lds_barrier();
+    int seg = 0, seg_end = FUSED ? nchunk / S : c_end;      // FUSED: first chunk behind the current segment
+    for (int c = c_begin; c < c_end; ++c) {
+      const int buf = (c - c_begin) & 1;
+      if (c + 1 < c_end) fetch(c + 1);
+      compute(buf);
+      if (c + 1 < c_end) commit(buf ^ 1);
+      lds_barrier();
+      if constexpr (MULTI) {
+        if (c + 1 == seg_end) {                   // a segment ends: fold its sum (left to right), start the next from zero
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[n][r] += acc[n][r];
+          zero_acc();
+          ++seg;
+          seg_end = (seg + 1) * nchunk / S;
+        }
+      }
+    }
+    if constexpr (MULTI) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] = tot[n];
     }
   }
   if (ovf) report_h3_overflow(a.ovf, a.ovf_layer, a.seq);
-  // ---- the W partial tiles meet in LDS
+  constexpr float inv = 1.f / kH3Scale;
 #pragma unroll
-  for (int m = 0; m < MB; ++m)
+  for (int n = 0; n < NB; ++n)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[((wave * MB + m) * 16 + r) * 64 + lane] = acc[m][r];
-  __syncthreads();
-  // thread t sums element t (and t + 64 W, ...) of the MB x 16 x 64 tile over the waves in order, then the common epilogue
-  for (int e = tid; e < MB * 16 * 64; e += 64 * W) {
-    float v = 0.f;
+    for (int r = 0; r < 16; ++r) acc[n][r] *= inv;
+
+  const int co_w = co0 + wr * 32 + 4 * h, nn_w = n0 + wc * (NB * 32) + i;
+  if constexpr (!FUSED) {
+    float* pb = a.part + ((long)ks * a.B + b) * a.Cout_g * a.Nout;      // the slab layout of conv_h3's split-K
 #pragma unroll
-    for (int w = 0; w < W; ++w) v += red[w * (MB * 16 * 64) + e];
-    const int ln = e & 63, r = (e >> 6) & 15, m = e >> 10;
-    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-    const int nn = n0 + (ln & 31);
-    if (co < a.Cout_g && nn < a.Nout) store_elem(a, b, co, nn, v * inv, len_out);
+    for (int n = 0; n < NB; ++n) {
+      const int nn = nn_w + n * 32;
+      if (nn < a.Nout) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_w + (r & 3) + 8 * (r >> 2);
+          if (co < a.Cout_g) pb[(long)co * a.Nout + nn] = acc[n][r];
+        }
+      }
+    }
+  } else {
+    using Blocks = std::make_integer_sequence<int, NB>;
+    if (fast_epilogue_ok(a)) {
+      ws_for_blocks(Blocks{}, [&](auto nt) { store_tile_fast(a, b, co_w, nn_w + nt.value * 32, acc[nt.value], len_out); });
+    } else if (a.out_mode == OUT_SHUF1D) {
+      ws_for_blocks(Blocks{}, [&](auto nt) { store_tile_shuf1d(a, b, co_w, nn_w + nt.value * 32, acc[nt.value], len_out); });
+    } else {
+      ws_for_blocks(Blocks{}, [&](auto nt) { store_tile(a, b, 0, co_w, nn_w + nt.value * 32, acc[nt.value], len_out); });
+    }
   }
+}
+
+struct WsKern {
+  int ks;
+  void (*split)(const ConvArgs);
+  void (*single)(const ConvArgs);
+  void (*multi)(const ConvArgs);
+};
+template <int KS>
+constexpr WsKern ws_kern() {
+  return {KS, conv_ws_kernel<KS, 0>, conv_ws_kernel<KS, 1>, conv_ws_kernel<KS, 2>};
+}
+const WsKern kWs[] = {ws_kern<3>(), ws_kern<4>(), ws_kern<5>(), ws_kern<7>(), ws_kern<9>(), ws_kern<11>()};
+
+size_t ws_lds_bytes(int ks, int halo) { return (size_t)2 * (ks * 4 * kWsBM + 4 * (kWsBN + halo)) * 16; }
+
+int ws_mode() {      // 0 off; 1 (default): the 2-D maps of the F0 U-Net; 2: + the 1-D layers with >= 64 k-steps (tuning)
+  static const int m = getenv("RVCX_CONV_WS") ? atoi(getenv("RVCX_CONV_WS")) : 1;
+  return m;
 }
 
 }  // namespace
 
+// the number of K segments of a layer: a function of its shape (channels, taps, positions PER ITEM) only
+int conv_ws_segments(const ConvArgs& a) {
+  const int nchunk = a.Cin_gp / 16;
+  const long base = (long)(a.Cout_gp / kWsBM) * cdiv(a.Nout, kWsBN);
+  int S = 1;
+  while (base * S < 192 && S < 16 && nchunk % (2 * S) == 0 && nchunk / (2 * S) >= 1) S *= 2;
+  if (g_conv_override.splitk > 0 && nchunk % g_conv_override.splitk == 0) S = g_conv_override.splitk;   // tests
+  return S;
+}
+
 bool conv_deep_ok(const ConvArgs& a) {
-  // OFF by default: measured (round 5, tools/bench_deep.py and the C2 bench, one box) it does not break the floor it was
-  // built against -- 512 -> 512 on 624 positions 41 -> 48 us, 256 -> 256 on 2080 31 -> 24, 128 -> 128 on 7488 33 -> 31; F0 stage
-  // 8.46 -> 8.61 ms.  Cutting the dependent round trips per wave from 18 to 3 (forms 2 / 3: six or four k-steps per request)
-  // made it SLOWER (59 / 37 / 30 us), which names the real bound: L2 -> CU operand traffic.  With N = 624 positions no tiling
-  // has both enough workgroups and enough reuse -- a 64 x 32 tile without LDS sharing re-reads 2 x 590 KB of operands per
-  // workgroup (380 MB per conv), the 64 x 64 LDS tile 190 MB: 20 - 40 us at the ~10 TB/s the L2s deliver, whatever the schedule.
-  // RVCX_CONV_DEEP=1 turns it on (tests/test_gpu_modes.py keeps it correct).
-  static const bool on = getenv("RVCX_CONV_DEEP") && atoi(getenv("RVCX_CONV_DEEP")) != 0;
-  static const int max_n = getenv("RVCX_CONV_DEEP_N") ? atoi(getenv("RVCX_CONV_DEEP_N")) : 8192;
-  if (!on || !a.w_h3 || !conv_h3_enabled()) return false;
-  if (a.groups != 1 || a.stride != 1 || a.Cin_gp % 16 != 0 || a.Cout_gp % 64 != 0 || a.Cin_g != a.Cin_gp) return false;
-  if (a.x_split || a.y_split || a.pre_act != ACT_NONE || a.acc2_mode != ACC2_NONE || a.nz_har) return false;
-  if (!(a.out_mode == OUT_NORMAL || a.out_mode == OUT_SHUF2D)) return false;
-  // a long reduction over few positions PER ITEM (the decision must not depend on the batch size: the summation order is
-  // part of the result) -- 2-D maps only (kw < ksize): the 1-D layers of this size are served by the time-major GEMM path
-  if (a.kw >= a.ksize || a.Nout > max_n || a.ksize * (a.Cin_gp / 16) < 64) return false;
+  const int mode = g_conv_override.tile == 163 ? 2 : (g_conv_override.tile >= 0 ? 0 : ws_mode());    // tile 163: forced (tests / tools)
+  if (mode == 0 || !a.w_h3 || !conv_h3_enabled()) return false;
+  if (a.groups != 1 || a.stride != 1 || a.Cin_gp % 16 != 0 || a.Cout_gp % kWsBM != 0 || a.Cin_g != a.Cin_gp) return false;
+  if (a.x_split || a.y_split || a.nz_har || !a.x) return false;
+  if (a.pre_act != ACT_NONE && a.pre_act != ACT_LRELU) return false;
+  bool have = false;
+  for (const auto& k : kWs) have |= k.ks == a.ksize;
+  if (!have) return false;
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int kk = 0; kk < a.ksize; ++kk) {
+    lo = std::min(lo, conv_tap_off(a, kk));
+    hi = std::max(hi, conv_tap_off(a, kk));
+  }
+  if (hi - lo > kWsMaxHalo) return false;
   if ((long)a.Cin_gp * a.x_cs * 4 >= kH3Oob || (long)a.ksize * a.Cin_gp * a.Cout_gp * 4 >= kH3Oob) return false;
+  const int ksteps = a.ksize * (a.Cin_gp / 16);
+  const bool map2d = a.kw < a.ksize;
+  if (mode == 1) {
+    // the F0 U-Net from 64 channels up: (Cout >= 64 is implied by Cout_gp % 64) 2-D maps of at most 32 768 positions per item
+    if (!map2d || a.Nout > 32768 || ksteps < 36) return false;
+  } else {
+    if (ksteps < 36) return false;
+  }
+  // the segment slabs must fit the caller's scratch, per item and for the batch
+  const int S = conv_ws_segments(a);
+  const long cap_item = a.part_cap_item > 0 ? a.part_cap_item : a.part_cap;
+  if (S > 1 && a.part && (long)S * a.Cout_g * a.Nout > cap_item) return false;      // (no scratch at all: the fused form)
   return true;
 }
 
-void launch_conv_deep(const ConvArgs& a, hipStream_t stream) {
+void launch_conv_deep(const ConvArgs& a_in, hipStream_t stream) {
+  ConvArgs a = a_in;
   static std::mutex mu;
   static uint64_t done = 0;
   int dev = 0;
@@ -186,38 +311,34 @@ void launch_conv_deep(const ConvArgs& a, hipStream_t stream) {
   {
     std::lock_guard<std::mutex> g(mu);
     if (!((done >> (dev & 63)) & 1)) {
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<16, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   16 * 2 * 16 * 64 * 4));
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<16, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   16 * 1 * 16 * 64 * 4));
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   8 * 2 * 16 * 64 * 4));
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<16, 6, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   16 * 1 * 16 * 64 * 4));
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<16, 4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   16 * 1 * 16 * 64 * 4));
-      RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_deep_kernel<8, 5, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   8 * 1 * 16 * 64 * 4));
+      for (const auto& k : kWs)
+        for (auto fn : {k.split, k.single, k.multi})
+          RVCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ws_lds_bytes(k.ks, kWsMaxHalo)));
       done |= 1ull << (dev & 63);
     }
   }
-  const int KS = a.ksize * (a.Cin_gp / 16);
-  dim3 grid(cdiv(a.Nout, 32), a.Cout_gp / 64, a.B);
-  static const int form = getenv("RVCX_CONV_DEEP_FORM") ? atoi(getenv("RVCX_CONV_DEEP_FORM")) : 0;
-  // 16 waves when every wave still gets >= 8 k-steps, else 8 (a function of the layer's shape only)
-  if (form == 2 || form == 3) {             // batch requests: 6 (or 4) steps per round trip, 32 x 32 tiles
-    grid.y = a.Cout_gp / 32;
-    if (KS < 128) hipLaunchKernelGGL((conv_deep_kernel<8, 5, 1, false>), grid, dim3(512), 8 * 1 * 16 * 64 * 4, stream, a);
-    else if (form == 2) hipLaunchKernelGGL((conv_deep_kernel<16, 6, 1, false>), grid, dim3(1024), 16 * 1 * 16 * 64 * 4, stream, a);
-    else hipLaunchKernelGGL((conv_deep_kernel<16, 4, 1, false>), grid, dim3(1024), 16 * 1 * 16 * 64 * 4, stream, a);
-  } else if (KS >= 128 && form == 1) {          // 32 x 32 tiles: twice the workgroups (the 512-channel level: 320 instead of 160), two steps per request
-    grid.y = a.Cout_gp / 32;
-    hipLaunchKernelGGL((conv_deep_kernel<16, 2, 1>), grid, dim3(1024), 16 * 1 * 16 * 64 * 4, stream, a);
-  } else if (KS >= 128) {
-    hipLaunchKernelGGL((conv_deep_kernel<16, 1, 2>), grid, dim3(1024), 16 * 2 * 16 * 64 * 4, stream, a);
-  } else {
-    hipLaunchKernelGGL((conv_deep_kernel<8, 2, 2>), grid, dim3(512), 8 * 2 * 16 * 64 * 4, stream, a);
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int kk = 0; kk < a.ksize; ++kk) {
+    lo = std::min(lo, conv_tap_off(a, kk));
+    hi = std::max(hi, conv_tap_off(a, kk));
   }
+  a.off_min = lo;
+  a.wrow = hi - lo;
+  const WsKern* K = nullptr;
+  for (const auto& k : kWs)
+    if (k.ks == a.ksize) K = &k;
+  RVCX_CHECK(K != nullptr, "conv_ws: unsupported tap count");
+  const int S = conv_ws_segments(a);
+  a.splitk = S;
+  const long base = (long)(a.Cout_gp / kWsBM) * cdiv(a.Nout, kWsBN);
+  // one workgroup per tile walks all segments when that fills the chip, or when the batch's slabs would not fit the scratch
+  static const int fuse_at = getenv("RVCX_CONV_WS_FUSE_AT") ? atoi(getenv("RVCX_CONV_WS_FUSE_AT")) : 160;
+  const bool fused = S == 1 || base * a.B >= fuse_at || !a.part || (long)S * a.B * a.Cout_g * a.Nout > a.part_cap;
+  const size_t lds = ws_lds_bytes(a.ksize, a.wrow);
+  dim3 grid(cdiv(a.Nout, kWsBN), a.Cout_gp / kWsBM, fused ? a.B : a.B * S);
+  hipLaunchKernelGGL(!fused ? K->split : (S == 1 ? K->single : K->multi), grid, dim3(256), lds, stream, a);
+  if (!fused) launch_splitk_finish(a, stream);
   RVCX_HIP(hipGetLastError());
 }
 

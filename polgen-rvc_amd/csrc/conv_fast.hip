@@ -485,8 +485,8 @@ void conv_fast_describe(ConvProfile* p) {
   p->bn[kConv3ThinSlot] = 30;
   p->halo[kConv3ThinSlot] = 300004;   // conv3_thin_kernel
   p->bm[kConvDeepSlot] = 64;
-  p->bn[kConvDeepSlot] = 32;
-  p->halo[kConvDeepSlot] = 300003;    // conv_deep_kernel
+  p->bn[kConvDeepSlot] = 320;
+  p->halo[kConvDeepSlot] = 300003;    // conv_ws_kernel (conv_deep.hip)
   for (int t = 0; t < kNumFast; ++t) {
     const int s = 8 + t;
     p->bm[s] = kFast[t].bm;

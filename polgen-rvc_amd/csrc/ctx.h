@@ -181,6 +181,7 @@ struct Ctx {
   hipEvent_t ev_done[2] = {nullptr, nullptr};  // main stream is done with micro-batch k's front set
   hipEvent_t ev_src[2] = {nullptr, nullptr};   // NSF source branch (sine + noise convs) beside TextEncoder/flow
   Arena arena;
+  size_t arena_budget = 0;        // activation budget of convert_micro_batch, probed once per context state (0: not yet)
   Arena arena_f0;                 // RMVPE workspace: lives on stream2 across the main stream's arena resets
   Arena arena_hub;                // HuBERT workspace: its own arena because HuBERT k+1 is enqueued (on aux[0], behind decoder k's branch there) before the main arena of k is released
   WeightSlab slab;

@@ -416,10 +416,11 @@ struct BitReader {
     const uint32_t m = 1u << (bits - 1);
     return (int32_t)((v ^ m) - m);
   }
-  uint32_t get_unary() {             // zeros before the next one
+  uint32_t get_unary(uint32_t limit = 1u << 26) {     // zeros before the next one; a crafted run cannot wrap the count
     uint32_t q = 0;
     for (;;) {
       if (pos >= n * 8) flac_fail("truncated stream");
+      if (q > limit) flac_fail("unary run too long");
       const size_t byte = pos >> 3;
       const int off = (int)(pos & 7);
       const uint8_t rest = (uint8_t)(p[byte] << off);
@@ -466,11 +467,16 @@ StreamInfo parse_header(const uint8_t* d, size_t n) {
       si.bps = (int)((packed >> 36) & 31) + 1;
       si.total = (int64_t)(packed & 0xFFFFFFFFFull);
       memcpy(si.md5, s + 18, 16);
+      if (si.sample_rate == 0) flac_fail("STREAMINFO sample rate 0");
       first = false;
     }
     o += len;
   }
   si.audio_offset = o;
+  // a frame of <= 65535 samples needs >= 10 bytes (header, one CONSTANT subframe per channel, CRC-16): a total beyond
+  // that cannot be honest, and the caller sizes its output from it
+  const int64_t audio_bytes = (int64_t)(n - o);
+  if (si.total > (audio_bytes / 10 + 1) * 65536) flac_fail("STREAMINFO sample count is implausible for the stream's size");
   return si;
 }
 
@@ -501,10 +507,17 @@ void decode_subframe(BitReader& br, int n, int bps, int64_t* x, std::vector<int3
   if (br.get(1)) flac_fail("subframe padding bit set");
   const int type = (int)br.get(6);
   int wasted = 0;
-  if (br.get(1)) wasted = (int)br.get_unary() + 1;
+  if (br.get(1)) wasted = (int)br.get_unary(32) + 1;
   if (wasted >= bps) flac_fail("wasted bits >= sample size");
   bps -= wasted;
   if (bps > 32) flac_fail("33-bit side channel of a 32-bit stream is not supported");
+  // every predicted sample must fit the subframe's sample size (one spare bit: encoders differ on the side channel):
+  // bounds the int64 prediction arithmetic below on crafted coefficients
+  const int64_t lim = (int64_t)1 << bps;
+  auto in_range = [&](int64_t v) {
+    if (v < -lim || v >= lim) flac_fail("predicted sample exceeds the stream's sample size");
+    return v;
+  };
   if (type == 0) {
     const int64_t v = br.get_signed(bps);
     for (int i = 0; i < n; ++i) x[i] = v;
@@ -521,16 +534,16 @@ void decode_subframe(BitReader& br, int n, int bps, int64_t* x, std::vector<int3
         for (int i = 0; i < n; ++i) x[i] = r[i];
         break;
       case 1:
-        for (int i = 1; i < n; ++i) x[i] = r[i] + x[i - 1];
+        for (int i = 1; i < n; ++i) x[i] = in_range(r[i] + x[i - 1]);
         break;
       case 2:
-        for (int i = 2; i < n; ++i) x[i] = r[i] + 2 * x[i - 1] - x[i - 2];
+        for (int i = 2; i < n; ++i) x[i] = in_range(r[i] + 2 * x[i - 1] - x[i - 2]);
         break;
       case 3:
-        for (int i = 3; i < n; ++i) x[i] = r[i] + 3 * x[i - 1] - 3 * x[i - 2] + x[i - 3];
+        for (int i = 3; i < n; ++i) x[i] = in_range(r[i] + 3 * x[i - 1] - 3 * x[i - 2] + x[i - 3]);
         break;
       default:
-        for (int i = 4; i < n; ++i) x[i] = r[i] + 4 * x[i - 1] - 6 * x[i - 2] + 4 * x[i - 3] - x[i - 4];
+        for (int i = 4; i < n; ++i) x[i] = in_range(r[i] + 4 * x[i - 1] - 6 * x[i - 2] + 4 * x[i - 3] - x[i - 4]);
         break;
     }
   } else if (type >= 32) {
@@ -548,7 +561,7 @@ void decode_subframe(BitReader& br, int n, int bps, int64_t* x, std::vector<int3
     for (int i = order; i < n; ++i) {
       int64_t acc = 0;
       for (int j = 0; j < order; ++j) acc += (int64_t)coef[j] * x[i - 1 - j];
-      x[i] = r[i] + (acc >> shift);
+      x[i] = in_range(r[i] + (acc >> shift));
     }
   } else {
     flac_fail("reserved subframe type");
@@ -557,10 +570,12 @@ void decode_subframe(BitReader& br, int n, int bps, int64_t* x, std::vector<int3
     for (int i = 0; i < n; ++i) x[i] *= (int64_t)1 << wasted;
 }
 
-int64_t decode(const uint8_t* d, size_t n, int32_t* out, int64_t cap, StreamInfo* info_out) {
+// count_only: walk the frames (full decode, nothing stored) and return the frame count -- what rvcx_flac_info reports for a
+// stream whose STREAMINFO leaves the total at 0 (streamed encodes)
+int64_t decode(const uint8_t* d, size_t n, int32_t* out, int64_t cap, StreamInfo* info_out, bool count_only = false) {
   const StreamInfo si = parse_header(d, n);
   if (info_out) *info_out = si;
-  if (!out) return si.total;
+  if (!out && !count_only) return si.total;
   if (si.bps < 4 || si.bps > 32) flac_fail("unsupported sample size");
   size_t o = si.audio_offset;
   int64_t done = 0;
@@ -625,6 +640,11 @@ int64_t decode(const uint8_t* d, size_t n, int32_t* out, int64_t cap, StreamInfo
         ch[0][i] = (mid + side) >> 1;
         ch[1][i] = (mid - side) >> 1;
       }
+    if (count_only) {
+      done += bs;
+      o += br.byte_pos();
+      continue;
+    }
     if ((done + bs) * nch > cap) flac_fail("output buffer too small");
     raw.resize((size_t)bs * nch * bytes_ps);
     size_t rp = 0;
@@ -640,6 +660,7 @@ int64_t decode(const uint8_t* d, size_t n, int32_t* out, int64_t cap, StreamInfo
     if (si.total && done >= si.total) break;
   }
   if (si.total && done != si.total) flac_fail("stream holds fewer samples than STREAMINFO says");
+  if (count_only) return done;
   bool have_md5 = false;
   for (int i = 0; i < 16; ++i) have_md5 = have_md5 || si.md5[i] != 0;
   if (have_md5) {
@@ -687,7 +708,8 @@ int64_t rvcx_flac_encode_s16(const int16_t* pcm, int64_t frames, int channels, i
 int rvcx_flac_info(const uint8_t* data, int64_t n, int64_t* frames, int32_t* channels, int32_t* sample_rate, int32_t* bits) {
   return (int)guarded([&]() -> int64_t {
     if (!data) flac_fail("null buffer");
-    const StreamInfo si = parse_header(data, (size_t)n);
+    StreamInfo si = parse_header(data, (size_t)n);
+    if (frames && si.total == 0) si.total = decode(data, (size_t)n, nullptr, 0, nullptr, true);   // unknown length: count the frames
     if (frames) *frames = si.total;
     if (channels) *channels = si.channels;
     if (sample_rate) *sample_rate = si.sample_rate;

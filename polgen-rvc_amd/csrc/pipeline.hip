@@ -444,13 +444,28 @@ int convert_micro_batch(Ctx& c, int model_id, long n, const rvcx_params& p) {
   // Activation budget: RVCX_ARENA_GB if set; else 100 GB (64 x 30 s: micro-batches of 16 instead of 11, +1 %) but never
   // more than 70 % of what the device has FREE right now -- a second context on the same GPU, or a smaller GPU, must not
   // turn the default into an out-of-memory error (the arena only ever grows: what this context already holds counts as free).
+  // The free-memory probe runs ONCE per context state (first conversion after a load / unload: api_call clears the cached
+  // value on every non-repeating entry point), on the context's OWN device -- rvcx_micro_batch reaches this function
+  // without api_call's hipSetDevice -- so that the micro-batch partition is a function of (inputs, resident models,
+  // environment), not of what another context happened to hold at the moment of the call.  The 70 % rule is a heuristic
+  // against the obvious failure (two contexts, a smaller GPU), not an out-of-memory guarantee: two contexts created
+  // together can each see the same free bytes.
   size_t budget = (size_t)(getenv("RVCX_ARENA_GB") ? atoi(getenv("RVCX_ARENA_GB")) : 100) << 30;
   if (!getenv("RVCX_ARENA_GB")) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-      const size_t mine = c.arena.capacity() + c.arena_f0.capacity() + c.arena_hub.capacity();
-      budget = std::min(budget, (size_t)((double)(free_b + mine) * 0.7));
+    if (c.arena_budget == 0) {
+      int cur = -1;
+      (void)hipGetDevice(&cur);
+      if (cur != c.device) (void)hipSetDevice(c.device);
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+        const size_t mine = c.arena.capacity() + c.arena_f0.capacity() + c.arena_hub.capacity();
+        c.arena_budget = std::max<size_t>(1, std::min(budget, (size_t)((double)(free_b + mine) * 0.7)));
+      } else {
+        c.arena_budget = budget;
+      }
+      if (cur >= 0 && cur != c.device) (void)hipSetDevice(cur);
     }
+    budget = c.arena_budget;
   }
   const size_t per = convert_item_bytes(c, model_id, n, p) + f0_arena_bytes(c, p, 1, n + 32000L * p.x_pad);
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)env_max, budget / std::max<size_t>(per, 1)));

@@ -222,7 +222,9 @@ void run_block(Ctx& c, const RmvpeModel::Block& b, const Map2& x, const Map2& y,
   // their launches rely on split-K, which the split store does not go through
   ConvArgs a2 = conv2d_args(b.c2, tmp1, y.p, B, H, Wp);
   a2.lens_in = a2.lens_out = lens;
-  const bool split = (long)H * Wp >= 20000 && conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
+  // (round 6: a block both of whose convs the weight-stationary tile takes -- 64 channels and up -- stays on fp32 maps)
+  const bool ws = conv_deep_ok(a) && conv_deep_ok(a2);
+  const bool split = !ws && (long)H * Wp >= 20000 && conv_h3_split_ok(a) && conv_h3_split_ok(a2) && !getenv("RVCX_NO_SPLIT");
   if (split) {
     a.y_split = tmp1;
     a.y = nullptr;

@@ -69,9 +69,13 @@ def default_device() -> int:
 
 
 def context(device=None) -> "_lib.Context":
-    """One rvcx context per GPU, created on first use."""
+    """One rvcx context per GPU, created on first use.  The hit path is a plain dict read (atomic under the GIL): a
+    request never waits here for another thread's model load; LOCK is taken only to create."""
+    idx = default_device() if device is None else dev_index(device)
+    c = _CTX.get(idx)
+    if c is not None:
+        return c
     with LOCK:
-        idx = default_device() if device is None else dev_index(device)
         if idx not in _CTX:
             _CTX[idx] = _lib.Context(idx)
         return _CTX[idx]

@@ -158,18 +158,27 @@ def load_fcpe(device, model_path=None, cpt=None):
         _RESIDENT[slot] = (key, True)
 
 
-@_state.locked       # table lock only: validation must work without a GPU, and adding a model disturbs no request
 def get_vc(device, is_half, config, model_path, cpt=None):
     """rvc/infer/infer.py:78-105 -> (cpt, version, net_g, tgt_sr, vc).  A ``model_path`` seen before (same
     realpath, mtime and size) returns the voice model already resident in HBM; the returned ``cpt`` then
-    carries the checkpoint's metadata (config, version, f0, ...) without the weight tensors."""
+    carries the checkpoint's metadata (config, version, f0, ...) without the weight tensors.
+
+    Locking: the process-wide table lock is held for the ``_SYNTHS`` lookup and for the insert only -- un-pickling and
+    validation (seconds for a real checkpoint) run outside it, so requests of other threads (whose ``context()`` /
+    table reads used to queue behind a model load) go on; two threads that load the same new file both load it and the
+    second finds the first's entry at the re-check (its own copy is unloaded with its handle).  ``ctx.load_synth``
+    serialises against conversions on the context's C mutex, as every entry point does."""
     skey = None
+
+    def hit():
+        light, net_g = _SYNTHS.pop(skey)
+        _SYNTHS[skey] = (light, net_g)              # most recently used
+        return dict(light), light.get("version", "v1"), net_g, light["config"][-1], VC(light["config"][-1], config)
     if cpt is None:
         skey = (_dev_index(device), _file_key(model_path))
-        if skey in _SYNTHS:
-            light, net_g = _SYNTHS.pop(skey)
-            _SYNTHS[skey] = (light, net_g)          # most recently used
-            return dict(light), light.get("version", "v1"), net_g, light["config"][-1], VC(light["config"][-1], config)
+        with _state.LOCK:
+            if skey in _SYNTHS:
+                return hit()
         cpt = _torch_load(model_path)
     if "config" not in cpt or "weight" not in cpt:
         raise ValueError(f"Invalid format for {model_path}. Use a voice model trained with RVC v2.")
@@ -180,16 +189,20 @@ def get_vc(device, is_half, config, model_path, cpt=None):
     if version != "v2" or not pitch_guidance:
         raise ValueError("rvcx supports RVC v2 voice models with pitch guidance (f0=1)")
     input_dim = int(cpt["weight"]["enc_p.emb_phone.weight"].shape[1])
-    ctx = _context(device)
     state = weights.strip_enc_q(cpt["weight"])
-    mid = ctx.load_synth(weights.synth_cfg_struct(cpt["config"], input_dim), state)
+    cfg_struct = weights.synth_cfg_struct(cpt["config"], input_dim)
+    ctx = _context(device)
+    mid = ctx.load_synth(cfg_struct, state)         # outside the table lock (the context's own mutex orders it)
     net_g = SynthHandle(ctx, mid, list(cpt["config"]))
-    vc = VC(tgt_sr, config)
     if skey is not None:
-        _SYNTHS[skey] = ({k: v for k, v in cpt.items() if k != "weight"}, net_g)
-        while len(_SYNTHS) > MAX_RESIDENT_SYNTHS:
-            _SYNTHS.pop(next(iter(_SYNTHS)))        # least recently used; unloads when the caller let go too
-    return cpt, version, net_g, tgt_sr, vc
+        with _state.LOCK:
+            if skey in _SYNTHS:                     # another thread loaded the same file meanwhile: keep theirs,
+                del net_g                           # ours is unloaded with its handle
+                return hit()
+            _SYNTHS[skey] = ({k: v for k, v in cpt.items() if k != "weight"}, net_g)
+            while len(_SYNTHS) > MAX_RESIDENT_SYNTHS:
+                _SYNTHS.pop(next(iter(_SYNTHS)))    # least recently used; unloads when the caller let go too
+    return cpt, version, net_g, tgt_sr, VC(tgt_sr, config)
 
 
 def load_audio(file, sample_rate, *, device=None):

@@ -125,7 +125,66 @@ class _Table:
 # ----------------------------------------------------------------------------
 # Synthesizer (enc_q removed, as after infer.py:99)
 # ----------------------------------------------------------------------------
-def synth_state(cfg: List, seed: int = 0, input_dim: int = 768) -> Dict[str, np.ndarray]:
+# Real voice models are not O(1) everywhere either: weight-norm g vectors of trained HiFi-GAN decoders spread over two
+# orders of magnitude and single channels carry activations of a few hundred.  ``outliers=True`` plants that in the NSF
+# decoder (78 % of the path's FLOPs, all on the split-fp16 kernels), function-preservingly -- leaky_relu is positively
+# homogeneous, so a producer channel scaled by G is undone in its consumer's input column:
+#   * dec.conv_pre / dec.cond rows DEC_OUTLIER_PRE x G, the matching weight-norm g entries of dec.ups.0 (per INPUT channel:
+#     ConvTranspose1d, dim = 0) / G -> g of ups.0 spreads over 1 : G, its input carries channels of a few hundred;
+#   * one ResBlock1 step per (stage, kernel): rows DEC_OUTLIER_UNITS of convs1[m] (g and bias) x G, the matching input
+#     columns of convs2[m] / G (re-parametrised: v' = the new effective weight, g' = its row norms) -> the c1 -> c2 hand-off
+#     of the fused step (an LDS tile of split halves) holds values of 50 ... 500, c2 rows mix weights 1 : G apart.
+DEC_OUTLIER_GAIN, DEC_OUTLIER_UNITS, DEC_OUTLIER_PRE = 150.0, 3, 2      # not a power of two: the split halves change
+
+
+def _wn_effective(t, prefix):
+    """effective weight g v / ||v|| (norm over all dims but 0) of a parametrized conv, float64"""
+    g = t[prefix + ".parametrizations.weight.original0"].astype(np.float64)
+    v = t[prefix + ".parametrizations.weight.original1"].astype(np.float64)
+    n = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(1)).reshape(g.shape)
+    return g * v / n
+
+
+def _wn_set(t, prefix, w):
+    """re-parametrise: v = w, g = ||w|| per dim-0 slice (so g v / ||v|| = w exactly up to fp32 rounding)"""
+    w = np.asarray(w, np.float64)
+    n = np.sqrt((w.reshape(w.shape[0], -1) ** 2).sum(1))
+    t[prefix + ".parametrizations.weight.original1"] = w.astype(np.float32)
+    t[prefix + ".parametrizations.weight.original0"] = n.reshape((w.shape[0],) + (1,) * (w.ndim - 1)).astype(np.float32)
+
+
+def _plant_decoder_outliers(t: Dict[str, np.ndarray], cfg: List, seed: int) -> None:
+    (_, _, inter, hidden, filt, n_heads, n_layers, ksz, _, _, rks, rds, ups, up_init, upks, spk, gin, _) = cfg
+    G = DEC_OUTLIER_GAIN
+    # conv_pre (+ cond) -> lrelu -> ups.0
+    rows = _rng("outlier.dec.pre", seed).choice(up_init, min(DEC_OUTLIER_PRE, up_init), replace=False)
+    for n in ("dec.conv_pre", "dec.cond"):
+        w, b = np.array(t[n + ".weight"]), np.array(t[n + ".bias"])
+        w[rows] *= np.float32(G)
+        b[rows] *= np.float32(G)
+        t[n + ".weight"], t[n + ".bias"] = w, b
+    g0 = np.array(t["dec.ups.0.parametrizations.weight.original0"])
+    g0[rows] /= np.float32(G)
+    t["dec.ups.0.parametrizations.weight.original0"] = g0
+    # one dilation step m of every ResBlock1: convs1[m] rows x G, convs2[m] columns / G
+    for i in range(len(ups)):
+        co = up_init // (2 ** (i + 1))
+        for j in range(len(rks)):
+            blk = f"dec.resblocks.{i * len(rks) + j}"
+            m = (i + j) % len(rds[j])
+            units = _rng(f"outlier.{blk}", seed).choice(co, min(DEC_OUTLIER_UNITS, co), replace=False)
+            p1, p2 = f"{blk}.convs1.{m}", f"{blk}.convs2.{m}"
+            g1 = np.array(t[p1 + ".parametrizations.weight.original0"])
+            b1 = np.array(t[p1 + ".bias"])
+            g1[units] *= np.float32(G)
+            b1[units] *= np.float32(G)
+            t[p1 + ".parametrizations.weight.original0"], t[p1 + ".bias"] = g1, b1
+            w2 = _wn_effective(t, p2)
+            w2[:, units] /= G
+            _wn_set(t, p2, w2)
+
+
+def synth_state(cfg: List, seed: int = 0, input_dim: int = 768, outliers: bool = False) -> Dict[str, np.ndarray]:
     (_, _, inter, hidden, filt, n_heads, n_layers, ksz, _, _, rks, rds, ups, up_init,
      upks, spk, gin, _) = cfg
     T = _Table(seed)
@@ -177,6 +236,8 @@ def synth_state(cfg: List, seed: int = 0, input_dim: int = 768) -> Dict[str, np.
         T.wn_conv(p + ".enc.cond_layer", (2 * hidden * 3, gin, 1), gain=0.5)
         T.conv(p + ".post", (half, hidden, 1), gain=0.3)
     T.normal("emb_g.weight", (spk, gin), 0.3)
+    if outliers and not _SHAPES_ONLY:
+        _plant_decoder_outliers(T.t, cfg, seed)
     return T.t
 
 
@@ -208,7 +269,32 @@ def _conv_block_res(T: _Table, prefix: str, cin: int, cout: int):
         T.conv(prefix + ".shortcut", (cout, cin, 1, 1), gain=0.7)
 
 
-def rmvpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
+# U-Net of the F0 model: a BatchNorm scale of G on a few channels of a block's first conv (ReLU is positively homogeneous),
+# undone in the input columns of the block's second conv -- the pre-split hand-off between the two 3 x 3 convs of a
+# ConvBlockRes then carries values of a few hundred.  One block per encoder level, one intermediate, one decoder block.
+UNET_OUTLIER_GAIN, UNET_OUTLIER_UNITS = 150.0, 2
+
+
+def _plant_unet_outliers(t: Dict[str, np.ndarray], cfg: dict, seed: int) -> None:
+    nb, nenc, nint = cfg["n_blocks"], cfg["en_de_layers"], cfg["inter_layers"]
+    G = np.float32(UNET_OUTLIER_GAIN)
+    blocks = [f"unet.encoder.layers.{l}.conv.{l % nb}" for l in range(nenc)]
+    blocks += [f"unet.intermediate.layers.{nint - 1}.conv.{nb - 1}", f"unet.decoder.layers.{nenc - 1}.conv2.{nb - 1}",
+               "unet.decoder.layers.0.conv2.0"]
+    for blk in blocks:
+        c = t[blk + ".conv.1.weight"].shape[0]
+        units = _rng(f"outlier.{blk}", seed).choice(c, min(UNET_OUTLIER_UNITS, c), replace=False)
+        gam, bet = np.array(t[blk + ".conv.1.weight"]), np.array(t[blk + ".conv.1.bias"])
+        mean = np.array(t[blk + ".conv.1.running_mean"])
+        gam[units] *= G
+        bet[units] *= G           # y = gam (x - mean) / sd + bet: both terms x G
+        t[blk + ".conv.1.weight"], t[blk + ".conv.1.bias"], t[blk + ".conv.1.running_mean"] = gam, bet, mean
+        w = np.array(t[blk + ".conv.3.weight"])
+        w[:, units] /= G
+        t[blk + ".conv.3.weight"] = w
+
+
+def rmvpe_state(cfg: dict = None, seed: int = 0, outliers: bool = False) -> Dict[str, np.ndarray]:
     cfg = cfg or RMVPE_CFG_FULL
     nb, nenc, nint, c0 = cfg["n_blocks"], cfg["en_de_layers"], cfg["inter_layers"], cfg["en_out_channels"]
     T = _Table(seed + 17)
@@ -246,6 +332,8 @@ def rmvpe_state(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
     w = _normal("fc.1.weight", (360, 2 * H), 1.0, seed + 17)
     T.t["fc.1.weight"] = (_smooth_axis0(w, 1.6) * np.float32(4.0 / math.sqrt(2 * H))).astype(np.float32)
     T.t["fc.1.bias"] = _smooth_axis0(_normal("fc.1.bias", (360,), 1.0, seed + 17), 9.0) * np.float32(0.3) - np.float32(10.5 if c0 >= 16 else 11.5)
+    if outliers and not _SHAPES_ONLY:
+        _plant_unet_outliers(T.t, cfg, seed)
     return T.t
 
 

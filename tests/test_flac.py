@@ -112,3 +112,34 @@ def test_mirror_writes_flac_only_for_the_flac_extension_and_reads_it_back(tmp_pa
     open(p2, "wb").write(_lib.flac_encode(st, 44100))
     a, sr = A.read_audio(p2)
     assert sr == 44100 and a.shape == (5000, 2) and np.array_equal(np.rint(a * 32768.0).astype(np.int16), st)
+
+
+def _patch_streaminfo(blob, total=None, sample_rate=None):
+    """rewrite fields of the STREAMINFO block (bytes 8 .. 41 of a stream whose first metadata block is STREAMINFO)"""
+    b = bytearray(blob)
+    packed = int.from_bytes(b[18:26], "big")
+    if total is not None:
+        packed = (packed & ~0xFFFFFFFFF) | (total & 0xFFFFFFFFF)
+    if sample_rate is not None:
+        packed = (packed & ~(0xFFFFF << 44)) | ((sample_rate & 0xFFFFF) << 44)
+    b[18:26] = packed.to_bytes(8, "big")
+    return bytes(b)
+
+
+def test_streams_of_unknown_length_and_crafted_headers():
+    """a STREAMINFO total of 0 (streamed encodes) is legal -- the frames are counted, a stream of silence (a
+    CONSTANT subframe holds 4096 samples in a dozen bytes) decodes; totals that are implausible for the byte count and a
+    sample rate of 0 are refused before anything is allocated."""
+    silence = np.zeros(50000, np.int16)
+    speech = _speechlike(12345, 5, 2)
+    for pcm in (silence, speech):
+        blob = _patch_streaminfo(_lib.flac_encode(pcm, 48000), total=0)
+        got, sr, bps = _lib.flac_decode(blob)
+        assert sr == 48000 and bps == 16 and np.array_equal(got.reshape(pcm.shape), pcm)
+    blob = _lib.flac_encode(speech, 48000)
+    with pytest.raises(_lib.RvcxError, match="implausible"):
+        _lib.flac_decode(_patch_streaminfo(blob, total=(1 << 36) - 1))
+    with pytest.raises(_lib.RvcxError, match="sample rate 0"):
+        _lib.flac_decode(_patch_streaminfo(blob, sample_rate=0))
+    with pytest.raises(_lib.RvcxError):                       # a total that is plausible but wrong still fails, after decoding
+        _lib.flac_decode(_patch_streaminfo(blob, total=12346))

@@ -169,9 +169,9 @@ class Cfg:
 
 
 # ------------------------------------------------------------------ stage goldens
-def gold_synth(tag, cfg, T, seed):
-    print(f"[synth {tag}] T={T}")
-    sd = S.to_torch(S.synth_state(cfg, seed))
+def gold_synth(tag, cfg, T, seed, outliers=False):
+    print(f"[synth {tag}] T={T} outliers={outliers}")
+    sd = S.to_torch(S.synth_state(cfg, seed, outliers=outliers))
     net = ref_synth(cfg, sd)
     c = O_synth.cfg_fields(cfg)
     g = torch.Generator().manual_seed(100 + seed)
@@ -196,7 +196,7 @@ def gold_synth(tag, cfg, T, seed):
     report("z", z, parts["z"])
     e = report("audio", o, oo)
     assert e < 1e-5, e
-    np.savez_compressed(os.path.join(GOLD, f"synth_{tag}.npz"), seed=seed, cfg=json.dumps(cfg),
+    np.savez_compressed(os.path.join(GOLD, f"synth_{tag}.npz"), seed=seed, cfg=json.dumps(cfg), outliers=bool(outliers),
                         phone=phone.numpy(), pitch=pitch.numpy(), f0=f0.numpy(), z_noise=z_noise.numpy(),
                         src_noise=src_noise.numpy().astype(np.float32), m_p=m_p.numpy(), logs_p=logs_p.numpy(),
                         z_p=z_p.numpy(), z=z.numpy(), audio=o.numpy())
@@ -223,11 +223,11 @@ def stable_seed(rcfg, audio_pad_f32, seed, f0_min=50, f0_max=1100, pitch=0.0, tr
     raise RuntimeError("no stable seed found")
 
 
-def gold_rmvpe(tag, cfg, seconds, seed, stride=1):
-    print(f"[rmvpe {tag}] {seconds}s")
+def gold_rmvpe(tag, cfg, seconds, seed, stride=1, outliers=False):
+    print(f"[rmvpe {tag}] {seconds}s outliers={outliers}")
     audio = S.make_clip(7 + seed, seconds).astype(np.float64)
-    seed = stable_seed(cfg, audio.astype(np.float32), seed)
-    sd = S.to_torch(S.rmvpe_state(cfg, seed))
+    seed = stable_seed(cfg, audio.astype(np.float32), seed)      # the planting is function-preserving: same conditioning
+    sd = S.to_torch(S.rmvpe_state(cfg, seed, outliers=outliers))
     pred = ref_rmvpe(cfg, sd)
     a = torch.from_numpy(audio).float().unsqueeze(0)
     mel = pred.mel_extractor(a, center=True)
@@ -237,7 +237,7 @@ def gold_rmvpe(tag, cfg, seconds, seed, stride=1):
     report("mel", mel, omel); e1 = report("hidden", hid, ohid); e2 = report("f0", f0, of0)
     assert e1 < 1e-5 and e2 < 1e-2, (e1, e2)
     print(f"  voiced frames {int((f0 > 0).sum())}/{len(f0)}  hidden max {hid.max():.3f}")
-    np.savez_compressed(os.path.join(GOLD, f"rmvpe_{tag}.npz"), seed=seed, cfg=json.dumps(cfg),
+    np.savez_compressed(os.path.join(GOLD, f"rmvpe_{tag}.npz"), seed=seed, cfg=json.dumps(cfg), outliers=bool(outliers),
                         audio=audio.astype(np.float32), mel=mel.numpy()[:, :, ::stride],
                         hidden=hid[::stride], f0=f0, stride=stride)
 
@@ -337,12 +337,14 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
 
 
 def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, protect, f0_min, f0_max,
-                  full_store=True):
+                  full_store=True, fixed_seed=None):
     hcfg, rcfg, scfg = cfgs
     print(f"[pipeline {tag}] {seconds}s geo={geo} pitch={pitch} env={volume_envelope}")
     a_ = O_pipe.highpass(S.make_clip(clip, seconds).astype(np.float64))
     a_ = np.pad(a_, (16000 * geo[0], 16000 * geo[0]), mode="reflect").astype(np.float32)
-    seed = stable_seed(rcfg, a_, seed, f0_min, f0_max, pitch)
+    # fixed_seed: found beforehand by tools/find_stable_seed.py (the same criteria, scanned over processes: ~1 % of the
+    # seeds qualify on a 9 700-frame clip)
+    seed = fixed_seed if fixed_seed is not None else stable_seed(rcfg, a_, seed, f0_min, f0_max, pitch)
     hsd, rsd, ssd = (S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.rmvpe_state(rcfg, seed)),
                      S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])))
     tgt_sr = scfg[-1]
@@ -610,6 +612,10 @@ def main():
         "rmvpe_tiny": lambda: gold_rmvpe("tiny", S.RMVPE_CFG_TINY, 0.7, 1),
         "rmvpe_full": lambda: gold_rmvpe("full_1s", S.RMVPE_CFG_FULL, 1.0, 0),
         "rmvpe_illcond": gold_rmvpe_illcond,
+        # round 6: planted outlier channels in the NSF decoder (weight-norm g spread 1 : 150, c1 -> c2 hand-off values of a
+        # few hundred) and in the F0 U-Net (BatchNorm scale x 150 on the block-internal hand-off): synthetic.py
+        "synth_outliers": lambda: gold_synth("48k_T24_outliers", S.SYNTH_CFG_48K, 24, 0, outliers=True),
+        "rmvpe_outliers": lambda: gold_rmvpe("full_1s_outliers", S.RMVPE_CFG_FULL, 1.0, 0, outliers=True),
         "hubert_tiny": lambda: gold_hubert("tiny", S.HUBERT_CFG_TINY, 0.5, 1),
         "hubert_base": lambda: gold_hubert("base_1s", S.HUBERT_CFG_BASE, 1.0, 0),
         # the same model with planted outlier units (synthetic.py: _plant_outliers): what real ContentVec-shaped weights do
@@ -636,6 +642,13 @@ def main():
                                                            0, 2100, 0, 1.0, 0.33, full_store=False,
                                                            min_margin=2e-4)   # 3200 frames: the salience
         # maximum of some frame always comes within ~1e-4 of the 0.03 threshold; 2e-4 is ~30x the GPU's error
+        # round 6: the cut-point / per-chunk / trim / concat branch (pipeline.py:330-344,381-447) at the REAL geometry and
+        # model size: a 95 s clip is cut into three chunks at silence-aligned points, F0 once over 9 700 frames
+        # seed 12800: `tools/find_stable_seed.py --start 7000 --n 200 --rel 2e-4 --tie-margin 5e-4` (no ill-conditioned frame,
+        # no coarse value within 5e-4 of a rounding tie -- 7x the error bound of an f0 that is 1e-6 off)
+        steps["pipe_long95"] = lambda: gold_pipeline("long95_48k", full48, (1, 6, 38, 41), 95.0, 3, 3000, 0, 1.0, 0.33,
+                                                     50, 1100, full_store=False,
+                                                     fixed_seed=int(os.environ.get("RVCX_LONG95_SEED", "12800")))
         steps["pipe_c3"] = gold_pipeline_c3
         steps["pipe_c5"] = gold_pipeline_c5
     for k, fn in steps.items():
