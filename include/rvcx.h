@@ -268,10 +268,15 @@ int rvcx_get_f0_crepe_x(rvcx_ctx*, const float* x_hd, int64_t n, int64_t p_len, 
 int rvcx_f0_file_track(const float* inp_f0, int rows, double* track, int cap);
 /* librosa.resample(librosa.to_mono(audio.T), orig_sr=sr_in, target_sr=sr_out) of load_audio (rvc/lib/my_utils.py:9-13):
  * x = (frames, channels) interleaved float64 (host or device), y = rvcx_resample_len(frames, ...) mono float64 samples.
- * Band-limited sinc interpolation with resampy's published "kaiser_best" filter (csrc/audio.hip; soxr, librosa's
- * current default, is not published as a formula: parity unpinned). */
+ * Band-limited sinc interpolation (csrc/audio.hip).  librosa's default res_type is "soxr_hq": libsoxr is not vendored and
+ * its coefficients are unpublished, its design targets are (pass-band flat to 0.9136 x Nyquist, -120.4 dB from 1.0 x
+ * Nyquist, linear phase).  kind 0 (the default; -1 = default / RVCX_RESAMPLER): "kaiser_hq", a Kaiser-windowed sinc
+ * designed to those targets (measured +-0.001 dB / -127 dB); kind 1: resampy's published "kaiser_best" (librosa's default
+ * before 0.10) in its published arithmetic. */
 int64_t rvcx_resample_len(int64_t n, int sr_in, int sr_out);
 int rvcx_resample_f64(rvcx_ctx*, const double* x_hd, int64_t frames, int channels, int sr_in, int sr_out, double* y_hd);
+int rvcx_resample_f64_kind(rvcx_ctx*, const double* x_hd, int64_t frames, int channels, int sr_in, int sr_out, int kind,
+                           double* y_hd);
 /* VC.vc(model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version="v2", protect) --
  * rvc/infer/pipeline.py:203-287: HuBERT -> (retrieval blend with the resident index when index_rate != 0) ->
  * x2 upsample / protect mix -> Synthesizer.infer.  audio0 (n samples of audio_pad); pitch / pitchf (n_pitch
@@ -310,6 +315,10 @@ int64_t rvcx_fp32_reruns(rvcx_ctx*);
  * meets an activation beyond fp16 range stamps its layer; the entry point pins the first offender of the call (launch
  * order) for the life of the model and repeats the call once -- later requests pay nothing. */
 int64_t rvcx_fp32_layers(rvcx_ctx*);
+/* which ones: one text line per layer the range guard pinned at run time since its model was loaded ("voice model 0: layer
+ * 17 of 142 (conv 128 <- 128 x 7)"), in the order they were pinned; returns the length of the full text (buf receives at
+ * most cap - 1 bytes + NUL).  Diagnostics for checkpoints with outlier channels; no reference counterpart. */
+int rvcx_fp32_pinned(rvcx_ctx*, char* buf, int cap);
 /* calls repeated with the single-workgroup BiGRU kernel because the cluster kernel's workgroups were not co-resident */
 int64_t rvcx_gru_fallbacks(rvcx_ctx*);
 /* retrieval: queries whose 8 neighbours could not be certified from the split-fp16 pre-filter and were searched

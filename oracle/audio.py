@@ -4,24 +4,31 @@
 
 PARITY UNPINNED: ``librosa`` / ``soxr`` / ``resampy`` / ``soundfile`` are third-party packages that are neither vendored
 in /root/reference nor installed here (the reference does not even pin a librosa version: requirements.txt lists none).
-``librosa.resample``'s default ``res_type`` is "soxr_hq" since librosa 0.10 and was "kaiser_best" before; soxr's filter
-design is not published as a formula, resampy's is.  This file restates **resampy's "kaiser_best"** band-limited sinc
-interpolation (Smith's algorithm as published with resampy: a Kaiser-windowed sinc with num_zeros = 64, 2**9 table
-samples per zero crossing, roll-off 0.9475937167399596, beta 14.769656459379492, linear interpolation between table
-samples, output length int(n * ratio)) from its published description.  The product's resampler (csrc/audio.hip) is
-tested against this restatement; neither is checked against soxr.
+``librosa.resample``'s default ``res_type`` is "soxr_hq" since librosa 0.10 and was "kaiser_best" before.  libsoxr's
+coefficients are not published as a formula; its DESIGN TARGETS are (soxr.c, soxr_quality_spec, HQ = 20-bit precision):
+linear phase, pass-band flat to 0.9136 x Nyquist(out) (7.31 kHz at 16 kHz), stop-band from 1.0 x Nyquist(out) at -120.4 dB.
 
-STATED BOUND against the reference's resampler (tests/test_resample_spec.py measures every figure).  soxr's "HQ" recipe
-is public (soxr.c, soxr_quality_spec: 20-bit precision): pass-band flat to 0.9136 x Nyquist(out) = 7.31 kHz, stop-band
-from 1.0 x Nyquist(out) = 8 kHz at -120.4 dB, linear phase.  kaiser_best at 44.1 k / 48 k -> 16 k:
-  * a constant pass-band gain of +0.034 ... +0.036 dB (resampy steps through its table with int(scale * 512): 185 for
-    185.76), flat within +-0.02 dB of that up to 7.0 kHz; -0.4 dB at 7.3 kHz, -4 dB at 7.5 kHz (soxr_hq: still flat);
-  * alias rejection -55 ... -64 dB for 8 ... 9 kHz, below -67 dB from 10 kHz, below -78 dB from 20 kHz (soxr_hq: -120 dB);
-  * on the C2 benchmark signal rendered at 44.1 kHz, against a Kaiser FIR built to soxr_hq's targets: 3.1e-3 relative RMS
-    (-50 dB); 1.6e-3 (-56 dB) with the least-squares gain of 1.0027 divided out.
-So a request whose upload is not 16 kHz enters the networks ~0.3 % louder and with a 0.3 kHz narrower top octave than in
-the reference -- three orders of magnitude above the waveform parity the 16 kHz path is held to (1e-5), which is why
-parity is defined, tested and benchmarked on 16 kHz input (BASELINE.json: "synthetic 16 kHz mono clips").
+Two restatements, both tested against the product's resampler (csrc/audio.hip) to 1e-12:
+
+* ``resample_kaiser_hq`` (round 6; what the product computes by default): a Kaiser-windowed sinc DESIGNED TO soxr_hq's
+  published targets -- cut-off in the middle of the transition band (roll-off 0.9568), beta 12.82 (a 125 dB Kaiser
+  window), 96 zero crossings per wing (the Kaiser length for a 0.0864 x Nyquist transition), a 2**11-per-crossing table
+  with linear interpolation (table error -141 dB), every tap at its exact table position.  Measured at 44.1 k / 48 k ->
+  16 k (tests/test_resample_spec.py): pass-band within +-0.001 dB up to 7.31 kHz, -0.44 dB at 7.5 kHz, alias rejection
+  below -127 dB from 8.0 kHz on: INSIDE the published targets.  Against a scipy FIR built to the same targets the C2
+  benchmark signal rendered at 44.1 kHz differs by 4.1e-5 relative RMS (-88 dB; 4.5e-7 when band-limited to 6.5 kHz: the
+  rest lies in the 7.31 ... 8 kHz transition band,
+  where the recipe does not fix the shape); against libsoxr itself the difference cannot be measured here and is bounded
+  by the same figures: two filters that both meet the recipe agree to the ripple (1e-4) below 7.31 kHz and to 1e-6 of
+  full scale above 8 kHz.
+* ``resample_kaiser_best``: resampy's published "kaiser_best" band-limited sinc interpolation (Smith's algorithm as
+  published with resampy: num_zeros = 64, 2**9 table samples per zero crossing, roll-off 0.9475937167399596, beta
+  14.769656459379492, integer table step, output length int(n * ratio)); selectable in the product
+  (RVCX_RESAMPLER=kaiser_best).  Against the targets: a constant gain of +0.035 dB, -0.4 dB at 7.3 kHz, aliases at -55 ... -64
+  dB between 8 and 9 kHz; 3.1e-3 relative RMS from the soxr_hq-spec FIR on the same signal.
+
+Parity of the conversion itself is defined, tested and benchmarked on 16 kHz input (BASELINE.json: "synthetic 16 kHz mono
+clips"), where no resampler runs.
 
 Only tests/ (and tools/) may import this module."""
 from __future__ import annotations
@@ -83,6 +90,46 @@ def resample_kaiser_best(x: np.ndarray, sr_orig: int, sr_new: int) -> np.ndarray
     return y
 
 
+KAISER_HQ = dict(num_zeros=96, precision=11, rolloff=0.9568, beta=12.82)
+
+
+def resample_kaiser_hq(x: np.ndarray, sr_orig: int, sr_new: int, dtype=np.float64) -> np.ndarray:
+    """The default filter of csrc/audio.hip (header above): taps at exact table positions p = (frac + i scale) 2**11,
+    linear interpolation between table samples, left wing then right wing, running sum in ``dtype``."""
+    x = np.asarray(x, dtype=np.float64)
+    ratio = float(sr_new) / float(sr_orig)
+    n_out = int(x.shape[0] * ratio)
+    win, table = sinc_window(**KAISER_HQ)
+    scale = min(1.0, ratio)
+    if ratio < 1:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    nwin, n_orig = win.shape[0], x.shape[0]
+    t = np.arange(n_out, dtype=np.float64) * (1.0 / ratio)
+    n = t.astype(np.int64)
+    frac = scale * (t - n)
+    step = scale * table
+    y = np.zeros(n_out, dtype=dtype)
+    taps = int((nwin - 1) / step) + 2
+
+    def wing(p0, src, ok):
+        nonlocal y
+        for i in range(taps):
+            p = p0 + float(i) * step
+            idx = p.astype(np.int64)
+            live = (idx < nwin - 1) & ok(i)
+            if not live.any():
+                break
+            idx = np.where(live, idx, 0)
+            w = win[idx] + (p - idx) * delta[idx]
+            term = np.where(live, w * x[np.where(live, src(i), 0)], 0.0)
+            y = (y.astype(np.float64) + term).astype(dtype)
+    wing(frac * table, lambda i: n - i, lambda i: n - i >= 0)
+    wing((scale - frac) * table, lambda i: n + i + 1, lambda i: n + i + 1 < n_orig)
+    return y
+
+
 def to_mono(audio: np.ndarray) -> np.ndarray:
     """librosa.to_mono(audio.T) of a (frames, channels) array as soundfile returns it (my_utils.py:10-11)."""
     a = np.asarray(audio, dtype=np.float64)
@@ -93,7 +140,7 @@ def load_audio_from_array(audio: np.ndarray, sr: int, sample_rate: int) -> np.nd
     """my_utils.py:9-16 after ``sf.read``: mono mean -> resample (when the rates differ) -> flatten."""
     a = to_mono(audio)
     if sr != sample_rate:
-        a = resample_kaiser_best(a, sr, sample_rate)
+        a = resample_kaiser_hq(a, sr, sample_rate)
     return a.flatten()
 
 

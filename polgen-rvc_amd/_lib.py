@@ -82,9 +82,9 @@ SYMBOLS = [
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convblock2d", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
-    "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers",
+    "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers", "rvcx_fp32_pinned",
     "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
-    "rvcx_resample_len", "rvcx_resample_f64", "rvcx_bench_gemm", "rvcx_device_info",
+    "rvcx_resample_len", "rvcx_resample_f64", "rvcx_resample_f64_kind", "rvcx_bench_gemm", "rvcx_device_info",
     "rvcx_op_resblock3", "rvcx_flac_encode_bound", "rvcx_flac_encode_s16", "rvcx_flac_info", "rvcx_flac_decode_s32", "rvcx_flac_last_error",
 ]
 
@@ -751,14 +751,15 @@ class Context:
                                         C.byref(got)), "get_f0_x_ex")
         return coarse[:got.value].copy(), f0[:got.value].copy()
 
-    def resample(self, audio, sr_in: int, sr_out: int) -> np.ndarray:
-        """librosa.resample(librosa.to_mono(audio.T), sr_in -> sr_out): audio (frames,) or (frames, channels) -> float64 mono"""
+    def resample(self, audio, sr_in: int, sr_out: int, kind: int = -1) -> np.ndarray:
+        """librosa.resample(librosa.to_mono(audio.T), sr_in -> sr_out): audio (frames,) or (frames, channels) -> float64 mono.
+        kind -1: the default filter (kaiser_hq: a Kaiser design to soxr_hq's published targets), 1: resampy's kaiser_best"""
         a = np.ascontiguousarray(audio, dtype=np.float64)
         frames, ch = a.shape[0], (1 if a.ndim == 1 else a.shape[1])
         n_out = int(lib().rvcx_resample_len(C.c_int64(frames), int(sr_in), int(sr_out)))
         y = np.empty(max(n_out, 0), np.float64)
-        self._ck(lib().rvcx_resample_f64(self._h, _p(a, C.c_double), C.c_int64(frames), ch, int(sr_in), int(sr_out),
-                                         _p(y, C.c_double)), "resample_f64")
+        self._ck(lib().rvcx_resample_f64_kind(self._h, _p(a, C.c_double), C.c_int64(frames), ch, int(sr_in), int(sr_out),
+                                              int(kind), _p(y, C.c_double)), "resample_f64")
         return y
 
     def vc_frames(self, n: int) -> int:
@@ -871,6 +872,13 @@ class Context:
     def fp32_reruns(self) -> int:
         """calls repeated on the exact-fp32 kernels after an fp16-split overflow"""
         return int(lib().rvcx_fp32_reruns(self._h))
+
+    def fp32_pinned(self) -> str:
+        """text, one line per layer the range guard pinned to the exact-fp32 kernels at run time (rvcx_fp32_pinned)"""
+        buf = C.create_string_buffer(1 << 16)
+        if lib().rvcx_fp32_pinned(self._h, buf, len(buf)) < 0:
+            raise RvcxError("fp32_pinned")
+        return buf.value.decode()
 
     def fp32_layers(self) -> int:
         """layers pinned to the exact-fp32 kernels after an activation left fp16 range (sticky per model)"""

@@ -272,6 +272,23 @@ int64_t rvcx_fp32_layers(rvcx_ctx* ctx) {
   return n;
 }
 
+int rvcx_fp32_pinned(rvcx_ctx* ctx, char* buf, int cap) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
+  if (!ctx || !buf || cap <= 0) return -1;
+  Ctx& c = ctx->c;
+  std::string t;
+  if (c.hubert) t += c.hubert->region->pinned_text("hubert");
+  if (c.rmvpe) t += c.rmvpe->region->pinned_text("rmvpe");
+  if (c.fcpe) t += c.fcpe->region->pinned_text("fcpe");
+  if (c.crepe) t += c.crepe->region->pinned_text("crepe");
+  for (size_t i = 0; i < c.synths.size(); ++i)
+    if (c.synths[i]) t += c.synths[i]->region->pinned_text("voice model " + std::to_string(i));
+  const int n = (int)std::min<size_t>(t.size(), (size_t)cap - 1);
+  memcpy(buf, t.data(), (size_t)n);
+  buf[n] = 0;
+  return (int)t.size();
+}
+
 int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { CtxLock ctx_guard_ = lock_ctx(ctx); return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
 
 int64_t rvcx_index_exhaustive(rvcx_ctx* ctx) {
@@ -1611,21 +1628,26 @@ int64_t rvcx_resample_len(int64_t n, int sr_in, int sr_out) {
   return (sr_in > 0 && sr_out > 0 && n >= 0) ? (int64_t)resample_out_len((long)n, sr_in, sr_out) : -1;
 }
 
-int rvcx_resample_f64(rvcx_ctx* ctx, const double* x, int64_t frames, int channels, int sr_in, int sr_out, double* y) {
+int rvcx_resample_f64_kind(rvcx_ctx* ctx, const double* x, int64_t frames, int channels, int sr_in, int sr_out, int kind,
+                           double* y) {
   API_BEGIN(ctx)
   if (!x || !y || frames <= 0 || channels < 1 || sr_in <= 0 || sr_out <= 0) fail("resample: bad argument");
   const long n_out = resample_out_len((long)frames, sr_in, sr_out);
-  C->arena.reserve(((size_t)frames * channels + (size_t)n_out) * 8 + ((size_t)2 << 20));
+  C->arena.reserve(((size_t)frames * channels + (size_t)n_out) * 8 + ((size_t)8 << 20));
   C->arena.reset();
   hipStream_t s = C->stream;
   double* dx = any_to_dev(*C, x, (size_t)frames * channels);
   double* dy = C->arena.alloc<double>((size_t)std::max<long>(n_out, 1));
-  const ResampleFilter f = make_resample_filter(C->arena, sr_in, sr_out, s);
+  const ResampleFilter f = make_resample_filter(C->arena, sr_in, sr_out, s, kind);
   launch_resample_f64(f, dx, (long)frames, channels, dy, n_out, s);
   RVCX_HIP(hipMemcpyAsync(y, dy, (size_t)n_out * 8, hipMemcpyDefault, s));
   RVCX_HIP(hipStreamSynchronize(s));
   C->arena.reset();
   API_END
+}
+
+int rvcx_resample_f64(rvcx_ctx* ctx, const double* x, int64_t frames, int channels, int sr_in, int sr_out, double* y) {
+  return rvcx_resample_f64_kind(ctx, x, frames, channels, sr_in, sr_out, -1, y);
 }
 
 int rvcx_vc_frames(rvcx_ctx* ctx, int64_t n) {

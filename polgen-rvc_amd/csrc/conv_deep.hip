@@ -265,8 +265,10 @@ int ws_mode() {      // 0 off; 1 (default): the 2-D maps of the F0 U-Net; 2: + t
 int conv_ws_segments(const ConvArgs& a) {
   const int nchunk = a.Cin_gp / 16;
   const long base = (long)(a.Cout_gp / kWsBM) * cdiv(a.Nout, kWsBN);
+  // as many segments as fill the chip with ONE workgroup per CU (a second round of workgroups doubles the launch's time),
+  // each of at least two chunks (a one-chunk segment has nothing to overlap its loads with)
   int S = 1;
-  while (base * S < 192 && S < 16 && nchunk % (2 * S) == 0 && nchunk / (2 * S) >= 1) S *= 2;
+  while (base * S * 2 <= 256 && S < 16 && nchunk % (2 * S) == 0 && nchunk / (2 * S) >= 2) S *= 2;
   if (g_conv_override.splitk > 0 && nchunk % g_conv_override.splitk == 0) S = g_conv_override.splitk;   // tests
   return S;
 }
@@ -290,10 +292,15 @@ bool conv_deep_ok(const ConvArgs& a) {
   const int ksteps = a.ksize * (a.Cin_gp / 16);
   const bool map2d = a.kw < a.ksize;
   if (mode == 1) {
-    // the F0 U-Net from 64 channels up: (Cout >= 64 is implied by Cout_gp % 64) 2-D maps of at most 32 768 positions per item
-    if (!map2d || a.Nout > 32768 || ksteps < 36) return false;
+    // Default: the 3 x 3 convs of the F0 U-Net with >= 256 input channels (levels 4 / 5, the intermediate layers, the first
+    // decoder blocks).  Measured in round 6 (tools/bench_ws.py, tools/prof_rmvpe.py; LABNOTES 12): in a batch of 16 the
+    // 512 -> 512 layers take 199 us against 262 on the 64 x 64 tile and 256 -> 256 211 against 311; a single clip is level
+    // (32 us either way: two launches and the slabs' trip through HBM are the floor); below 256 channels, on the 2 x 2
+    // polyphase ConvTranspose2d and on every 1-D layer of the synthesizer the 64 x 64 tile at three workgroups per CU is
+    // as fast or faster (the tile form is not what bounds the split-fp16 kernels) -- those stay where they were.
+    if (!map2d || a.ksize != 9 || a.Cin_gp < 256 || a.Nout > 32768) return false;
   } else {
-    if (ksteps < 36) return false;
+    if (ksteps < 32) return false;
   }
   // the segment slabs must fit the caller's scratch, per item and for the batch
   const int S = conv_ws_segments(a);

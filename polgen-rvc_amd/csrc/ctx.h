@@ -96,9 +96,23 @@ class WeightRegion {
   void drop_flag(int index) {
     flags_[index] = 0;
     ++dropped_;
+    pinned_.push_back(index);
     if (!chunks_.empty()) RVCX_HIP(hipMemcpy(chunks_[0].base, flags_.get(), kMaxFlags, hipMemcpyHostToDevice));
   }
   int dropped() const { return dropped_; }
+  // what a flag stands for ("conv 128 <- 128 x 7", "attention"): host-side, for rvcx_fp32_pinned; not part of the layout
+  void describe_flag(const uint8_t* flag, const std::string& what) {
+    const size_t i = (size_t)(flag - flags_.get());
+    if (desc_.size() <= i) desc_.resize(i + 1);
+    desc_[i] = what;
+  }
+  std::string pinned_text(const std::string& region) const {
+    std::string t;
+    for (int i : pinned_)
+      t += region + ": layer " + std::to_string(i) + " of " + std::to_string(nflags_) + " (" +
+           ((size_t)i < desc_.size() && !desc_[i].empty() ? desc_[i] : std::string("?")) + ")\n";
+    return t;
+  }
   void seal() {     // publish the host flags into the device header (end of a load)
     if (chunks_.empty()) reserve(256);
     RVCX_HIP(hipMemcpy(chunks_[0].base, flags_.get(), kMaxFlags, hipMemcpyHostToDevice));
@@ -137,6 +151,8 @@ class WeightRegion {
   std::unique_ptr<uint8_t[]> flags_;
   int* ovf_words_ = nullptr;
   int nflags_ = 0, dropped_ = 0;
+  std::vector<int> pinned_;            // flag indices dropped at run time, in order
+  std::vector<std::string> desc_;
   uint64_t hash_ = 1469598103934665603ull;
 };
 
@@ -297,6 +313,7 @@ inline AttFlag make_att_flag(Ctx& c) {
   AttFlag f;
   f.ok = c.slab.new_flag(true);
   f.word = c.slab.cur().ovf_word(f.ok);
+  c.slab.cur().describe_flag(f.ok, "attention call");
   return f;
 }
 

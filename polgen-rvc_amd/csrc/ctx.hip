@@ -183,6 +183,9 @@ static void upload_h3(Ctx& c, ConvW& L, const std::vector<float>& wp, int k) {
   L.w_h3 = hp.empty() ? c.slab.cur().reserve(n * sizeof(float)) : c.slab.upload(hp);
   L.h3_ok = c.slab.new_flag(!hp.empty());
   L.ovf_word = c.slab.cur().ovf_word(L.h3_ok);
+  c.slab.cur().describe_flag(L.h3_ok, "conv " + std::to_string(L.cout) + " <- " + std::to_string(L.cin) + " x " + std::to_string(k) +
+                                          (L.groups > 1 ? " groups " + std::to_string(L.groups) : std::string()) +
+                                          (hp.empty() ? ", weights beyond fp16 range at load" : ""));
 }
 
 ConvW make_conv(Ctx& c, const float* w, const float* bias, int cout, int cin_g, int k, int groups, bool h3) {

@@ -114,15 +114,18 @@ void launch_f0_override(const double* rep, int count, int start, float* f0, int*
                         double f0_max, hipStream_t s);
 std::vector<double> f0_file_track(const float* tbl, int rows);   // host: np.interp restated (see ops.hip)
 
-// ---- audio.hip: librosa.resample stand-in (resampy "kaiser_best", see the file header)
+// ---- audio.hip: librosa.resample stand-in (kind 0: "kaiser_hq", a Kaiser design to soxr_hq's published targets -- the
+// default; kind 1: resampy's published "kaiser_best"; see the file header)
 struct ResampleFilter {
-  const double* win = nullptr;     // device: interp_win, kWin doubles
+  const double* win = nullptr;     // device: interp_win, nwin doubles
   const double* delta = nullptr;   // device: forward differences
   double scale = 1.0, time_increment = 1.0;
-  int index_step = 512;
+  int index_step = 512;            // kaiser_best: int(scale * table)
+  int table = 512, nwin = 0, exact = 0;
 };
 long resample_out_len(long n, int sr_in, int sr_out);                // int(n * sr_out / sr_in)
-ResampleFilter make_resample_filter(Arena& A, int sr_in, int sr_out, hipStream_t s);
+int resample_default_kind();                                         // RVCX_RESAMPLER=kaiser_best -> 1, else 0
+ResampleFilter make_resample_filter(Arena& A, int sr_in, int sr_out, hipStream_t s, int kind = -1);
 // x: (n frames, channels) interleaved float64, averaged over the channels on the fly; y: n_out mono samples
 void launch_resample_f64(const ResampleFilter& f, const double* x, long n, int channels, double* y, long n_out,
                          hipStream_t s);

@@ -8,8 +8,10 @@ with the library's own host-side decoder (csrc/flac.hip: the whole format, CRC /
 ogg, ...) raises a clear error naming the missing decoder -- this image has neither soundfile nor ffmpeg.
 Encoding: ``rvc_infer`` writes WAV bytes whatever the extension (infer.py:153) -- kept, except that a path ending in
 ".flac" gets a real FLAC stream (``write_output``; 16-bit, lossless, csrc/flac.hip).
-Resampling runs on the GPU (``rvcx_resample_f64``, csrc/audio.hip): resampy's published "kaiser_best" filter;
-``librosa.resample``'s current default (soxr_hq) is not published as a formula -- parity unpinned, see oracle/audio.py.
+Resampling runs on the GPU (``rvcx_resample_f64``, csrc/audio.hip): a Kaiser-windowed sinc designed to the published
+targets of ``librosa.resample``'s default (soxr_hq: flat to 0.9136 x Nyquist, -120 dB from Nyquist; measured +-0.001 dB /
+-127 dB); libsoxr's own coefficients are unpublished -- parity unpinned, bounded by those targets (oracle/audio.py);
+``RVCX_RESAMPLER=kaiser_best`` selects resampy's published filter (librosa's default before 0.10).
 """
 from __future__ import annotations
 

@@ -208,8 +208,8 @@ def get_vc(device, is_half, config, model_path, cpt=None):
 def load_audio(file, sample_rate, *, device=None):
     """rvc/lib/my_utils.py:5-16 (`device`: keyword-only extra, default = the GPU this process already serves): read -> mono mean -> resample -> flatten (float64).  Decoding: infer/audio.py
     (soundfile when installed, RIFF/WAVE otherwise).  The mono mix and the rate conversion run on the GPU in one pass
-    (``rvcx_resample_f64``): resampy's "kaiser_best" band-limited interpolation; librosa's current default, soxr_hq, is
-    not published as a formula, so this edge stays "parity unpinned" (oracle/audio.py restates what is computed)."""
+    (``rvcx_resample_f64``): a Kaiser-windowed sinc designed to soxr_hq's published targets (librosa's default res_type;
+    libsoxr's coefficients are unpublished, so this edge is "parity unpinned, within the published spec": oracle/audio.py)"""
     try:
         file = file.strip(" ").strip('"').strip("\n").strip('"').strip(" ")
         from .audio import read_audio

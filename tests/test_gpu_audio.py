@@ -1,6 +1,7 @@
 """Audio I/O edges on the GPU: the device resampler behind ``load_audio`` (rvc/lib/my_utils.py:5-16) and
 VC.pipeline's ``resample_sr`` branch (rvc/infer/pipeline.py:453-454) against the oracle's numpy restatement of the same
-published algorithm (oracle/audio.py: resampy "kaiser_best"; parity unpinned against soxr, librosa's current default)."""
+arithmetic (oracle/audio.py: "kaiser_hq", the Kaiser design to soxr_hq's published targets that is the default since
+round 6, and resampy's published "kaiser_best"; parity unpinned against libsoxr itself)."""
 import numpy as np
 import pytest
 
@@ -26,6 +27,9 @@ def test_resample_to_16k_vs_oracle(ctx, sr, channels, seconds):
     e = np.abs(got - want).max()
     print(f"{sr} Hz x{channels} -> 16 kHz: {len(got)} samples, max abs diff vs oracle {e:.2e}")
     assert e < 1e-12                                  # same table, same taps, same order: only fma / i0 rounding differs
+    # the published resampy filter stays selectable (librosa's default before 0.10), in its published arithmetic
+    want_kb = OA.resample_kaiser_best(OA.to_mono(audio), sr, 16000)
+    assert np.abs(ctx.resample(audio, sr, 16000, kind=1) - want_kb).max() < 1e-12
     # and the result is a faithful band-limited copy: the 330 Hz tone keeps its level within the filter's known gain
     if channels == 1 and sr > 16000:
         ref = 0.4 * np.sin(2 * np.pi * 330.0 * np.arange(len(got)) / 16000)
@@ -72,7 +76,7 @@ def test_pipeline_resample_sr_vs_oracle(ctx):
     pcm0, f0 = vc.pipeline(*args, 0, *tail, return_f32=True)                   # resample_sr = 0: off
     assert tgt_sr == 4800
     pcm1, f1 = vc.pipeline(*args, 16000, *tail, return_f32=True)               # 4800 -> 16000
-    want = OA.resample_kaiser_best(f0.astype(np.float64), tgt_sr, 16000)
+    want = OA.resample_kaiser_hq(f0.astype(np.float64), tgt_sr, 16000, dtype=np.float32)
     assert len(pcm1) == len(f1) == len(want) == int(len(f0) * (16000 / tgt_sr))
     e = rms(f1 - want) / rms(want)
     print(f"resample_sr {tgt_sr} -> 16000: rel diff vs oracle {e:.2e}")

@@ -32,7 +32,7 @@ def row(tag, fn, gflop):
             us, tiles = timed(fn)
         finally:
             ctx.conv_override(-1, -1, -1)
-        out.append(f"{name} {us:7.1f} us {gflop / us * 1e-3:6.1f} TF/s [{tiles}]")
+        out.append(f"{name} {us:7.1f} us {gflop / us * 1e3:6.1f} TF/s [{tiles}]")
     print(f"{tag:38s} " + "   ".join(out), flush=True)
 
 
