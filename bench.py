@@ -58,12 +58,12 @@ DOM_ALGO_BYTES_PER_LAUNCH = 2 * 128 * 383760 * 4
 PEAK_FILE = "mfma_peak_r04.json"   # profiles/: measured split-fp16 ceiling on random operands (tools/mfma_peak.hip)
 
 
-def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False, outliers=False):
+def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False, outliers=False, dec_outliers=False):
     """zero: this rank receives rank 0's folded weights by broadcast -- it loads shape-only placeholders (zeros, no
     random numbers drawn: the region layout depends on shapes only)."""
     if zero:
         with S.shapes_only():
-            return load_models(ctx, False, fcpe, also_40k, crepe, outliers)
+            return load_models(ctx, False, fcpe, also_40k, crepe, outliers, dec_outliers)
 
     def z(state):
         return state
@@ -76,8 +76,10 @@ def load_models(ctx, zero=False, fcpe=False, also_40k=False, crepe=False, outlie
         sd = S.fcpe_state(S.FCPE_CFG_FULL, 0)
         ctx.load_fcpe(W.fcpe_cfg_struct(W.fcpe_cfg_from_state(sd)), z(sd))
     else:
-        ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, 0)))
-    mid48 = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, 0)))
+        ctx.load_rmvpe(W.rmvpe_cfg_struct(S.RMVPE_CFG_FULL), z(S.rmvpe_state(S.RMVPE_CFG_FULL, 0, outliers=dec_outliers)))
+    # dec_outliers: planted outlier channels in the NSF decoder (weight-norm g spread 1 : 150, c1 -> c2 hand-offs of a few
+    # hundred) and in the F0 U-Net (BatchNorm scale x 150), function-preserving (synthetic.py)
+    mid48 = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_48K, 768), z(S.synth_state(S.SYNTH_CFG_48K, 0, outliers=dec_outliers)))
     if not also_40k:
         return mid48
     mid40 = ctx.load_synth(W.synth_cfg_struct(S.SYNTH_CFG_40K, 768), z(S.synth_state(S.SYNTH_CFG_40K, 1)))
@@ -235,6 +237,25 @@ def outliers_child(steps, warmup):
     return out
 
 
+def decoder_outliers_child(steps, warmup):
+    """C2 again with outlier channels planted in the NSF decoder and the F0 U-Net: the split kernels'
+    range guard must leave (almost) every layer where it is -- `fast_path` shows what it pinned during warm-up."""
+    out, _ = child_bench(["--steps", str(steps), "--warmup", str(max(3, warmup)), "--decoder-outliers"], {},
+                         {"workload": "c2 with outlier channels planted in the NSF decoder (conv_pre / ups.0 and one step of every "
+                                      "ResBlock1: x150 / /150) and in the F0 U-Net (BatchNorm scale x150 in eight blocks)"},
+                         roofline=False)
+    return out
+
+
+def long_clip_child():
+    """The reference's real workload in small: one 95 s clip per step -- F0 once over 9 700 frames, three silence-aligned
+    chunks through HuBERT / TextEncoder / flow / decoder (the branch tests/test_gpu_round6.py pins to the reference)."""
+    out, _ = child_bench(["--steps", "5", "--warmup", "2", "--clip-seconds", "95"], {},
+                         {"workload": "one 95 s 16 kHz clip per step (3 chunks), RVC v2 48k, rmvpe+, geometry (1,6,38,41)"},
+                         roofline=False)
+    return out
+
+
 def c3_child():
     """BASELINE configs[2] at its stated size: 64 x 30 s per step, index_rate 0.75 over 65 536 x 768."""
     out, d = child_bench(["--workload", "c3", "--steps", "3", "--warmup", "1"], {},
@@ -357,6 +378,9 @@ def main():
     ap.add_argument("--profile-out", default="")
     ap.add_argument("--hubert-outliers", action="store_true",
                     help="HuBERT with planted massive-activation units (what real ContentVec-shaped weights do to the range guard)")
+    ap.add_argument("--decoder-outliers", action="store_true",
+                    help="NSF decoder and F0 U-Net with planted outlier channels (synthetic.synth_state / rmvpe_state(outliers=True))")
+    ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS, help="clip length of the c2 / c3 workloads (default 30)")
     ap.add_argument("--verify-ranks", action="store_true",
                     help="every rank converts one probe clip after the weight broadcast; rank 0 reports whether all PCM digests agree")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing run (gloo): launcher, shard, timing")
@@ -381,9 +405,13 @@ def main():
     if a.dry_run:
         return dry_run(a, rank, world)
     fp32 = c3_obj = c5_obj = out_obj = dec_out_obj = long_obj = None
-    if world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe and not a.hubert_outliers:
+    clip_seconds = float(a.clip_seconds)
+    if (world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe and not a.hubert_outliers
+            and not a.decoder_outliers and clip_seconds == CLIP_SECONDS):
         fp32 = exact_fp32_child(a.steps, a.warmup)       # all before the first GPU call of this process
         out_obj = outliers_child(a.steps, a.warmup)
+        dec_out_obj = decoder_outliers_child(a.steps, a.warmup)
+        long_obj = long_clip_child()
         c3_obj = c3_child()
         c5_obj = c5_child()
         time.sleep(5.0)                                  # the children left the chip warm: let it idle before the headline loop
@@ -394,7 +422,8 @@ def main():
 
     # rank 0 parses/folds/packs the checkpoints; the folded weight regions go to the other GPUs over RCCL/xGMI
     t0 = time.perf_counter()
-    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5, crepe=crepe, outliers=a.hubert_outliers)
+    mids = load_models(ctx, zero=(rank != 0), fcpe=fcpe, also_40k=c5, crepe=crepe, outliers=a.hubert_outliers,
+                       dec_outliers=a.decoder_outliers)
     mid = mids[0] if c5 else mids
     if c3:
         big = S.make_index(C3_INDEX_ROWS, 768, 0)
@@ -424,9 +453,9 @@ def main():
         model_of = [mids[1] if i % 2 == 0 else mids[0] for i in mine]       # even -> 40 k, odd -> 48 k
         audio_seconds_per_step = sum(lengths) / 16000.0                     # the whole job's, all ranks
     else:
-        clips = [S.make_clip(rank * B + i, CLIP_SECONDS) for i in range(B)]
+        clips = [S.make_clip(rank * B + i, clip_seconds) for i in range(B)]
         model_of = [mid] * B
-        audio_seconds_per_step = world * B * CLIP_SECONDS
+        audio_seconds_per_step = world * B * clip_seconds
     wavs = [torch.from_numpy(c).pin_memory() for c in clips]
     outs = [torch.empty(ctx.out_capacity(m, c.shape[0], params), dtype=torch.int16).pin_memory()
             for c, m in zip(clips, model_of)]
@@ -461,7 +490,7 @@ def main():
     # boost clock (DESIGN.md "What sustained load does").  For the record, NOT the headline: the same step 80 more times
     # (~2 s of uninterrupted load), reported as `sustained`.
     sustained = None
-    if world == 1 and not (c3 or c5) and not fcpe and B == 1 and not a.no_roofline:
+    if world == 1 and not (c3 or c5) and not fcpe and B == 1 and not a.no_roofline and clip_seconds == CLIP_SECONDS:
         n_sus = 80
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -554,7 +583,8 @@ def main():
                 wl = (f"C4 (BASELINE configs[3]): {world * B} x 30 s clips sharded {world} ways ({B} per rank), weights "
                       "broadcast from rank 0 over RCCL/xGMI, no collective in the hot loop; per rank: ") + wl
         else:
-            wl = (("single 30 s 16 kHz clip per GPU per step" if B == 1 else f"{B} x 30 s 16 kHz clips per GPU per step") +
+            cs = f"{clip_seconds:g}"
+            wl = ((f"single {cs} s 16 kHz clip per GPU per step" if B == 1 else f"{B} x {cs} s 16 kHz clips per GPU per step") +
                   ", RVC v2 48k, f0_method=rmvpe+, HuBERT-base, index_rate=0, geometry (1,6,38,41)")
         if fcpe:
             wl = wl.replace("f0_method=rmvpe+", f"f0_method={a.f0_method} (secondary line: BASELINE's metric is quoted on rmvpe+)")
@@ -624,7 +654,8 @@ def main():
         if c5_obj is not None:
             res["c5"] = c5_obj
         if fp32 is not None or c3_obj is not None:
-            res["order"] = "children (exact_fp32, outliers, c3, c5) ran first, each to completion; 5 s idle; then this process's warm-up and timed loop"
+            res["order"] = ("children (exact_fp32, outliers, decoder_outliers, long_clip, c3, c5) ran first, each to completion; 5 s idle; "
+                            "then this process's warm-up and timed loop")
         if not a.no_cpu_baseline and world == 1 and not fcpe:
             res["cpu_baseline"] = cpu_baseline()
         else:

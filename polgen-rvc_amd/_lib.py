@@ -802,11 +802,11 @@ class Context:
         self._ck(lib().rvcx_weights_adopt(self._h), "weights_adopt")
 
     def conv_profile_begin(self):
-        z = (C.c_int64 * 64)()
+        z = (C.c_int64 * 72)()
         self._ck(lib().rvcx_conv_profile(self._h, 1, z, None, None, None, None, None, 0), "conv_profile")
 
     def conv_profile_end(self):
-        N = 64
+        N = 72
         la, fl, ms = (C.c_int64 * N)(), (C.c_double * N)(), (C.c_double * N)()
         bm, bn, kd = (C.c_int32 * N)(), (C.c_int32 * N)(), (C.c_int32 * N)()
         self._ck(lib().rvcx_conv_profile(self._h, 0, la, fl, ms, bm, bn, kd, N), "conv_profile")
@@ -816,6 +816,8 @@ class Context:
                 return f"conv_mfma_kernel<{bm[i]},{bn[i]}> (generic, strided/grouped)"
             if kd[i] == 600001:
                 return "gemm_f32<64,64> (time-major Linear, exact fp32)"
+            if kd[i] == 600002:
+                return f"gemm_bd<{bm[i]},{bn[i]}> (time-major Linear, activations straight from global memory)"
             if kd[i] >= 600000:
                 return f"gemm_h3<{bm[i]},{bn[i]}> (time-major Linear)"
             if kd[i] == 500003:

@@ -67,6 +67,9 @@ void build_window(const FilterSpec& F, double gain, std::vector<double>& win, st
     const long double taper = bessel_i0((long double)F.beta * sqrtl(std::max(0.0L, 1.0L - r * r))) / i0b;
     win[i] = (double)taper * (F.rolloff * sinc) * gain;
   }
+  // exact tap positions: the last tap of a wing can lie within rounding of the window's edge, where a Kaiser window is not
+  // zero (1e-8 of the peak) -- the final table sample is zero, so the weight runs out continuously (oracle/audio.py)
+  if (F.exact) win[n] = 0.0;
   for (int i = 0; i < n; ++i) delta[i] = win[i + 1] - win[i];
 }
 

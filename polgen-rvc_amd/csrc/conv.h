@@ -155,7 +155,7 @@ struct ConvProfile;
 void resblock_pair_describe(ConvProfile* p);
 
 struct ConvProfile {
-  static constexpr int kMaxTiles = 64;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
+  static constexpr int kMaxTiles = 72;   // 0-7 generic tiles, 8.. stride-1 family (sb), 24.. (DMA double-buffered)
   long launches[kMaxTiles] = {0};
   double flops[kMaxTiles] = {0};
   double ms[kMaxTiles] = {0};

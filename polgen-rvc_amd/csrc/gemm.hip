@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
+#include <utility>
 
 #include "conv.h"
 #include "conv_device.h"
@@ -282,6 +284,182 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const GemmArgs a) {
   if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
 }
 
+
+// ---- gemm_bd_kernel (round 6): the same arithmetic with the ACTIVATIONS fed straight from global memory ----------------
+// gemm_h3_kernel stages both operands through LDS: per 16-channel chunk a 64 x 64 wave tile reads eight 16-byte fragments
+// for twelve MFMAs, and a 128 x 128 workgroup commits another 16 KB -- 125 B / clk / CU of LDS traffic with two
+// workgroups per CU against the ~115 the LDS delivers for 16-byte reads (LABNOTES "Round 4 (a)"): the batched Linear
+// layers of HuBERT sat at 150 - 185 TFLOP/s because of it.  The split input image is ALREADY the MFMA B fragment (a row's
+// 16-byte element (op, h) of a chunk is exactly what lane (row, h) feeds), so here a wave loads its own 64 rows' fragments
+// with plain 16-byte buffer loads -- no LDS write, no LDS read, no sharing needed: the four waves of a workgroup own
+// DIFFERENT rows -- and only the weights (shared by all four waves) go through LDS.  Tile: 128 output channels x 256 rows
+// (a wave = 128 x 64: eight accumulators); per chunk and wave 8 weight-fragment reads for 24 MFMAs (0.33 per MFMA against
+// 0.67), LDS traffic per CU a third.  Same k-order (chunk-major, hh / hl / lh), same epilogue: bit-identical to every
+// gemm_h3 tile.  WN = 1 (128 x 128) is the form for the long-K layers, whose four K segments need a second accumulator set.
+template <typename F, int... N>
+__device__ __forceinline__ void gemm_for_tiles(std::integer_sequence<int, N...>, F&& f) {
+  (f(std::integral_constant<int, N>{}), ...);
+}
+
+template <int WN, int NSEG>
+__global__ __launch_bounds__(256, 2) void gemm_bd_kernel(const GemmArgs a) {
+  constexpr int BM = 128, WM = 4, BN = 4 * WN * 32;
+  constexpr int A_ST = kKC * 4 * BM;                     // 16-byte elements of one weight stage
+  constexpr int NA = A_ST / 256;
+  __shared__ uint4 As[2][A_ST];                          // [buf][cl][op*2 + h][co]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.y * BM;
+  const long n0 = (long)blockIdx.x * BN;
+  const int nchunk = a.cin_p / 16;
+  const int nst = (nchunk + kKC - 1) / kKC;
+  const int seg_len = nst / NSEG;
+  const H3Rsrc wres = h3_rsrc(a.w_h3, nchunk * 4 * a.cout_p * 16);
+  const long rows_here = a.rows - n0 < BN ? a.rows - n0 : BN;
+  const H3Rsrc xres = h3_rsrc(static_cast<const char*>(a.xs) + n0 * a.ld_xs, (int)(rows_here * a.ld_xs));
+  const int slab = 4 * a.cout_p * 16;
+  const int row_bytes = a.cin_p * 4;
+
+  int a_off[NA], a_cl[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int e = tid + 256 * j;                         // (cl, oph, co)
+    const int co = e % BM, rest = e / BM;
+    a_cl[j] = rest >> 2;
+    a_off[j] = co0 + co < a.cout_p ? ((rest & 3) * a.cout_p + co0 + co) * 16 : kH3Oob;
+  }
+  // this lane's rows: block n of the wave's 64-row strip; byte offset of (row, h) inside the tile's buffer
+  int b_off[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) {
+    const int p = wave * (WN * 32) + n * 32 + i;
+    b_off[n] = p < rows_here ? (int)(p * a.ld_xs) + h * 16 : kH3Oob;
+  }
+
+  // Registers: ONE weight set (stage st + 1 travels in it while stage st is multiplied) and one fragment set per chunk of a
+  // stage (refilled with the next stage's chunk right behind its last use) -- two full sets of each spilled at 256 registers
+  uint4 ra[NA];
+  uint4 rb[kKC][2][WN];                                  // [cl][op][n]
+  auto fetch_a = [&](int st) {
+    const int c0 = st * kKC;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int ch = c0 + a_cl[j];
+      ra[j] = h3_load4(wres, (a_off[j] != kH3Oob && ch < nchunk) ? ch * slab + a_off[j] : kH3Oob);
+    }
+  };
+  auto fetch_b = [&](int st, auto clt) {
+    constexpr int cl = decltype(clt)::value;
+    const int cb = (st * kKC + cl) * 64;                  // byte offset of the chunk inside a row
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+        rb[cl][op][n] = h3_load4(xres, (b_off[n] != kH3Oob && cb < row_bytes) ? b_off[n] + cb + op * 32 : kH3Oob);
+  };
+  auto commit_a = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) As[buf][tid + 256 * j] = ra[j];
+  };
+  auto lds_barrier = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  auto compute = [&](int buf, auto clt) {
+    constexpr int cl = decltype(clt)::value;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      const half8 af0 = __builtin_bit_cast(half8, As[buf][(cl * 4 + 0 + h) * BM + m * 32 + i]);
+      const half8 af2 = __builtin_bit_cast(half8, As[buf][(cl * 4 + 2 + h) * BM + m * 32 + i]);
+      const half8 af1 = af0 * (_Float16)(1.f / kH3Scale);
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const half8 bf0 = __builtin_bit_cast(half8, rb[cl][0][n]);
+        const half8 bf1 = __builtin_bit_cast(half8, rb[cl][1][n]);
+        acc[m][n] = h3_mfma(af0, bf0, acc[m][n]);          // (S wh) xh
+        acc[m][n] = h3_mfma(af1, bf1, acc[m][n]);          // wh (S xl)
+        acc[m][n] = h3_mfma(af2, bf0, acc[m][n]);          // (S wl) xh
+      }
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  static_assert(kKC == 2, "gemm_bd: two chunks per stage");
+  // iteration st: the weights of stage st + 1 (fetched during iteration st - 1) go to LDS buffer (st + 1) & 1 -- nobody reads
+  // it any more -- and stage st + 2 is requested; each chunk's MFMAs are followed by the request for the same chunk of the
+  // next stage into the fragment registers they just freed
+  auto iter = [&](int st) {
+    if (st + 1 < nst) commit_a((st + 1) & 1);
+    fetch_a(st + 2);
+    compute(st & 1, C0{});
+    fetch_b(st + 1, C0{});
+    compute(st & 1, C1{});
+    fetch_b(st + 1, C1{});
+    lds_barrier();
+  };
+
+  bool dead = false;
+  if (a.lens) {
+    const long last = (n0 + BN <= a.rows ? n0 + BN : a.rows) - 1;
+    const long b0 = n0 / a.T;
+    dead = last / a.T == b0 && (int)(n0 - b0 * a.T) >= a.lens[b0];
+  }
+  if (!dead) {
+    fetch_a(0);
+    fetch_b(0, C0{});
+    fetch_b(0, C1{});
+    commit_a(0);
+    fetch_a(1);
+    lds_barrier();
+    if constexpr (NSEG > 1) {
+      f32x16 tot[WM][WN];
+      for (int st = 0; st < nst; ++st) {
+        iter(st);
+        if ((st + 1) % seg_len == 0) {       // a segment ends here: fold its sum, start the next from zero
+          const bool first = st + 1 == seg_len;
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                tot[m][n][r] = first ? acc[m][n][r] : tot[m][n][r] + acc[m][n][r];
+                acc[m][n][r] = 0.f;
+              }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = tot[m][n];
+    } else {
+      for (int st = 0; st < nst; ++st) iter(st);
+    }
+  }
+  constexpr float inv = 1.f / kH3Scale;
+  bool ovf = false;
+  // compile-time loop over the eight accumulator tiles: a `#pragma unroll` loop around the inlined epilogue is silently left
+  // rolled, the accumulators are then indexed at run time and live in scratch (conv_deep.hip has the same note)
+  gemm_for_tiles(std::make_integer_sequence<int, WM * WN>{}, [&](auto tt) {
+    constexpr int m = decltype(tt)::value / WN, n = decltype(tt)::value % WN;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][n][r] *= inv;
+    gemm_store_tile(a, co0 + m * 32, n0 + wave * (WN * 32) + n * 32 + i, h, acc[m][n], ovf);
+  });
+  if (ovf) report_h3_overflow(a.ovf, a.ovf_next, a.seq);
+}
+
 // the second half of a K-split launch: segment sums added left to right (the canonical order, see gemm_h3_kernel), then the
 // epilogue of the tile kernel.  One thread per (row, four channels).
 template <int NSEG>
@@ -381,7 +559,7 @@ bool gemm_h3_enabled() {
   return mode != 0 && conv_h3_enabled();
 }
 
-constexpr int kGemmSlot0 = 53, kGemmF32Slot = 57;
+constexpr int kGemmSlot0 = 53, kGemmF32Slot = 57, kGemmBdSlot = 64;
 
 void gemm_describe(ConvProfile* p) {
   for (int t = 0; t < kNumGemm; ++t) {
@@ -392,6 +570,9 @@ void gemm_describe(ConvProfile* p) {
   p->bm[kGemmF32Slot] = 64;
   p->bn[kGemmF32Slot] = 64;
   p->halo[kGemmF32Slot] = 600001;
+  p->bm[kGemmBdSlot] = 128;
+  p->bn[kGemmBdSlot] = 256;
+  p->halo[kGemmBdSlot] = 600002;
 }
 
 void gemm_init() {      // per DEVICE: a second-GPU context of the same process needs the >64 KB dynamic-LDS attribute too
@@ -430,8 +611,29 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     int best = 3;                                          // 64 x 64
     if (blocks(0) >= 512) best = 0;                        // 128 x 128 (its segmented form: 248 VGPRs, still two waves per SIMD)
     else if (blocks(1) >= 384) best = 1;                   // 64 x 128
-    if (forced >= 0 && !(seg && !kGemm[forced].kern_seg)) best = forced;
+    if (forced >= 0 && forced < kNumGemm && !(seg && !kGemm[forced].kern_seg)) best = forced;
     gemm_init();
+    // Round 6: the B-direct tile (gemm_bd_kernel: 128 x 256, long-K layers 128 x 128).  Bit-identical to the other tiles and
+    // OFF by default: measured (tools/bench_gemm.py, B = 16) 199 / 166 / 205 / 210 TFLOP/s on qkv / o / fc1 / fc2 against
+    // 221 / 212 / 218 / 223 for the LDS-staged 128 x 128 tile, HuBERT of 16 clips 51.1 against 47.5 ms, C3 1438 against
+    // 1453x -- a third of the LDS traffic buys nothing: the LDS was not what bounds these launches (LABNOTES 12).
+    // RVCX_GEMM_BD=1 (auto: grids of >= 512 workgroups) / 2 (always), override tile 204 (tests).
+    {
+      static const int bd_mode = getenv("RVCX_GEMM_BD") ? atoi(getenv("RVCX_GEMM_BD")) : 0;      // 0 off, 1 auto, 2 always
+      const bool want = forced == 4 || (forced < 0 && bd_mode != 0);
+      const int force_split = g_conv_override.splitk;
+      if (want && a.cout_p % 128 == 0 && !(seg && force_split >= 2)) {
+        const int bn = seg ? 128 : 256;
+        const long blocks_bd = (long)(a.cout_p / 128) * cdiv64(a.rows, bn);
+        if (forced == 4 || bd_mode == 2 || blocks_bd >= 512) {
+          dim3 grid((unsigned)cdiv64(a.rows, bn), a.cout_p / 128, 1);
+          if (seg) hipLaunchKernelGGL((gemm_bd_kernel<1, kGemmSeg>), grid, dim3(256), 0, stream, a);
+          else hipLaunchKernelGGL((gemm_bd_kernel<2, 1>), grid, dim3(256), 0, stream, a);
+          RVCX_HIP(hipGetLastError());
+          return kGemmBdSlot;
+        }
+      }
+    }
     if (seg) {
       const bool fits = a.part && (long)kGemmSeg * a.rows * a.cout <= a.part_cap;
       const int force = g_conv_override.splitk;           // tests (rvcx_conv_override): 1 never, >= 2 always
@@ -441,7 +643,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         // fc2 of a 30 s clip (tools/bench_gemm.py): 128 x 64 46.5 us, 128 x 128 51, 64 x 64 55, 64 x 128 56 (one workgroup per tile: 62 - 69)
         best = kGemmSeg * blocks(2) >= 256 ? 2 : 3;
         if (split_tile >= 0 && split_tile < kNumGemmTiles) best = split_tile;
-        if (forced >= 0) best = forced;
+        if (forced >= 0 && forced < kNumGemm) best = forced;
       }
       const GemmCfg& F = kGemm[best];
       if (split) {

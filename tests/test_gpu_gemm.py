@@ -34,6 +34,8 @@ def _ref(x_cf, w, bias, res, act):
     (2, 77, 128, 160, 3, True),          # tiny HuBERT shapes, batch folded into the rows, ragged tiles
     (3, 33, 160, 128, 2, False),
     (1, 5, 48, 36, 0, True),             # Cin = 3 chunks (odd stage count), Cout not a multiple of 32
+    (5, 333, 768, 768, 0, True),         # rows not a multiple of the 256-row B-direct tile, ragged last tile
+    (2, 700, 176, 256, 3, False),        # Cin = 11 chunks: odd stage count on the B-direct tile
 ])
 def test_gemm_tm_vs_torch(ctx, B, T, cin, cout, act, use_res):
     from polgen_rvc_amd import _lib
@@ -52,7 +54,7 @@ def test_gemm_tm_vs_torch(ctx, B, T, cin, cout, act, use_res):
         assert np.abs(ysp - y).max() <= 2.0 ** -20 * np.abs(y).max() + 1e-30      # split form: 22 significant bits
     try:
         outs = []
-        for tile in range(4):
+        for tile in range(5):      # 4: gemm_bd (round 6: activations straight from global memory; taken when cout % 128 == 0)
             _lib.Context.conv_override(tile=200 + tile)
             outs.append(ctx.gemm_tm(x, w, bias, res, act)[0])
         for o in outs[1:]:
@@ -117,6 +119,11 @@ def test_long_k_layers_sum_in_segments_split_or_not(ctx, B, T, cin, cout, act, u
     e = rms(one[0] - ref) / rms(ref)
     print(f"gemm_tm long K {B}x{T} {cin}->{cout}: rel err {e:.2e}")
     assert np.isfinite(one[0]).all() and e < 2e-6
-    for a_, b_, c_ in zip(one, four, auto):
+    try:
+        _lib.Context.conv_override(tile=204)            # gemm_bd's long-K form (128 x 128, second accumulator set)
+        bd = ctx.gemm_tm(x, w, bias, res, act)
+    finally:
+        _lib.Context.conv_override()
+    for a_, b_, c_, d_ in zip(one, four, auto, bd):
         if a_ is not None:
-            assert np.array_equal(a_, b_) and np.array_equal(a_, c_)
+            assert np.array_equal(a_, b_) and np.array_equal(a_, c_) and np.array_equal(a_, d_)

@@ -8,11 +8,11 @@ import polgen_rvc_amd  # noqa
 from polgen_rvc_amd import _lib
 
 SHAPES = [("qkv", 768, 2304), ("o", 768, 768), ("fc1", 768, 3072), ("fc2", 3072, 768)]
-TILES = ["128x128", "64x128", "128x64", "64x64"]
+TILES = ["128x128", "64x128", "128x64", "64x64", "bd128x256"]
 if __name__ == "__main__":
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     ctx = _lib.Context(0)
-    for B in (1, 8):
+    for B in (1, 8, 16):
         rows = 1599 * B
         tot_auto = 0.0
         for name, cin, cout in SHAPES:
