@@ -19,13 +19,13 @@ def _S():
     return synthetic
 
 
-@pytest.mark.parametrize("tag", ["tiny", "48k_T24"])
+@pytest.mark.parametrize("tag", ["tiny", "48k_T24", "48k_T24_outliers"])
 def test_synth_oracle_vs_reference(tag):
     from oracle import synth as O
     S = _S()
     d = np.load(os.path.join(GOLD, f"synth_{tag}.npz"))
     cfg = json.loads(str(d["cfg"]))
-    sd = S.to_torch(S.synth_state(cfg, int(d["seed"])))
+    sd = S.to_torch(S.synth_state(cfg, int(d["seed"]), outliers=tag.endswith("outliers")))
     T = d["phone"].shape[1]
     out, parts = O.synthesizer_infer(sd, cfg, torch.from_numpy(d["phone"]), torch.tensor([T]),
                                      torch.from_numpy(d["pitch"]), torch.from_numpy(d["f0"]), torch.tensor([0]),
@@ -36,13 +36,13 @@ def test_synth_oracle_vs_reference(tag):
     assert rms(out.numpy() - d["audio"]) < 1e-5
 
 
-@pytest.mark.parametrize("tag", ["tiny", "full_1s"])
+@pytest.mark.parametrize("tag", ["tiny", "full_1s", "full_1s_outliers"])
 def test_rmvpe_oracle_vs_reference(tag):
     from oracle import rmvpe as O
     S = _S()
     d = np.load(os.path.join(GOLD, f"rmvpe_{tag}.npz"))
     cfg = json.loads(str(d["cfg"]))
-    sd = S.to_torch(S.rmvpe_state(cfg, int(d["seed"])))
+    sd = S.to_torch(S.rmvpe_state(cfg, int(d["seed"]), outliers=tag.endswith("outliers")))
     f0, hid, mel = O.infer_f0(sd, cfg, d["audio"].astype(np.float64), return_hidden=True)
     st = int(d["stride"])
     assert rms(hid[::st] - d["hidden"]) / rms(d["hidden"]) < 1e-4
