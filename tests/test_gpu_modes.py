@@ -76,9 +76,21 @@ def test_fp32_hand_off_between_layers_passes_the_hubert_and_f0_goldens():
     _run_mode({"RVCX_NO_SPLIT": "1"}, "test_gpu_rmvpe_hubert.py", "hubert or rmvpe", "passed")
 
 
-def test_in_workgroup_split_k_convs_pass_the_f0_goldens():
-    """RVCX_CONV_DEEP=1: the deep U-Net levels (3 x 3 convs and the 2 x 2 polyphase ConvTranspose2d with 128 - 512 channels on
-    <= 8192 positions) on conv_deep_kernel -- the waves of a workgroup split K, partial tiles meet in LDS, no finish launch
-    (csrc/conv_deep.hip; off by default: measured no faster).  Same goldens, kernel-level conv tests included."""
-    _run_mode({"RVCX_CONV_DEEP": "1"}, "test_gpu_rmvpe_hubert.py", "rmvpe", "passed")
-    _run_mode({"RVCX_CONV_DEEP": "1"}, "test_gpu_conv.py", "conv2d3x3 or convtranspose2d", "passed")
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_weight_stationary_conv_tile_off_and_everywhere_pass_the_f0_goldens(mode):
+    """RVCX_CONV_WS (csrc/conv_deep.hip, round 6): 0 takes the weight-stationary 64 x 320 tile out (every U-Net level on the
+    conv_h3 tiles, round 5's dispatch), 2 puts every eligible layer on it (3 x 3 convs from 64 channels up, the 2 x 2 polyphase
+    ConvTranspose2d, the 1-D layers with >= 32 k-steps: measured slower there, which is why the default is the >= 256-channel
+    3 x 3 convs only).  Same goldens; in mode 2 also the full C2 conversion (its decoder convs run on the tile then)."""
+    _run_mode({"RVCX_CONV_WS": mode}, "test_gpu_rmvpe_hubert.py", "rmvpe", "passed")
+    _run_mode({"RVCX_CONV_WS": mode}, "test_gpu_conv.py", "conv2d3x3 or convtranspose2d or convblockres", "passed")
+    if mode == "2":
+        _run_mode({"RVCX_CONV_WS": mode}, "test_gpu_pipeline.py", "c2_30s_48k or tiny_chunked", "2 passed")
+
+
+def test_b_direct_gemm_tile_everywhere_passes_the_hubert_goldens():
+    """RVCX_GEMM_BD=2 (csrc/gemm.hip, round 6): every Linear with Cout % 128 == 0 on gemm_bd_kernel (activations straight
+    from global memory; off by default: measured slower).  HuBERT goldens, the kernel-level GEMM tests, C2 end to end."""
+    _run_mode({"RVCX_GEMM_BD": "2"}, "test_gpu_rmvpe_hubert.py", "hubert", "passed")
+    _run_mode({"RVCX_GEMM_BD": "2"}, "test_gpu_gemm.py", "gemm", "passed")
+    _run_mode({"RVCX_GEMM_BD": "2"}, "test_gpu_pipeline.py", "c2_30s_48k", "1 passed")
