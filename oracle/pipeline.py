@@ -154,8 +154,9 @@ def to_int16(audio_opt: np.ndarray) -> np.ndarray:
 class Models:
     """Bundle of state dicts + configs the oracle needs (all torch tensors, CPU)."""
 
-    def __init__(self, hubert_sd, hubert_cfg, rmvpe_sd, rmvpe_cfg, synth_sd, synth_cfg, fcpe_sd=None):
+    def __init__(self, hubert_sd, hubert_cfg, rmvpe_sd, rmvpe_cfg, synth_sd, synth_cfg, fcpe_sd=None, version="v2"):
         self.fcpe_sd = fcpe_sd
+        self.version = version          # of the voice model (infer.py:91-97): "v1" = HuBERT layer 9 + final_proj, input_dim 256
         self.hubert_sd, self.hubert_cfg = hubert_sd, hubert_cfg
         self.rmvpe_sd, self.rmvpe_cfg = rmvpe_sd, rmvpe_cfg
         self.synth_sd, self.synth_cfg = synth_sd, synth_cfg
@@ -165,9 +166,13 @@ class Models:
 def vc_chunk(models: Models, audio0: np.ndarray, pitch: np.ndarray, pitchf: np.ndarray, sid: int,
              big_npy: Optional[np.ndarray], index_rate: float, protect: float,
              z_noise: torch.Tensor, src_noise: torch.Tensor, return_parts=False):
-    """VC.vc (pipeline.py:203-287), version v2, f0 guided.  pitch/pitchf are the per-chunk slices."""
+    """VC.vc (pipeline.py:203-287), f0 guided.  pitch/pitchf are the per-chunk slices.  ``models.version``: "v2" (output
+    layer 12, 768-dim features) or "v1" (output layer 9 + ``final_proj``, 256-dim: pipeline.py:228-236)."""
     feats = torch.from_numpy(audio0).float().view(1, -1)
-    feats = O_hubert.extract_features(models.hubert_sd, models.hubert_cfg, feats, 12)
+    if getattr(models, "version", "v2") == "v1":
+        feats = O_hubert.final_proj(models.hubert_sd, O_hubert.extract_features(models.hubert_sd, models.hubert_cfg, feats, 9))
+    else:
+        feats = O_hubert.extract_features(models.hubert_sd, models.hubert_cfg, feats, 12)
     feats0 = feats.clone() if protect < 0.5 else None
     ids = None
     if big_npy is not None and index_rate != 0:

@@ -1665,8 +1665,9 @@ int rvcx_vc(rvcx_ctx* ctx, int model_id, const float* audio0, int64_t n, const i
   SynthModel& M = get_synth(*C, model_id);
   if (!C->hubert) fail("hubert not loaded");
   if (!pitch || !pitchf) fail("vc: non-f0 models cannot run in the reference either (generators.py:57-77)");
-  const int E = C->hubert->cfg.embed_dim, inter = M.cfg.inter_channels;
-  RVCX_CHECK(E == M.cfg.input_dim, "hubert embed dim != synthesizer input_dim");
+  const int E = M.cfg.input_dim, inter = M.cfg.inter_channels;      // v2: the HuBERT's embed_dim; v1: its final_proj width
+  RVCX_CHECK(E == C->hubert->cfg.embed_dim || (C->hubert->has_final_proj && E == C->hubert->final_proj.cout),
+             "the voice model's input_dim is neither the HuBERT's embed_dim (v2) nor its final_proj width (v1)");
   const int Th = hubert_frames(*C->hubert, n);
   RVCX_CHECK(Th > 0, "vc: chunk too short");
   const int T = (int)std::min<long>(n / 160, 2L * Th);       // p_len clamp, pipeline.py:257-262
@@ -1685,7 +1686,7 @@ int rvcx_vc(rvcx_ctx* ctx, int model_id, const float* audio0, int64_t n, const i
   float* feats = C->arena.alloc<float>((size_t)E * Th);
   {
     const size_t mk = C->arena.mark();
-    hubert_forward(*C, *C->hubert, 1, dw, n, 12, feats, s);
+    hubert_features_for(*C, *C->hubert, E, 1, dw, n, feats, s);     // v2: layer 12; v1: final_proj(layer 9)
     C->arena.reset(mk);
   }
   const float* feats0 = feats;

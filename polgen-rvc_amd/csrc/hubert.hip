@@ -65,6 +65,15 @@ std::unique_ptr<HubertModel> hubert_load(Ctx& c, const rvcx_hubert_cfg& cfg, con
     L.ln2_b = c.slab.upload(t.f32(p + ".final_layer_norm.bias"));
     M->layers.push_back(L);
   }
+  // present in fairseq checkpoints, used by RVC v1 voice models only (feats = final_proj(layer 9), pipeline.py:231-236)
+  if (t.has("final_proj.weight") && t.has("final_proj.bias")) {
+    auto w = t.f32("final_proj.weight");
+    auto b = t.f32("final_proj.bias");
+    const auto shp = t.shape("final_proj.weight");
+    RVCX_CHECK((int)shp[1] == E, "hubert final_proj: input width != embed_dim");
+    M->final_proj = make_conv(c, w.data(), b.data(), (int)shp[0], E, 1, 1);
+    M->has_final_proj = true;
+  }
   M->region->seal();
   return M;
 }
@@ -78,9 +87,10 @@ int hubert_frames(const HubertModel& m, int64_t n) {
 size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
   const int64_t t0 = (n - m.cfg.conv_kernels[0]) / m.cfg.conv_strides[0] + 1;
   const int T = hubert_frames(m, n);
+  const size_t v1_extra = m.has_final_proj ? (size_t)B * m.cfg.embed_dim * T * sizeof(float) + 256 : 0;   // layer-9 map of the v1 path
   size_t conv = 2 * (size_t)m.cfg.conv_dim * t0;
   size_t enc = (size_t)T * (size_t)(11 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + (8 * 98 + 2 * 96 + 8) * m.cfg.heads);
-  return (size_t)B * (conv + enc) * sizeof(float) + ((size_t)64 << 20);
+  return (size_t)B * (conv + enc) * sizeof(float) + v1_extra + ((size_t)64 << 20);
 }
 
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
@@ -299,6 +309,22 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     launch_layernorm_c(h2, L.ln2_g, L.ln2_b, (l == nl - 1) ? feats_ct : h, B, E, T, 1e-5f, nullptr, s);
   }
   if (nl == 0) RVCX_HIP(hipMemcpyAsync(feats_ct, h, (size_t)B * E * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RVCX_HIP(hipGetLastError());
+}
+
+void hubert_features_for(Ctx& c, const HubertModel& m, int out_dim, int B, const float* wav, int64_t n, float* feats_ct,
+                         hipStream_t s, long wav_bs, const int* ns_host) {
+  if (out_dim == m.cfg.embed_dim) {
+    hubert_forward(c, m, B, wav, n, 12, feats_ct, s, nullptr, wav_bs, ns_host);
+    return;
+  }
+  RVCX_CHECK(m.has_final_proj && m.final_proj.cout == out_dim,
+             "the voice model's input width is neither the HuBERT's embed_dim (RVC v2) nor its final_proj width (RVC v1)");
+  const int T = hubert_frames(m, n);
+  float* l9 = c.arena.alloc<float>((size_t)B * m.cfg.embed_dim * T);
+  hubert_forward(c, m, B, wav, n, 9, l9, s, nullptr, wav_bs, ns_host);
+  ConvArgs a = conv1d_args(m.final_proj, l9, feats_ct, B, T, T);
+  c.conv_on(a, s);
   RVCX_HIP(hipGetLastError());
 }
 

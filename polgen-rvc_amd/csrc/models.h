@@ -168,6 +168,8 @@ struct HubertModel {
   std::vector<ConvW> convs;
   const float *gn_g = nullptr, *gn_b = nullptr, *ln0_g = nullptr, *ln0_b = nullptr;
   ConvW proj, pos_conv;
+  ConvW final_proj;                                      // Linear(embed, final_dim): v1 voice models only (pipeline.py:236)
+  bool has_final_proj = false;
   const float *eln_g = nullptr, *eln_b = nullptr;
   struct Layer {
     ConvW qkv, o, fc1, fc2;
@@ -187,6 +189,12 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n);
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
                     float* feats_ct, hipStream_t s, const std::function<void()>* after_extractor = nullptr,
                     long wav_bs = 0 /* element stride between the B signals, 0 = n */, const int* ns_host = nullptr);
+
+// What VC.vc feeds the retrieval blend and the synthesizer (pipeline.py:228-236): out_dim == embed_dim -> the output of
+// transformer layer 12 (RVC v2); out_dim == final_proj's width (256) -> final_proj(output of layer 9) (RVC v1).
+// feats_ct: device (B, out_dim, T') channel-first.  Other arguments as hubert_forward.
+void hubert_features_for(Ctx& c, const HubertModel& m, int out_dim, int B, const float* wav, int64_t n, float* feats_ct,
+                         hipStream_t s, long wav_bs = 0, const int* ns_host = nullptr);
 
 // ------------------------------------------------------------------------------ retrieval index
 struct IndexData {

@@ -573,8 +573,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   const SynthModel& M = *c.synths[model_id];
   const Geometry g = make_geometry(p, M.cfg.sr);
   RVCX_CHECK(M.cfg.sr == 100 * M.upp, "synth sample rate must be 100 * prod(upsample_rates)");
-  const int E = c.hubert->cfg.embed_dim, inter = M.cfg.inter_channels;
-  RVCX_CHECK(E == M.cfg.input_dim, "hubert embed dim != synthesizer input_dim");
+  // the feature width VC.vc works with (pipeline.py:228-236): the HuBERT's embed_dim for RVC v2 voice models, the width of
+  // its final_proj (256) for RVC v1 ones (output layer 9 + final_proj: hubert_features_for)
+  const int E = M.cfg.input_dim, inter = M.cfg.inter_channels;
+  RVCX_CHECK(E == c.hubert->cfg.embed_dim || (c.hubert->has_final_proj && E == c.hubert->final_proj.cout),
+             "the voice model's input_dim is neither the HuBERT's embed_dim (v2) nor its final_proj width (v1)");
   const int NB = (int)ios.size();
   if (NB == 0) return;
   hipStream_t s = c.stream;
@@ -958,8 +961,8 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
                                     (size_t)ns * 4, hipMemcpyDeviceToDevice, sh));
           wav = wg;
         }
-        hubert_forward(c, *c.hubert, G, wav, ns, 12, f.feats + P.feats_off[gi], sh, nullptr, wav_bs,
-                       P.groups[gi].ragged ? nsv.data() : nullptr);
+        hubert_features_for(c, *c.hubert, E, G, wav, ns, f.feats + P.feats_off[gi], sh, wav_bs,
+                            P.groups[gi].ragged ? nsv.data() : nullptr);
         c.arena.reset(mk);
       } catch (...) {
         c.arena.swap(c.arena_hub);

@@ -56,8 +56,8 @@ class HubertHandle:
 
 
 class SynthHandle:
-    def __init__(self, ctx, model_id, cfg):
-        self.ctx, self.model_id, self.cfg = ctx, model_id, cfg
+    def __init__(self, ctx, model_id, cfg, input_dim=768):
+        self.ctx, self.model_id, self.cfg, self.input_dim = ctx, model_id, cfg, input_dim
 
     def __del__(self):
         try:
@@ -181,19 +181,25 @@ def get_vc(device, is_half, config, model_path, cpt=None):
                 return hit()
         cpt = _torch_load(model_path)
     if "config" not in cpt or "weight" not in cpt:
-        raise ValueError(f"Invalid format for {model_path}. Use a voice model trained with RVC v2.")
+        raise ValueError(f"Invalid format for {model_path}. Use a voice model trained with RVC v2.")     # the reference's text (infer.py:84)
     tgt_sr = cpt["config"][-1]
     cpt["config"][-3] = cpt["weight"]["emb_g.weight"].shape[0]
     pitch_guidance = cpt.get("f0", 1)
     version = cpt.get("version", "v1")
-    if version != "v2" or not pitch_guidance:
-        raise ValueError("rvcx supports RVC v2 voice models with pitch guidance (f0=1)")
+    if not pitch_guidance:
+        raise ValueError("rvcx supports voice models with pitch guidance (f0=1); the reference cannot run the others either "
+                         "(generators.py:57-77)")
+    if version not in ("v1", "v2"):
+        raise ValueError(f"unknown voice model version {version!r}")
+    # infer.py:91-97: input_dim = 768 if version == "v2" else 256 -- read off the tensor, checked against the version
     input_dim = int(cpt["weight"]["enc_p.emb_phone.weight"].shape[1])
+    if (version, input_dim) in (("v1", 768), ("v2", 256)):
+        raise ValueError(f"checkpoint says version {version!r} but enc_p.emb_phone takes {input_dim} features")
     state = weights.strip_enc_q(cpt["weight"])
     cfg_struct = weights.synth_cfg_struct(cpt["config"], input_dim)
     ctx = _context(device)
     mid = ctx.load_synth(cfg_struct, state)         # outside the table lock (the context's own mutex orders it)
-    net_g = SynthHandle(ctx, mid, list(cpt["config"]))
+    net_g = SynthHandle(ctx, mid, list(cpt["config"]), input_dim)
     if skey is not None:
         with _state.LOCK:
             if skey in _SYNTHS:                     # another thread loaded the same file meanwhile: keep theirs,

@@ -113,6 +113,18 @@ class VC:
         return p
 
     @staticmethod
+    def _check_version(version, net_g):
+        """pipeline.py:228-236 / infer.py:91-97: "v1" = HuBERT output layer 9 + final_proj into a 256-wide emb_phone, "v2" =
+        layer 12 into a 768-wide one.  The library reads the case off the voice model's input width; the caller's
+        ``version`` must agree with it (the reference would fail inside emb_phone with a shape error)."""
+        if version not in ("v1", "v2"):
+            raise ValueError(f"unknown voice model version {version!r} (v1 or v2)")
+        want = getattr(net_g, "input_dim", None)
+        if (version, want) in (("v1", 768), ("v2", 256)):        # the two canonical widths (infer.py:92)
+            raise ValueError(f"version {version!r} does not match the voice model (emb_phone takes {want} features: "
+                             f"{'v1' if want == 256 else 'v2'})")
+
+    @staticmethod
     def _check_method(f0_method):
         if f0_method not in F0_METHODS:
             raise ValueError(f"f0_method={f0_method!r} is not implemented by rvcx (supported: {F0_METHODS})")
@@ -193,8 +205,7 @@ class VC:
     def vc(self, model, net_g, sid, audio0, pitch, pitchf, index, big_npy, index_rate, version, protect, *,
            z_noise=None, src_noise=None):
         """pipeline.py:203-287: one chunk of audio_pad -> np.float32 waveform (un-trimmed)."""
-        if version != "v2":
-            raise ValueError("only RVC v2 voice models are supported")
+        self._check_version(version, net_g)
         if pitch is None or pitchf is None:
             raise ValueError("non-f0 models cannot run in the reference either (generators.py:57-77)")
         ctx = net_g.ctx
@@ -289,8 +300,7 @@ class VC:
         self._check_method(f0_method)
         if not pitch_guidance:
             raise ValueError("non-f0 models cannot run in the reference either (generators.py:57-77)")
-        if version != "v2":
-            raise ValueError("only RVC v2 voice models are supported")
+        self._check_version(version, net_g)
         inp_f0 = None
         if f0_file and hasattr(f0_file, "name"):              # pipeline.py:349-360 (failures are printed and ignored)
             try:

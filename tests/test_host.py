@@ -516,3 +516,19 @@ def test_shape_only_placeholders_match_the_real_layouts():
     assert all(np.array_equal(real[k], again[k]) for k in real)          # the mode does not leak out of the with-block
     real_s = S.synth_state(S.SYNTH_CFG_TINY, 3, input_dim=128)
     assert set(ph_s) == set(real_s) and all(ph_s[k].shape == real_s[k].shape for k in real_s)
+
+
+def test_get_vc_accepts_v1_and_refuses_a_version_that_contradicts_the_weights():
+    """rvc/infer/infer.py:91-97: input_dim = 768 if version == "v2" else 256.  A checkpoint whose ``version`` contradicts the
+    width of enc_p.emb_phone is refused before anything touches the GPU (the reference dies later, in load_state_dict)."""
+    from polgen_rvc_amd import synthetic as S
+    from polgen_rvc_amd.infer import infer as I
+    cfg = S.SYNTH_CFG_TINY
+    for version, dim in (("v2", 256), ("v1", 768)):
+        cpt = S.synth_checkpoint(cfg, 1, version=version)
+        cpt["weight"] = S.synth_state(cfg, 1, input_dim=dim)
+        with pytest.raises(ValueError, match="emb_phone"):
+            I.get_vc("cuda:0", False, I.Config(), None, cpt=cpt)
+    cpt = S.synth_checkpoint(cfg, 1, version="v3")
+    with pytest.raises(ValueError, match="version"):
+        I.get_vc("cuda:0", False, I.Config(), None, cpt=cpt)

@@ -61,15 +61,17 @@ def test_hubert_oracle_vs_hf_twin(tag):
     assert rms(out - d["out"]) / rms(d["out"]) < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short"])
+@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short", "tiny_v1"])
 def test_pipeline_oracle_vs_reference(tag):
     from oracle import pipeline as OP
     S = _S()
     d = np.load(os.path.join(GOLD, f"pipeline_{tag}.npz"))
     hcfg, rcfg, scfg = json.loads(str(d["cfgs"]))
     seed = int(d["seed"])
+    version = str(d["version"]) if "version" in d.files else "v2"         # "v1": HuBERT layer 9 + final_proj, emb_phone on final_dim
+    in_dim = hcfg["final_dim"] if version == "v1" else hcfg["embed_dim"]
     models = OP.Models(S.to_torch(S.hubert_state(hcfg, seed)), hcfg, S.to_torch(S.rmvpe_state(rcfg, seed)), rcfg,
-                       S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])), scfg)
+                       S.to_torch(S.synth_state(scfg, seed, input_dim=in_dim)), scfg, version=version)
     noises = [(torch.from_numpy(d[f"z_noise_{i}"]), torch.from_numpy(d[f"src_noise_{i}"]))
               for i in range(int(d["n_chunks"]))]
     audio = S.make_clip(int(d["clip"]), float(d["seconds"]))

@@ -153,9 +153,15 @@ def hf_hubert(cfg, sd):
 class HubertAdapter(torch.nn.Module):
     """``extract_features(source, padding_mask, output_layer)`` around the HF twin (Appendix A.6)."""
 
-    def __init__(self, hf):
+    def __init__(self, hf, sd=None):
         super().__init__()
         self.hf = hf
+        if sd is not None and "final_proj.weight" in sd:       # fairseq's HubertModel.final_proj: RVC v1 voice models (pipeline.py:236)
+            w = sd["final_proj.weight"]
+            self.final_proj = torch.nn.Linear(w.shape[1], w.shape[0])
+            with torch.no_grad():
+                self.final_proj.weight.copy_(w)
+                self.final_proj.bias.copy_(sd["final_proj.bias"])
 
     def extract_features(self, source, padding_mask=None, output_layer=12):
         out = self.hf(source, output_hidden_states=True)
@@ -299,11 +305,11 @@ def gold_hubert(tag, cfg, seconds, seed, outliers=False):
 
 
 def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0_min, f0_max, seed,
-                     tgt_sr, file_index=None, index_rate=0, prebuilt=None, f0_method="rmvpe+"):
+                     tgt_sr, file_index=None, index_rate=0, prebuilt=None, f0_method="rmvpe+", version="v2"):
     (hcfg, hsd), (rcfg, rsd), (scfg, ssd) = models_cfg
     vc = P.VC(tgt_sr, Cfg(geo))
     if prebuilt is None:
-        prebuilt = (ref_rmvpe(rcfg, rsd), HubertAdapter(hf_hubert(hcfg, hsd)))
+        prebuilt = (ref_rmvpe(rcfg, rsd), HubertAdapter(hf_hubert(hcfg, hsd), hsd))
     vc.model_rmvpe, hub = prebuilt
     net = ref_synth(scfg, ssd)
     draws = []
@@ -329,7 +335,7 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
     torch.manual_seed(seed)
     try:
         pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, f0_method, file_index, index_rate,
-                          1, 3, tgt_sr, 0, volume_envelope, "v2", protect, 128, None, f0_min, f0_max)
+                          1, 3, tgt_sr, 0, volume_envelope, version, protect, 128, None, f0_min, f0_max)
     finally:
         torch.randn_like = orig
     noises = [(draws[2 * i], draws[2 * i + 1]) for i in range(len(draws) // 2)]
@@ -337,8 +343,11 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
 
 
 def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, protect, f0_min, f0_max,
-                  full_store=True, fixed_seed=None):
+                  full_store=True, fixed_seed=None, version="v2"):
+    """version "v1": the voice model takes final_proj(HuBERT layer 9) -- emb_phone's input width is the HuBERT's final_dim
+    (pipeline.py:228-236, infer.py:91-97)"""
     hcfg, rcfg, scfg = cfgs
+    in_dim = hcfg["final_dim"] if version == "v1" else hcfg["embed_dim"]
     print(f"[pipeline {tag}] {seconds}s geo={geo} pitch={pitch} env={volume_envelope}")
     a_ = O_pipe.highpass(S.make_clip(clip, seconds).astype(np.float64))
     a_ = np.pad(a_, (16000 * geo[0], 16000 * geo[0]), mode="reflect").astype(np.float32)
@@ -346,14 +355,14 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
     # seeds qualify on a 9 700-frame clip)
     seed = fixed_seed if fixed_seed is not None else stable_seed(rcfg, a_, seed, f0_min, f0_max, pitch)
     hsd, rsd, ssd = (S.to_torch(S.hubert_state(hcfg, seed)), S.to_torch(S.rmvpe_state(rcfg, seed)),
-                     S.to_torch(S.synth_state(scfg, seed, input_dim=hcfg["embed_dim"])))
+                     S.to_torch(S.synth_state(scfg, seed, input_dim=in_dim)))
     tgt_sr = scfg[-1]
     audio = S.make_clip(clip, seconds)
     t0 = time.time()
     pcm, raw, noises = run_ref_pipeline(((hcfg, hsd), (rcfg, rsd), (scfg, ssd)), geo, audio, pitch,
-                                        volume_envelope, protect, f0_min, f0_max, seed, tgt_sr)
+                                        volume_envelope, protect, f0_min, f0_max, seed, tgt_sr, version=version)
     t_ref = time.time() - t0
-    models = O_pipe.Models(hsd, hcfg, rsd, rcfg, ssd, scfg)
+    models = O_pipe.Models(hsd, hcfg, rsd, rcfg, ssd, scfg, version=version)
     t0 = time.time()
     opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(tgt_sr, *geo), audio, pitch, 0, None, 0.0,
                                   volume_envelope, protect, f0_min, f0_max, noises=noises, return_parts=True)
@@ -366,7 +375,7 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
     print(f"  pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
     assert e < 1e-4 and d.max() <= 8, (e, d.max())
     rawcat = np.concatenate(raw)
-    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch,
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, version=version,
                  volume_envelope=volume_envelope, protect=protect, f0_min=f0_min, f0_max=f0_max,
                  cfgs=json.dumps([hcfg, rcfg, scfg]), n_chunks=len(raw),
                  chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
@@ -473,7 +482,7 @@ def gold_pipeline_fcpe(tag, cfgs, fcfg, geo, seconds, clip, seed, pitch, volume_
     print(f"  chunks={len(raw)} pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
     assert e < 1e-4 and d.max() <= 8, (e, d.max())
     rawcat = np.concatenate(raw)
-    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, volume_envelope=volume_envelope,
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, version=version, volume_envelope=volume_envelope,
                  protect=protect, f0_min=50, f0_max=1100, cfgs=json.dumps([hcfg, fcfg, scfg]), n_chunks=len(raw),
                  chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
                  coarse=parts["coarse"].astype(np.int16), sha256=hashlib.sha256(pcm.tobytes()).hexdigest(),
@@ -630,6 +639,8 @@ def main():
         "fcpe_full": lambda: gold_fcpe("full_2s", S.FCPE_CFG_FULL, 2.0, 22, 0, -3.0, stride=2),
         "pipe_fcpe_tiny": lambda: gold_pipeline_fcpe("tiny_fcpe", tiny, S.FCPE_CFG_TINY, (1, 6, 38, 41), 2.0, 14, 1, 1.0, 1.0, 0.33),
         "pipe_tiny_chunks": lambda: gold_pipeline("tiny_chunked", tiny, (1, 1, 2, 3), 7.3, 13, 1, 2, 1.0, 0.33, 50, 1100),
+        # round 6: an RVC v1 voice model (HuBERT output layer 9 + final_proj, emb_phone on final_dim features)
+        "pipe_tiny_v1": lambda: gold_pipeline("tiny_v1", tiny, (1, 6, 38, 41), 2.2, 16, 1, 0, 1.0, 0.33, 50, 1100, version="v1"),
     }
     if a.full:
         full40 = (S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL, S.SYNTH_CFG_40K)
@@ -649,6 +660,9 @@ def main():
         steps["pipe_long95"] = lambda: gold_pipeline("long95_48k", full48, (1, 6, 38, 41), 95.0, 3, 3000, 0, 1.0, 0.33,
                                                      50, 1100, full_store=False,
                                                      fixed_seed=int(os.environ.get("RVCX_LONG95_SEED", "12800")))
+        # an RVC v1 voice model at full size: HuBERT-base layer 9 (not 12) + final_proj 768 -> 256, 40 k synthesizer on 256 features
+        steps["pipe_v1_full"] = lambda: gold_pipeline("v1_5s_40k", full40, (1, 6, 38, 41), 5.0, 4, 0, 0, 1.0, 0.33,
+                                                      50, 1100, full_store=False, version="v1")
         steps["pipe_c3"] = gold_pipeline_c3
         steps["pipe_c5"] = gold_pipeline_c5
     for k, fn in steps.items():
