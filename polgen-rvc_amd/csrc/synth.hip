@@ -389,15 +389,25 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
   // largely served by the 256 MB Infinity Cache.  Measured with B = 8 in one launch sequence: 22.4 ms per clip
   // against 16.5 ms one at a time (every layer then streams from HBM) -- RVCX_DEC_BATCH overrides.
   if (!c.serial) RVCX_HIP(hipStreamWaitEvent(s, c.ev_src[1], 0));
-  static const int dec_batch = getenv("RVCX_DEC_BATCH") ? std::max(1, atoi(getenv("RVCX_DEC_BATCH"))) : 1;
+  // Round 6: utterances of EQUAL length go through the decoder `RVCX_DEC_BATCH` at a time (default 8): the persistent fused
+  // steps walk ceil(tiles / 256) rounds of tiles, 8.33 -> 9 for one 30 s utterance at C = 128, 33.3 -> 34 for four (C3: 1408 -
+  // 1414x at 1, 1419 at 2, 1428 at 3, 1439 at 4 on one box, 1455 - 1459 at 4 / 8 and 1464 at 16 on another; the round-2 finding
+  // above predates the fused steps).  Ragged members keep
+  // one utterance at a time at its own length (no work on padding).  Results do not depend on the grouping (the fused steps
+  // are per-position, every split decision is per item): batch == single holds bit for bit (tests/test_gpu_fullsize_batch.py).
+  static const int dec_batch_env = getenv("RVCX_DEC_BATCH") ? std::max(1, atoi(getenv("RVCX_DEC_BATCH"))) : 8;
+  bool equal_lens = true;
+  if (io.lens_host)
+    for (int b = 1; b < B; ++b) equal_lens &= io.lens_host[b] == io.lens_host[0];
+  const int dec_batch = equal_lens ? dec_batch_env : 1;
   const int C0 = cf.up_initial_channel;
   const size_t dec_mark = A.mark();
   for (int b0 = 0; b0 < B; b0 += dec_batch) {
     const int db = std::min(dec_batch, B - b0);
     A.reset(dec_mark);
-    // One utterance at a time runs at ITS OWN length Td (rows of the batched tensors stay T apart): no masks, no work on
-    // padding, and every launch decision (tile, split-K) is the one the utterance's single run takes.
-    const bool own = db == 1 && io.lens_host != nullptr;
+    // One utterance at a time -- or a group of EQUAL length -- runs at ITS OWN length Td (rows of the batched tensors stay T
+    // apart): no masks, no work on padding, and every launch decision (tile, split-K) is the one the utterance's single run takes.
+    const bool own = io.lens_host != nullptr && (db == 1 || equal_lens);
     const int Td = own ? io.lens_host[b0] : T;
     RVCX_CHECK(Td > 0 && Td <= T, "synth: item length outside (0, T]");
     float* cur = A.alloc<float>((size_t)db * C0 * Td);
@@ -587,9 +597,11 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       a.act = ACT_TANH;
       a.lens_in = (lens_stage[m.stages.size()] && !own) ? lens_stage[m.stages.size()] + b0 : nullptr;
       a.lens_out = a.lens_in;
+      a.y_bs = (long)Tupp;             // output rows are T * upp apart whatever the group's own length
       c.conv(a);
-      if (own && Td < T)               // the rest of the item's output row reads as silence
-        RVCX_HIP(hipMemsetAsync(io.out + (size_t)b0 * Tupp + (size_t)Td * m.upp, 0, (size_t)(T - Td) * m.upp * sizeof(float), s));
+      if (own && Td < T)               // the rest of each item's output row reads as silence
+        for (int q = 0; q < db; ++q)
+          RVCX_HIP(hipMemsetAsync(io.out + (size_t)(b0 + q) * Tupp + (size_t)Td * m.upp, 0, (size_t)(T - Td) * m.upp * sizeof(float), s));
     }
   }
   tm.mark(3);

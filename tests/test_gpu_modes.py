@@ -94,3 +94,12 @@ def test_b_direct_gemm_tile_everywhere_passes_the_hubert_goldens():
     _run_mode({"RVCX_GEMM_BD": "2"}, "test_gpu_rmvpe_hubert.py", "hubert", "passed")
     _run_mode({"RVCX_GEMM_BD": "2"}, "test_gpu_gemm.py", "gemm", "passed")
     _run_mode({"RVCX_GEMM_BD": "2"}, "test_gpu_pipeline.py", "c2_30s_48k", "1 passed")
+
+
+@pytest.mark.parametrize("db", ["1", "3"])
+def test_decoder_grouping_does_not_change_a_bit(db):
+    """RVCX_DEC_BATCH (round 6; default 8): how many utterances of equal length go through one decoder launch sequence.
+    1 = round 5's one at a time, 3 = groups that do not divide the micro-batch.  The batch == single tests (8 x 30 s with the
+    index, a ragged full-size batch, 64 x 30 s against their single runs) must hold whatever the value."""
+    _run_mode({"RVCX_DEC_BATCH": db}, "test_gpu_fullsize_batch.py", "c3_batch_of_8 or ragged_full_size", "2 passed")
+    _run_mode({"RVCX_DEC_BATCH": db}, "test_gpu_c3_full.py", "c3", "passed")
