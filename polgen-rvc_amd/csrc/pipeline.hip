@@ -982,9 +982,11 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
   // 1039-1050 / 1044-1064 / 1058-1072 / 1078-1081x; batched calls do not care (C3 1290 / 1295x with / without the wait).
   // Other F0 methods have no such hook: HuBERT is enqueued behind them and does not wait.
   int mid_mark = -1;
-  // Round 6: the wait is for SINGLE utterances (a latency-bound front end whose U-Net must not share the chip); in a
-  // micro-batch every stage is a throughput-type launch and HuBERT beside the U-Net is free: C3 1467 - 1470 -> 1492x without
-  // the wait (tools/sweep_c3_knobs.sh).  RVCX_HUBERT_GATE: 0 never, 1 always, unset = single utterances only.
+  // Round 6: the wait is for front ends that run EXPOSED and latency-bound -- a single utterance, or the first micro-batch
+  // of a call when it is small (B = 2 / 3 / 4 in one call: 1360 / 1433 / 1474x with the wait, 1311 / 1408 / 1453 without;
+  // B = 8: level).  A front end that runs beside the previous micro-batch's decoder is a throughput-type neighbour and HuBERT
+  // beside its U-Net is free: C3 1468 - 1471 -> 1486 - 1491x without the wait (tools/sweep_c3_knobs.sh,
+  // tools/sweep_gate_small_batches.sh).  RVCX_HUBERT_GATE: 0 never, 1 always, unset = this rule.
   static const int hub_gate_env = getenv("RVCX_HUBERT_GATE") ? atoi(getenv("RVCX_HUBERT_GATE")) : -1;
   auto enqueue_models = [&](int k) {
     bool hub_done = false, from_hook = true;
@@ -992,7 +994,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       if (hub_done) return;
       hub_done = true;
       if (k == 0) mid_mark = clk.mark(sf);
-      const bool hub_gate = hub_gate_env < 0 ? mbs[k].count <= 1 : hub_gate_env != 0;
+      const bool hub_gate = hub_gate_env < 0 ? (mbs[k].count <= 1 || (k == 0 && mbs[k].count < 8)) : hub_gate_env != 0;
       if (hub_gate && from_hook && sh != sf) {
         RVCX_HIP(hipEventRecord(c.ev_hub, sf));
         RVCX_HIP(hipStreamWaitEvent(sh, c.ev_hub, 0));
