@@ -191,7 +191,11 @@ int rvcx_create(int device, rvcx_ctx** out) {
     conv_init();
     resblock_pair_init();
     gemm_init();
-    h->c.resblock_streams = !getenv("RVCX_RESBLOCK_STREAMS") || atoi(getenv("RVCX_RESBLOCK_STREAMS")) != 0;
+    // Round 6: TWO branch streams (main + aux[0]) by default.  With the third (aux[1]) in use the process has four busy
+    // streams besides the null stream, and the main stream's ~110 small TextEncoder / flow launches of a single clip run
+    // 0.4 ms slower (the hardware-queue sharing of DESIGN "Batching and streams"): C2 1145 - 1151 -> 1179 - 1182x, C5 1276 -
+    // 1280 -> 1291 - 1292x, C3 level (tools/sweep_c2_knobs.sh; all on the main stream: C2 1169 - 1177, C5 1219).
+    h->c.resblock_streams = getenv("RVCX_RESBLOCK_STREAMS") ? atoi(getenv("RVCX_RESBLOCK_STREAMS")) : 2;
     // RVCX_SERIAL=1: every launch on the one main stream (rocprofv3 kernel durations are then each launch's own)
     h->c.serial_env = getenv("RVCX_SERIAL") && atoi(getenv("RVCX_SERIAL")) != 0;
     h->c.serial = h->c.serial_env;

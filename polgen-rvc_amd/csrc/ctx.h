@@ -203,7 +203,7 @@ struct Ctx {
   WeightSlab slab;
   std::string last_error;
   double flops = 0.0;
-  bool resblock_streams = false;  // run the ResBlocks of an NSF stage on 3 streams
+  int resblock_streams = 0;       // the ResBlocks of an NSF stage on 3 streams (1), on the main stream + aux[0] (2), on the main stream (0)
   bool serial = false;            // profiling: keep every launch on the main stream (true per-kernel times)
   bool serial_env = false;        // RVCX_SERIAL=1: serial for the whole life of the context
   int* dev_err = nullptr;         // device error word (conv.h: kErrGruTimeout, kErrH3Overflow), read after each API call

@@ -463,8 +463,8 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       // input, so block j runs on its own stream (main, aux0, aux1): their MFMA, staging and store phases
       // interleave on the CUs instead of marching in lockstep.  Only the running sum xs is ordered
       // (SET -> ADD -> ADD_DIV) through events.
-      const bool side = c.resblock_streams && !c.serial;   // measured gain ~3.5 %; RVCX_RESBLOCK_STREAMS=0 turns it off
-      hipStream_t rs[4] = {s, side ? c.aux[0] : s, side ? c.aux[1] : s, s};
+      const int side = c.serial ? 0 : c.resblock_streams;   // 1: three streams; 2: main + aux[0]; 0: main only
+      hipStream_t rs[4] = {s, side ? c.aux[0] : s, side == 1 ? c.aux[1] : s, s};
       RVCX_HIP(hipEventRecord(c.ev_aux[0], s));
       for (int j = 1; j < nk && j < 3; ++j) RVCX_HIP(hipStreamWaitEvent(rs[j], c.ev_aux[0], 0));
       for (int j = 0; j < nk; ++j) {
