@@ -103,3 +103,11 @@ def test_decoder_grouping_does_not_change_a_bit(db):
     index, a ragged full-size batch, 64 x 30 s against their single runs) must hold whatever the value."""
     _run_mode({"RVCX_DEC_BATCH": db}, "test_gpu_fullsize_batch.py", "c3_batch_of_8 or ragged_full_size", "2 passed")
     _run_mode({"RVCX_DEC_BATCH": db}, "test_gpu_c3_full.py", "c3", "passed")
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_branch_stream_modes_pass_the_reference_goldens(mode):
+    """RVCX_RESBLOCK_STREAMS (default 2 since round 6: the ResBlock branches of an NSF stage on the main stream + aux[0]): 1 =
+    three streams (rounds 2 - 5), 0 = all on the main stream.  The running mean over the branches is ordered by events, so the
+    PCM must not change: the multi-chunk tiny golden, the CI-argument golden, C2 at full size, the float waveform vs the oracle."""
+    _run_mode({"RVCX_RESBLOCK_STREAMS": mode})
