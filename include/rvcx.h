@@ -321,6 +321,11 @@ int64_t rvcx_fp32_layers(rvcx_ctx*);
 int rvcx_fp32_pinned(rvcx_ctx*, char* buf, int cap);
 /* calls repeated with the single-workgroup BiGRU kernel because the cluster kernel's workgroups were not co-resident */
 int64_t rvcx_gru_fallbacks(rvcx_ctx*);
+/* the cluster BiGRU publishes h_t inside one XCD with a plain store and relies on the partners' sc1 polls seeing it (a
+ * hardware observation, INTEGRATION.md "hardware assumptions").  The library checks that once per device when RMVPE is loaded
+ * (or at the first BiGRU call); this runs the check if it has not run and reports it: 1 holds (plain publish in use), 0 does
+ * not (the device uses the write-through publish), -1 undecided (no co-located pair ran side by side), -2 error. */
+int rvcx_gru_publish_probe(rvcx_ctx*);
 /* retrieval: queries whose 8 neighbours could not be certified from the split-fp16 pre-filter and were searched
  * exhaustively instead (csrc/index.hip) since the last call of this function; waits for the device.  -1: no index */
 int64_t rvcx_index_exhaustive(rvcx_ctx*);

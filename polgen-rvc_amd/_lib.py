@@ -83,7 +83,7 @@ SYMBOLS = [
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
     "rvcx_op_conv2d3x3", "rvcx_op_convblock2d", "rvcx_op_convtranspose2d", "rvcx_op_attention", "rvcx_op_layernorm_c",
     "rvcx_op_bigru", "rvcx_op_highpass", "rvcx_convert_batch_ex", "rvcx_get_f0_x_ex", "rvcx_fp32_layers", "rvcx_fp32_pinned",
-    "rvcx_gru_fallbacks", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
+    "rvcx_gru_fallbacks", "rvcx_gru_publish_probe", "rvcx_debug_inject", "rvcx_f0_file_track", "rvcx_op_gemm_tm", "rvcx_op_layernorm_tm",
     "rvcx_resample_len", "rvcx_resample_f64", "rvcx_resample_f64_kind", "rvcx_bench_gemm", "rvcx_device_info",
     "rvcx_op_resblock3", "rvcx_flac_encode_bound", "rvcx_flac_encode_s16", "rvcx_flac_info", "rvcx_flac_decode_s32", "rvcx_flac_last_error",
 ]
@@ -892,6 +892,11 @@ class Context:
 
     def gru_fallbacks(self) -> int:
         return int(lib().rvcx_gru_fallbacks(self._h))
+
+    def gru_publish_probe(self) -> int:
+        """1: the cluster BiGRU's plain-store publish was verified on this device, 0: it failed and the write-through
+        publish is used, -1: undecided"""
+        return int(lib().rvcx_gru_publish_probe(self._h))
 
     def debug_inject(self, what: int):
         self._ck(lib().rvcx_debug_inject(self._h, int(what)), "debug_inject")

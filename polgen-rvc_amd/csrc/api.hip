@@ -295,6 +295,15 @@ int rvcx_fp32_pinned(rvcx_ctx* ctx, char* buf, int cap) {
 
 int64_t rvcx_gru_fallbacks(rvcx_ctx* ctx) { CtxLock ctx_guard_ = lock_ctx(ctx); return ctx ? (int64_t)ctx->c.gru_fallbacks : -1; }
 
+int rvcx_gru_publish_probe(rvcx_ctx* ctx) {
+  int state = -1;
+  const int rc = api_call(ctx, false, [&](Ctx*) {
+    (void)bigru_probe_publish();
+    state = bigru_probe_state();
+  });
+  return rc ? -2 : state;
+}
+
 int64_t rvcx_index_exhaustive(rvcx_ctx* ctx) {
   CtxLock ctx_guard_ = lock_ctx(ctx);
   if (!ctx || !ctx->c.index || !ctx->c.index->exhaustive) return -1;
@@ -1114,6 +1123,7 @@ int rvcx_load_rmvpe(rvcx_ctx* ctx, const rvcx_rmvpe_cfg* cfg, const rvcx_tensor*
   API_BEGIN_ONCE(ctx)
   TensorTable t = make_table(tbl, n);
   C->rmvpe = rmvpe_load(*C, *cfg, t);
+  (void)bigru_probe_publish();   // the BiGRU's publish assumption, checked once per device while it is idle (gru.hip)
   API_END
 }
 

@@ -21,6 +21,11 @@ double attention_flops(int B, int H, int D, int T);
 // scratch: bigru_scratch_bytes(B) of device memory for the inter-CU exchange; err: device flag set to 1 if
 // the cluster kernel timed out waiting for a partner workgroup (null scratch/err -> single-CU kernel)
 size_t bigru_scratch_bytes(int B);
+// one-time check (per device, synchronous) that a plain store inside one XCD is seen by a partner's sc1 poll -- what the
+// cluster kernel's publish relies on; 0 switches the device to the write-through publish.  bigru_probe_state: 1 holds,
+// 0 does not, -1 undecided / not probed.
+int bigru_probe_publish();
+int bigru_probe_state();
 // lens (device, B ints or null): item b runs lens[b] <= T steps -- the reverse direction starts at frame lens[b] - 1 --
 // while rows stay T frames apart; y beyond an item's length is not written
 void launch_bigru(const float* gi, const float* whh, const float* bhh, float* y, int B, int T, int H,

@@ -71,6 +71,16 @@ def test_bigru_forms_and_the_cross_xcd_hand_off_pass_the_f0_goldens(env):
     _run_mode(env, "test_gpu_rmvpe_hubert.py", "gru or rmvpe", "passed")
 
 
+def test_a_failed_publish_probe_selects_the_write_through_store_and_passes_the_f0_goldens():
+    """Round 6: the plain-store publish is probed once per device (gru_publish_probe_kernel).  RVCX_GRU_PROBE_FAIL=1 (debug
+    builds of the environment only) makes the probe report failure: the co-located clusters must then run the write-through
+    publish -- same goldens, no time-out fallback -- and the probe state must read 0."""
+    _run_mode({"RVCX_DEBUG": "1", "RVCX_GRU_PROBE_FAIL": "1", "RVCX_EXPECT_PROBE": "0"}, "test_gpu_rmvpe_hubert.py",
+              "gru or rmvpe", "passed")
+    _run_mode({"RVCX_DEBUG": "1", "RVCX_GRU_PROBE_FAIL": "1", "RVCX_EXPECT_PROBE": "0"}, "test_gpu_round6.py",
+              "publish_probe", "1 passed")
+
+
 def test_fp32_hand_off_between_layers_passes_the_hubert_and_f0_goldens():
     """RVCX_NO_SPLIT=1: no pre-split fp16 hand-off (HuBERT extractor, U-Net blocks): consumers convert fp32 themselves."""
     _run_mode({"RVCX_NO_SPLIT": "1"}, "test_gpu_rmvpe_hubert.py", "hubert or rmvpe", "passed")

@@ -374,3 +374,19 @@ def test_v1_voice_model_vs_reference_golden(ctx, tag):
     if hcfg["final_dim"] == 256:
         with pytest.raises(ValueError, match="does not match"):
             vc.pipeline(*args, "v2", *tail)
+
+
+def test_bigru_publish_probe_holds_on_this_device(ctx):
+    """The cluster BiGRU's hand-off inside one XCD is a plain store + sc1 poll (gru.hip): a hardware observation, checked once
+    per device by gru_publish_probe_kernel when RMVPE is loaded.  On the MI355X of this pool it must hold (1: the fast publish
+    is the one the F0 goldens run); RVCX_EXPECT_PROBE=0 is the forced-failure run of tests/test_gpu_modes.py, where the state
+    must read 0 and the recurrence must still complete without a time-out fallback."""
+    from polgen_rvc_amd import synthetic as S, weights as W
+    want = int(os.environ.get("RVCX_EXPECT_PROBE", "1"))
+    cfg = S.RMVPE_CFG_TINY
+    ctx.load_rmvpe(W.rmvpe_cfg_struct(cfg), S.rmvpe_state(cfg, 3))
+    assert ctx.gru_publish_probe() == want
+    fb0 = ctx.gru_fallbacks()
+    rng = np.random.default_rng(5)
+    f0 = ctx.rmvpe_f0(rng.standard_normal(16000).astype(np.float32) * 0.1)
+    assert np.all(np.isfinite(f0)) and ctx.gru_fallbacks() == fb0
