@@ -87,8 +87,15 @@ __device__ __forceinline__ double iir_step(const IirCoef& cf, double (&z)[5], do
   return y;
 }
 
-// one lane per slice; `rev` walks the buffers backwards (filtfilt's second, time-reversed pass)
-__global__ void iir_slice_kernel(const double* __restrict__ in, double* __restrict__ out, long m, int rev,
+// one lane per slice; `rev` walks the buffers backwards (filtfilt's second, time-reversed pass).
+// Round 6: the lane's samples arrive 16 at a time, the NEXT block requested before the current one is filtered.  A pass is
+// ~30 single-wave workgroups of 3328 serial steps; with the loads of a block issued and awaited in place (round 2-5: 8 at a
+// time) every block paid a memory round trip -- 210 us per pass for ~60 us of dependent float64 FMAs (0.5 ms of a single
+// clip's 25.5).  Same recursion, same order: the bits do not change.
+constexpr int IIR_BLK = 16;
+static_assert(IIR_CHUNK % (2 * IIR_BLK) == 0 && IIR_WARM % (2 * IIR_BLK) == 0, "warm-up and slice are whole block pairs");
+template <bool rev>
+__global__ void iir_slice_kernel(const double* __restrict__ in, double* __restrict__ out, long m,
                                  long es, IirCoef cf, const int* __restrict__ ns) {
   const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long s = p * IIR_CHUNK;
@@ -103,23 +110,45 @@ __global__ void iir_slice_kernel(const double* __restrict__ in, double* __restri
     const double x0 = in[rev ? m - 1 - w0 : w0];
     for (int k = 0; k < 5; ++k) z[k] = cf.zi[k] * x0;      // lfilter(..., zi = zi * x[0])
   }
+  // straight-line bodies (no branch around a fetch: the compiler then waits for every load in flight before it issues the
+  // next ones).  A fetch that would run past the signal is moved back inside it: its values are never used (the block loops
+  // below only filter whole blocks inside [w0, e)).  One address per block, the elements at immediate offsets.
+  auto fetch = [&](double (&v)[IIR_BLK], long i0) {
+    const long c = min(i0, m - IIR_BLK);
+    const double* p = rev ? in + (m - 1 - c) : in + c;
+#pragma unroll
+    for (int k = 0; k < IIR_BLK; ++k) v[k] = rev ? p[-k] : p[k];
+    __builtin_amdgcn_sched_barrier(0);    // or the scheduler sinks these loads below the block they are meant to overlap
+  };
+  auto warm = [&](const double (&v)[IIR_BLK]) {
+#pragma unroll
+    for (int k = 0; k < IIR_BLK; ++k) (void)iir_step(cf, z, v[k]);
+  };
+  auto emit = [&](const double (&v)[IIR_BLK], long i0) {
+    double* q = rev ? out + (m - 1 - i0) : out + i0;
+#pragma unroll
+    for (int k = 0; k < IIR_BLK; ++k) q[rev ? -k : k] = iir_step(cf, z, v[k]);
+  };
   long i = w0;
-  for (; i + 8 <= s; i += 8) {                              // warm-up: loads hoisted 8 at a time
-    double xv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xv[k] = in[rev ? m - 1 - (i + k) : i + k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) (void)iir_step(cf, z, xv[k]);
+  double xa[IIR_BLK], xb[IIR_BLK];
+  fetch(xa, i);
+  // s - w0 is IIR_WARM or s, both multiples of 2 * IIR_BLK: the warm-up ends on a pair boundary
+  for (; i + 2 * IIR_BLK <= s; i += 2 * IIR_BLK) {
+    fetch(xb, i + IIR_BLK);
+    warm(xa);
+    fetch(xa, i + 2 * IIR_BLK);
+    warm(xb);
   }
-  for (; i < s; ++i) (void)iir_step(cf, z, in[rev ? m - 1 - i : i]);
-  for (; i + 8 <= e; i += 8) {
-    double xv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xv[k] = in[rev ? m - 1 - (i + k) : i + k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) out[rev ? m - 1 - (i + k) : i + k] = iir_step(cf, z, xv[k]);
+  for (; i + 2 * IIR_BLK <= e; i += 2 * IIR_BLK) {
+    fetch(xb, i + IIR_BLK);
+    emit(xa, i);
+    fetch(xa, i + 2 * IIR_BLK);
+    emit(xb, i + IIR_BLK);
   }
-  for (; i < e; ++i) out[rev ? m - 1 - i : i] = iir_step(cf, z, in[rev ? m - 1 - i : i]);
+  for (; i < e; ++i) {                                    // the last slice's ragged end
+    const double y = iir_step(cf, z, in[rev ? m - 1 - i : i]);
+    if (i >= s) out[rev ? m - 1 - i : i] = y;
+  }
 }
 
 __global__ void crop_ext_kernel(const double* ext, double* y64, float* y32, long n, long es, long ys,
@@ -160,8 +189,8 @@ void launch_highpass(const float* x32, const double* x64, double* ext, double* y
   const unsigned g = (unsigned)std::min<long>(cdiv64(m, 256), 65535);
   const int nslices = (int)cdiv64(m, IIR_CHUNK);
   hipLaunchKernelGGL(odd_ext_kernel, dim3(g, B), dim3(256), 0, s, x32, x64, ext, n, xs, es, ns);
-  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, ext, tmp, m, 0, es, cf, ns);
-  hipLaunchKernelGGL(iir_slice_kernel, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, tmp, ext, m, 1, es, cf, ns);
+  hipLaunchKernelGGL(iir_slice_kernel<false>, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, ext, tmp, m, es, cf, ns);
+  hipLaunchKernelGGL(iir_slice_kernel<true>, dim3(cdiv(nslices, 64), B), dim3(64), 0, s, tmp, ext, m, es, cf, ns);
   hipLaunchKernelGGL(crop_ext_kernel, dim3(g, B), dim3(256), 0, s, ext, y64, y32, n, es, n, ns);
 }
 
