@@ -10,9 +10,10 @@
 //                subframe type of the format (CONSTANT, VERBATIM, FIXED, LPC, wasted bits), Rice / Rice2 residuals with
 //                escape partitions, the three stereo decorrelation modes, 4-32 bits per sample, CRC-8 / CRC-16 / MD5 checked.
 //
-// Written from the published format description (xiph.org FLAC format / RFC 9639); libFLAC is not in this image, so the
-// codec is checked against an independent test-side reader / writer of the same format (tests/flac_codec.py) -- "parity
-// unpinned" against libFLAC's own output, like the other third-party edges (oracle/audio.py).
+// Written from the published format description (xiph.org FLAC format / RFC 9639); libFLAC is not in this image.  The
+// decoder is pinned on the three streams of RFC 9639 Appendix D (written by libFLAC 1.3.3; tests/golden/flac_rfc9639_*.flac,
+// samples and the encoder's MD5 checked in tests/test_flac.py); the encoder is checked by an independent test-side reader of
+// the same format (tests/flac_codec.py) and round trips -- its block / predictor choices are its own, not libFLAC's.
 #include "../../include/rvcx.h"
 
 #include <cstring>

@@ -143,3 +143,38 @@ def test_streams_of_unknown_length_and_crafted_headers():
         _lib.flac_decode(_patch_streaminfo(blob, sample_rate=0))
     with pytest.raises(_lib.RvcxError):                       # a total that is plausible but wrong still fails, after decoding
         _lib.flac_decode(_patch_streaminfo(blob, total=12346))
+
+
+# ---- streams the product did not write: the three example files of RFC 9639 (FLAC), Appendix D -------------------------------
+# Written by the reference encoder (example 2 carries its vendor string, "reference libFLAC 1.3.3 20190804") and published byte
+# for byte with their decoded samples.  Each carries the encoder's own MD5 of the PCM in STREAMINFO and a CRC-16 per frame, so
+# the fixtures authenticate themselves (the test recomputes the MD5 from what the product's decoder returns).  Between them:
+# VERBATIM subframes with wasted bits (1), left/side decorrelation, FIXED predictors, Rice partitions with an escape code,
+# SEEKTABLE / VORBIS_COMMENT / PADDING blocks and a short last frame (2), an LPC subframe of order 2 at 8 bits per sample (3).
+RFC9639 = {
+    "1": (44100, 16, [[25588, 10416]]),
+    "2": (44100, 16, [[10372, 6070], [18041, 10545], [14942, 8743], [17876, 10449], [15627, 9143], [17899, 10463],
+                      [16242, 9502], [18077, 10569], [16824, 9840], [18263, 10680], [17295, 10113], [-14418, -8428],
+                      [-15201, -8895], [-14508, -8476], [-15195, -8896], [-14818, -8653], [-15486, -9072], [-15349, -8958],
+                      [-16054, -9410]]),
+    "3": (32000, 8, [[v] for v in (0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6,
+                                   -4, -5, 0)]),
+}
+
+
+@pytest.mark.parametrize("ex", ["1", "2", "3"])
+def test_decoder_reads_the_reference_encoders_streams_of_rfc9639(ex):
+    import hashlib
+    sr, bps, want = RFC9639[ex]
+    blob = open(os.path.join(os.path.dirname(__file__), "golden", f"flac_rfc9639_example{ex}.flac"), "rb").read()
+    got, sr2, bps2 = _lib.flac_decode(blob)
+    want = np.asarray(want)
+    assert (sr2, bps2) == (sr, bps) and got.size == want.size      # (mono comes back as a vector)
+    got = got.reshape(want.shape)
+    assert np.array_equal(got, want)
+    # STREAMINFO's MD5 (bytes 26..41 of the file: 4 'fLaC' + 4 block header + 18) is libFLAC's signature over the interleaved
+    # little-endian PCM at the stream's sample width
+    pcm = got.astype({8: np.int8, 16: "<i2"}[bps]).tobytes()
+    assert hashlib.md5(pcm).digest() == blob[26:42]
+    ref, sr3, bps3 = FC.read(blob)                # the independent reader agrees (and checks every CRC on the way)
+    assert (sr3, bps3) == (sr, bps) and np.array_equal(ref.reshape(want.shape), want)
