@@ -284,7 +284,11 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
   // where the caller's hook (pipeline.hip: "now enqueue HuBERT") runs: behind encoder level 0 .. nenc-1, behind the
   // intermediate layers (nenc), or behind the whole U-Net, in front of the recurrence (nenc + 1 and above; the default)
   static const int hook_env = getenv("RVCX_HUBERT_AFTER") ? atoi(getenv("RVCX_HUBERT_AFTER")) : 99;
-  const int hook_at = std::min(hook_env, nenc + 1);
+  // RVCX_HUBERT_AFTER_DEC = d (round 6 probe): behind decoder level d of the U-Net instead (0 = the deepest; nenc - 1 = behind
+  // the whole U-Net, the default's place)
+  static const int hook_dec = getenv("RVCX_HUBERT_AFTER_DEC") ? atoi(getenv("RVCX_HUBERT_AFTER_DEC")) : -1;
+  const bool dec_hook = hook_dec >= 0 && hook_dec < nenc - 1;
+  const int hook_at = dec_hook ? 1000 : std::min(hook_env, nenc + 1);
   RVCX_CHECK(Tp % (1 << nenc) == 0, "rmvpe: clip too short for the U-Net depth");
   const int nb = N_FFT / 2 + 1;
   // ---- ragged batch: item b holds ns_host[b] <= n samples.  The launch geometry is that of n for every item; the
@@ -410,6 +414,7 @@ void rmvpe_forward(Ctx& c, const RmvpeModel& m, int B, const float* audio, int64
       run_block(c, blk, x, y, w1, w2, B, s, d_lv[lv]);
       x = y;
     }
+    if (after_shallow && dec_hook && l == hook_dec) (*after_shallow)();
   }
   if (after_shallow && hook_at == nenc + 1) (*after_shallow)();
   // ---- cnn -> BiGRU -> Linear -> sigmoid   (RMVPE.py:373-376)
