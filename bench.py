@@ -55,6 +55,16 @@ WORKER_DEADLINE_S = 3600.0   # launch_workers: the whole multi-rank run
 # algorithmic HBM bytes of one launch of the dominant kernel (fused ResBlock step, NSF stage 2 of a 32 s chunk at 48 k:
 # C = 128 channels x 383 760 positions x 4 B, read x once + write y once); DESIGN.md "Algorithmic work per unit"
 DOM_ALGO_BYTES_PER_LAUNCH = 2 * 128 * 383760 * 4
+
+
+def dom_algo_bytes_per_launch():
+    """The same under the decoder window (round 6, default): a decoder call covers frames [skip, T - skip) of its chunk,
+    skip = (t_pad frames - the decoder's receptive field) & ~3 = 84 of 3198 at 48 k -> 363 600 positions at stage 2."""
+    if os.environ.get("RVCX_DEC_WINDOW", "1") == "0":
+        return DOM_ALGO_BYTES_PER_LAUNCH
+    from polgen_rvc_amd import synthetic as S, weights as W
+    skip = (100 - W.synth_dec_rf(S.SYNTH_CFG_48K)) & ~3
+    return 2 * 128 * (383760 - 2 * skip * 120) * 4
 PEAK_FILE = "mfma_peak_r04.json"   # profiles/: measured split-fp16 ceiling on random operands (tools/mfma_peak.hip)
 
 
@@ -247,6 +257,15 @@ def decoder_outliers_child(steps, warmup):
     return out
 
 
+def full_decoder_child(steps, warmup):
+    """C2 with the NSF decoder evaluated over every frame of every call (RVCX_DEC_WINDOW=0), as the reference does before it
+    throws t_pad_tgt samples away at both ends: what the decoder window (round 6) is worth, in the open."""
+    out, _ = child_bench(["--steps", str(steps), "--warmup", str(warmup)], {"RVCX_DEC_WINDOW": "0"},
+                         {"env": "RVCX_DEC_WINDOW=0", "workload": "c2, NSF decoder over all 3198 frames of the padded chunk "
+                          "(default: frames 84 .. 3114, the kept 30 s + the decoder's receptive field)"}, roofline=False)
+    return out
+
+
 def long_clip_child():
     """The reference's real workload in small: one 95 s clip per step -- F0 once over 9 700 frames, three silence-aligned
     chunks through HuBERT / TextEncoder / flow / decoder (the branch tests/test_gpu_round6.py pins to the reference)."""
@@ -404,7 +423,7 @@ def main():
         raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
     if a.dry_run:
         return dry_run(a, rank, world)
-    fp32 = c3_obj = c5_obj = out_obj = dec_out_obj = long_obj = None
+    fp32 = c3_obj = c5_obj = out_obj = dec_out_obj = long_obj = full_dec_obj = None
     clip_seconds = float(a.clip_seconds)
     if (world == 1 and not a.no_children and a.workload == "c2" and B == 1 and not fcpe and not a.hubert_outliers
             and not a.decoder_outliers and clip_seconds == CLIP_SECONDS):
@@ -412,6 +431,7 @@ def main():
         out_obj = outliers_child(a.steps, a.warmup)
         dec_out_obj = decoder_outliers_child(a.steps, a.warmup)
         long_obj = long_clip_child()
+        full_dec_obj = full_decoder_child(a.steps, a.warmup)
         c3_obj = c3_child()
         c5_obj = c5_child()
         time.sleep(5.0)                                  # the children left the chip warm: let it idle before the headline loop
@@ -598,7 +618,11 @@ def main():
                "data": "synthetic",
                "value_per_gpu": rtf / world,
                "value_is": "whole-job aggregate over n_gpus (driver contract); value_per_gpu = value / n_gpus",
-               "config": {"workload": wl + "; timed region = H2D of float PCM (pinned host) + all kernels + D2H of int16",
+               "config": {"workload": wl + "; timed region = H2D of float PCM (pinned host) + all kernels + D2H of int16"
+                          + ("; NSF decoder over every frame of every call (RVCX_DEC_WINDOW=0)"
+                             if os.environ.get("RVCX_DEC_WINDOW", "1") == "0" else
+                             "; the NSF decoder evaluates the samples VC.pipeline keeps + its receptive field, not the t_pad ends "
+                             "it throws away (same output; `full_decoder_value` = without)"),
                           "clips_per_step": len(clips), "micro_batch": ctx.micro_batch(mid, n, params),
                           "micro_batches": mbs_per_step, "index_exhaustive_queries": idx_exhaustive,
                           "out_samples": got[0] if len(got) == 1 else sum(got), "weights_bcast_bytes": nbytes,
@@ -637,16 +661,20 @@ def main():
         cfgd["c3_roofline_frac"] = _val(c3_obj, "roofline", "frac")
         cfgd["c5_value"] = _val(c5_obj, "value")
         cfgd["long_clip_value"] = _val(long_obj, "value")
+        cfgd["full_decoder_value"] = _val(full_dec_obj, "value")
         cfgd["roofline_traffic_ratio"] = (None if roofline is None or not roofline.get("traffic") else
-                                          roofline["traffic"] / DOM_ALGO_BYTES_PER_LAUNCH)
+                                          roofline["traffic"] / dom_algo_bytes_per_launch())
         cfgd["roofline_traffic_ratio_note"] = ("PMC bytes per launch of the dominant kernel / its algorithmic bytes "
-                                               "(read x + write y of a C=128 stage-2 step: 2 x 196.5 MB)")
+                                               "(read x + write y of a C=128 stage-2 step over the decoder window: 2 x 186.2 MB; 2 x 196.5 MB "
+                                               "with RVCX_DEC_WINDOW=0)")
         if fp32 is not None:
             res["exact_fp32"] = fp32
         if dec_out_obj is not None:
             res["decoder_outliers"] = dec_out_obj
         if long_obj is not None:
             res["long_clip"] = long_obj
+        if full_dec_obj is not None:
+            res["full_decoder"] = full_dec_obj
         if out_obj is not None:
             res["outliers"] = out_obj
         if c3_obj is not None:
@@ -654,7 +682,7 @@ def main():
         if c5_obj is not None:
             res["c5"] = c5_obj
         if fp32 is not None or c3_obj is not None:
-            res["order"] = ("children (exact_fp32, outliers, decoder_outliers, long_clip, c3, c5) ran first, each to completion; 5 s idle; "
+            res["order"] = ("children (exact_fp32, outliers, decoder_outliers, long_clip, full_decoder, c3, c5) ran first, each to completion; 5 s idle; "
                             "then this process's warm-up and timed loop")
         if not a.no_cpu_baseline and world == 1 and not fcpe:
             res["cpu_baseline"] = cpu_baseline()

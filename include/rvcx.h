@@ -182,6 +182,17 @@ int rvcx_synth_infer(rvcx_ctx*, int model_id, int B, int T, const int32_t* lens,
                      const float* phone_hd, const int32_t* pitch_hd, const float* pitchf_hd,
                      const int32_t* sid, const float* z_noise_hd, const float* src_noise_hd,
                      uint64_t seed, float* out_hd);
+/* the same with the NSF decoder evaluated on frames [dec_skip, len - dec_skip) of every item only (TextEncoder, flow and the
+ * harmonic source stay whole); out samples outside that window read 0.  What VC.pipeline does with the result --
+ * audio1[t_pad_tgt:-t_pad_tgt], rvc/infer/pipeline.py:432-447 -- makes the discarded ends dead work: with
+ * dec_skip <= t_pad frames - rvcx_synth_dec_rf(model) the kept samples are those of the full evaluation (the decoder is
+ * convolutional, nsf.py:100-144; rvcx_synth_dec_rf = its receptive field in frames, each side, + 2).  rvcx_convert_batch
+ * uses this internally (RVCX_DEC_WINDOW=0 turns it off); no reference counterpart. */
+int rvcx_synth_infer_window(rvcx_ctx*, int model_id, int B, int T, const int32_t* lens,
+                            const float* phone_hd, const int32_t* pitch_hd, const float* pitchf_hd,
+                            const int32_t* sid, const float* z_noise_hd, const float* src_noise_hd,
+                            uint64_t seed, int dec_skip, float* out_hd);
+int rvcx_synth_dec_rf(rvcx_ctx*, int model_id);
 /* the same with the intermediates the reference returns beside the waveform (synthesizers.py:186-188):
  * stats (B, 2*inter, T) = [m_p ; logs_p] of the TextEncoder, zflow (B, inter, T) = z after the reverse flow */
 int rvcx_synth_infer_taps(rvcx_ctx*, int model_id, int B, int T, const int32_t* lens,

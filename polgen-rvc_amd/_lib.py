@@ -77,7 +77,7 @@ SYMBOLS = [
     "rvcx_create", "rvcx_destroy", "rvcx_last_error", "rvcx_version", "rvcx_load_hubert",
     "rvcx_load_rmvpe", "rvcx_index_exhaustive", "rvcx_load_crepe", "rvcx_crepe_frames", "rvcx_crepe_predict", "rvcx_op_crepe_decode", "rvcx_get_f0_crepe_x", "rvcx_load_fcpe", "rvcx_fcpe_f0", "rvcx_fcpe_frames", "rvcx_get_f0_fcpe_x", "rvcx_op_fcpe_post", "rvcx_load_synth", "rvcx_unload_synth", "rvcx_load_index", "rvcx_load_index_ivf",
     "rvcx_weights_regions", "rvcx_weights_adopt", "rvcx_weights_clone", "rvcx_rmvpe_f0", "rvcx_rmvpe_frames", "rvcx_rmvpe_mel", "rvcx_synth_infer_taps", "rvcx_hubert_features",
-    "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_upp", "rvcx_index_blend",
+    "rvcx_hubert_frames", "rvcx_synth_infer", "rvcx_synth_infer_window", "rvcx_synth_dec_rf", "rvcx_synth_upp", "rvcx_index_blend",
     "rvcx_out_len", "rvcx_convert_batch", "rvcx_convert_batch_f64", "rvcx_micro_batch", "rvcx_bucket_length", "rvcx_last_micro_batches", "rvcx_noise_len",
     "rvcx_get_f0", "rvcx_get_f0_x", "rvcx_vc", "rvcx_vc_frames", "rvcx_last_timing",
     "rvcx_flop_counter", "rvcx_fp32_reruns", "rvcx_mem_info", "rvcx_conv_profile", "rvcx_conv_profile_csv", "rvcx_stream", "rvcx_op_conv1d", "rvcx_op_resblock_pair", "rvcx_bench_resblock_pair", "rvcx_bench_conv1d", "rvcx_conv_override", "rvcx_op_convtranspose1d",
@@ -427,11 +427,18 @@ class Context:
         self._ck(lib().rvcx_load_synth(self._h, C.byref(cfg_struct), tbl, len(tbl), C.byref(mid)), "load_synth")
         return mid.value
 
+    def unload_synth(self, model_id: int):
+        self._ck(lib().rvcx_unload_synth(self._h, int(model_id)), "unload_synth")
+
     def synth_upp(self, model_id: int) -> int:
         return int(lib().rvcx_synth_upp(self._h, model_id))
 
+    def synth_dec_rf(self, model_id) -> int:
+        """frames of z an output sample of the NSF decoder can depend on, each side (+ 2)"""
+        return int(lib().rvcx_synth_dec_rf(self._h, int(model_id)))
+
     def synth_infer(self, model_id, phone, pitch, pitchf, lens=None, sid=None, z_noise=None, src_noise=None,
-                    seed=0, taps=False):
+                    seed=0, taps=False, dec_skip=0):
         phone, pitchf = f32(phone), f32(pitchf)
         pitch = i32(pitch)
         B, T, _ = phone.shape
@@ -451,6 +458,11 @@ class Context:
                                                  _p(pitch, C.c_int32), _p(pitchf), _p(sid, C.c_int32), _p(zn), _p(sn),
                                                  C.c_uint64(seed), _p(out), _p(stats), _p(zflow)), "synth_infer_taps")
             return out, stats, zflow
+        if dec_skip:
+            self._ck(lib().rvcx_synth_infer_window(self._h, model_id, B, T, _p(lens, C.c_int32), _p(phone),
+                                                   _p(pitch, C.c_int32), _p(pitchf), _p(sid, C.c_int32), _p(zn), _p(sn),
+                                                   C.c_uint64(seed), int(dec_skip), _p(out)), "synth_infer_window")
+            return out
         self._ck(lib().rvcx_synth_infer(self._h, model_id, B, T, _p(lens, C.c_int32), _p(phone),
                                         _p(pitch, C.c_int32), _p(pitchf), _p(sid, C.c_int32), _p(zn), _p(sn),
                                         C.c_uint64(seed), _p(out)), "synth_infer")

@@ -916,14 +916,28 @@ int rvcx_weights_adopt(rvcx_ctx* ctx) {
 
 static int synth_infer_impl(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                             const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
-                            const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow);
+                            const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow, int dec_skip);
 
 int rvcx_synth_infer(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                      const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
                      const float* src_noise, uint64_t seed, float* out) {
   CtxLock ctx_guard_ = lock_ctx(ctx);
   return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, nullptr,
-                          nullptr);
+                          nullptr, 0);
+}
+
+int rvcx_synth_infer_window(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
+                            const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
+                            const float* src_noise, uint64_t seed, int dec_skip, float* out) {
+  CtxLock ctx_guard_ = lock_ctx(ctx);
+  return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, nullptr,
+                          nullptr, dec_skip < 0 ? 0 : dec_skip);
+}
+
+int rvcx_synth_dec_rf(rvcx_ctx* ctx, int model_id) {
+  int rf = -1;
+  const int rc = api_call(ctx, false, [&](Ctx* C) { rf = get_synth(*C, model_id).dec_rf_frames; });
+  return rc ? -1 : rf;
 }
 
 int rvcx_synth_infer_taps(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
@@ -931,12 +945,12 @@ int rvcx_synth_infer_taps(rvcx_ctx* ctx, int model_id, int B, int T, const int32
                           const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow) {
   CtxLock ctx_guard_ = lock_ctx(ctx);
   return synth_infer_impl(ctx, model_id, B, T, lens, phone, pitch, pitchf, sid, z_noise, src_noise, seed, out, stats,
-                          zflow);
+                          zflow, 0);
 }
 
 static int synth_infer_impl(rvcx_ctx* ctx, int model_id, int B, int T, const int32_t* lens, const float* phone,
                             const int32_t* pitch, const float* pitchf, const int32_t* sid, const float* z_noise,
-                            const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow) {
+                            const float* src_noise, uint64_t seed, float* out, float* stats, float* zflow, int dec_skip) {
   API_BEGIN(ctx)
   SynthModel& M = get_synth(*C, model_id);
   const int D = M.cfg.input_dim, inter = M.cfg.inter_channels;
@@ -968,6 +982,7 @@ static int synth_infer_impl(rvcx_ctx* ctx, int model_id, int B, int T, const int
   io.out = dout;
   if (stats) io.stats_out = C->arena.alloc<float>((size_t)B * 2 * inter * T);
   if (zflow) io.z_out = C->arena.alloc<float>((size_t)B * inter * T);
+  io.dec_skip = dec_skip;
   synth_forward(*C, M, io, nullptr);
   if (stats) RVCX_HIP(hipMemcpyAsync(stats, io.stats_out, (size_t)B * 2 * inter * T * 4, hipMemcpyDefault, C->stream));
   if (zflow) RVCX_HIP(hipMemcpyAsync(zflow, io.z_out, (size_t)B * inter * T * 4, hipMemcpyDefault, C->stream));

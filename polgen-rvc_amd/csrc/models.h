@@ -13,6 +13,9 @@ struct SynthModel {
   std::shared_ptr<WeightRegion> region = std::make_shared<WeightRegion>();   // freed with the model
   rvcx_synth_cfg cfg{};
   int upp = 1;
+  // frames of z an output sample of the NSF decoder can depend on, each side (conv_pre + every stage's ConvTranspose1d and
+  // ResBlocks + conv_post, rounded up + 2): what SynthIO::dec_skip must leave around the samples the caller keeps
+  int dec_rf_frames = 0;
   // TextEncoder (rvc/lib/algorithm/encoders.py:76-126)
   ConvW emb_phone;
   const float* emb_pitch = nullptr;  // (256, hidden)
@@ -59,6 +62,11 @@ struct SynthIO {
   const float* z_noise = nullptr;     // device (B,inter,T)
   const float* src_noise = nullptr;   // device (B,T*upp)
   float* out = nullptr;               // device (B, T*upp)
+  // Round 6: the decoder evaluates frames [dec_skip, len - dec_skip) of every item only (the source branch, TextEncoder and
+  // flow stay whole); output samples outside that window read as zero.  VC.pipeline throws t_pad_tgt samples of every
+  // decoder call away at both ends (pipeline.py:432-447): with dec_skip <= t_pad frames - SynthModel::dec_rf_frames the
+  // samples it keeps are the ones the full evaluation gives (the decoder is convolutional; its source is computed whole).
+  int dec_skip = 0;
   // optional taps for parity tests (device, may be null)
   float* stats_out = nullptr;         // (B, 2*inter, T) = [m_p ; logs_p]
   float* z_out = nullptr;             // (B, inter, T)

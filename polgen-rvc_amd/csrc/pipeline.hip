@@ -1138,6 +1138,14 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       io.B = G;
       io.T = T;
       io.lens_host = ragged ? lens_q.data() : nullptr;
+      {
+        // Round 6: only the part of each decoder call that survives the trim below (audio1[t_pad_tgt:-t_pad_tgt],
+        // pipeline.py:432-447) is evaluated, plus the decoder's receptive field around it (synth.hip, SynthIO::dec_skip; a
+        // multiple of four frames so that every shifted pointer stays 16-byte aligned).  RVCX_DEC_WINDOW=0: everything.
+        static const bool window_on = !getenv("RVCX_DEC_WINDOW") || atoi(getenv("RVCX_DEC_WINDOW")) != 0;
+        const int pad_frames = (int)(g.t_pad_tgt / M.upp);
+        io.dec_skip = window_on ? std::max(0, pad_frames - M.dec_rf_frames) & ~3 : 0;
+      }
       io.phone_ct = phone;
       io.pitch = pitch;
       io.pitchf = pitchf;

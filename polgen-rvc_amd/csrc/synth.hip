@@ -157,6 +157,26 @@ std::unique_ptr<SynthModel> synth_load(Ctx& c, const rvcx_synth_cfg& cfg, const 
     ch = co;
   }
   M->emb_g = c.slab.upload(t.f32("emb_g.weight"));
+  {
+    // Receptive field of the decoder in frames of z, each side (nsf.py:100-144, residuals.py:15-62): conv_pre k = 7 -> 3
+    // frames; stage i at R_i samples per frame: the ConvTranspose1d (k_i taps, stride s_i) reaches (k_i - 1) / s_i + 1 input
+    // samples (rate R_{i-1}), a ResBlock1 of kernel k and dilations d reaches sum_d (k - 1) / 2 (d + 1) samples; conv_post
+    // k = 7 -> 3 samples.  (The harmonic source and its noise convs are evaluated whole, they add nothing.)  48 k: 11.1.
+    double rf = 3.0, rate = 1.0;
+    for (int i = 0; i < cfg.n_ups; ++i) {
+      rf += ((cfg.up_kernels[i] - 1) / cfg.up_rates[i] + 1) / rate;
+      rate *= cfg.up_rates[i];
+      int res = 0;
+      for (int j = 0; j < cfg.n_resblocks; ++j) {
+        int r = 0;
+        for (int d = 0; d < 3; ++d) r += (cfg.res_kernels[j] - 1) / 2 * (cfg.res_dilations[j][d] + 1);
+        res = std::max(res, r);
+      }
+      rf += res / rate;
+    }
+    rf += 3.0 / rate;
+    M->dec_rf_frames = (int)std::ceil(rf) + 2;
+  }
   M->region->seal();
   return M;
 }
@@ -408,11 +428,14 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     // One utterance at a time -- or a group of EQUAL length -- runs at ITS OWN length Td (rows of the batched tensors stay T
     // apart): no masks, no work on padding, and every launch decision (tile, split-K) is the one the utterance's single run takes.
     const bool own = io.lens_host != nullptr && (db == 1 || equal_lens);
-    const int Td = own ? io.lens_host[b0] : T;
-    RVCX_CHECK(Td > 0 && Td <= T, "synth: item length outside (0, T]");
+    const int Tfull = own ? io.lens_host[b0] : T;
+    RVCX_CHECK(Tfull > 0 && Tfull <= T, "synth: item length outside (0, T]");
+    // the window of frames the decoder evaluates (SynthIO::dec_skip): [skip, Tfull - skip) of every member of the group
+    const int skip = (io.dec_skip > 0 && (own || !lens) && Tfull - 2 * io.dec_skip > 2 * m.dec_rf_frames) ? io.dec_skip : 0;
+    const int Td = Tfull - 2 * skip;
     float* cur = A.alloc<float>((size_t)db * C0 * Td);
     {
-      ConvArgs a = conv1d_args(m.conv_pre, z + (size_t)b0 * inter * T, cur, db, Td, Td, 1, 1, 3);
+      ConvArgs a = conv1d_args(m.conv_pre, z + (size_t)b0 * inter * T + skip, cur, db, Td, Td, 1, 1, 3);
       a.x_bs = (long)inter * T;
       a.x_cs = T;
       a.lens_in = (lens && !own) ? lens + b0 : nullptr;
@@ -422,10 +445,11 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       c.conv(a);
       launch_add_channel_bias(cur, gcond, db, C0, Td, s);
     }
-    long Tin = Td, Tin_c = T;
+    long Tin = Td, Tin_c = T, off = skip;      // off: first sample of the window at this stage's rate
     for (size_t i = 0; i < m.stages.size(); ++i) {
       const auto& S = m.stages[i];
       const long Tout = Tin * cf.up_rates[i], Tout_c = Tin_c * cf.up_rates[i];
+      off *= cf.up_rates[i];
       const size_t n = (size_t)db * S.ch * Tout;
       float* xs = A.alloc<float>(n);      // survives the stage (next stage's input)
       const size_t stage_mark = A.mark();
@@ -445,7 +469,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       a.lens_in = lin;
       a.lens_out = lout;
       if (nz_fused[i]) {               // x = up(x) + noise_conv(har_source), the noise conv inside the epilogue
-        a.nz_har = har + (size_t)b0 * Tupp;
+        a.nz_har = har + (size_t)b0 * Tupp + (size_t)skip * m.upp;
         a.nz_bs = Tupp;
         a.nz_w = S.noise.w;
         a.nz_wstride = S.noise.cin_gp * S.noise.cout_gp;
@@ -453,10 +477,10 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
         a.nz_k = S.noise.k;
         a.nz_stride = S.noise_stride;
         a.nz_pad = S.noise_pad;
-        a.nz_len = own ? (int)((long)Td * m.upp) : (int)Tupp;
+        a.nz_len = (own || skip) ? (int)((long)Td * m.upp) : (int)Tupp;
         a.nz_lens = (lens_stage[m.stages.size()] && !own) ? lens_stage[m.stages.size()] + b0 : nullptr;
       } else {
-        conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout_c, S.ch, (int)Tout_c);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
+        conv_set_res(a, nz[i] + (size_t)b0 * S.ch * Tout_c + off, S.ch, (int)Tout_c);   // x = up(x) + noise_conv(har_source)   (nsf.py:129)
       }
       c.conv(a);
       // xs = mean_j ResBlock1_j(x)   (nsf.py:131-139, residuals.py:45-53).  The nk blocks only share their
@@ -591,7 +615,7 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
     }
     {
       // x = leaky_relu(x) [default slope 0.01, nsf.py:142]; tanh(conv_post(x))
-      ConvArgs a = conv1d_args(m.conv_post, cur, io.out + (size_t)b0 * Tupp, db, (int)Tin, (int)Tin, 1, 1, 3);
+      ConvArgs a = conv1d_args(m.conv_post, cur, io.out + (size_t)b0 * Tupp + (size_t)skip * m.upp, db, (int)Tin, (int)Tin, 1, 1, 3);
       a.pre_act = ACT_LRELU;
       a.pre_slope = 0.01f;
       a.act = ACT_TANH;
@@ -599,9 +623,13 @@ void synth_forward(Ctx& c, const SynthModel& m, const SynthIO& io, hipEvent_t* s
       a.lens_out = a.lens_in;
       a.y_bs = (long)Tupp;             // output rows are T * upp apart whatever the group's own length
       c.conv(a);
-      if (own && Td < T)               // the rest of each item's output row reads as silence
+      if (skip + Td < T)               // the rest of each item's output row reads as silence
         for (int q = 0; q < db; ++q)
-          RVCX_HIP(hipMemsetAsync(io.out + (size_t)(b0 + q) * Tupp + (size_t)Td * m.upp, 0, (size_t)(T - Td) * m.upp * sizeof(float), s));
+          RVCX_HIP(hipMemsetAsync(io.out + (size_t)(b0 + q) * Tupp + (size_t)(skip + Td) * m.upp, 0,
+                                  (size_t)(T - skip - Td) * m.upp * sizeof(float), s));
+      if (skip)                        // and so does what lies in front of the window
+        for (int q = 0; q < db; ++q)
+          RVCX_HIP(hipMemsetAsync(io.out + (size_t)(b0 + q) * Tupp, 0, (size_t)skip * m.upp * sizeof(float), s));
     }
   }
   tm.mark(3);

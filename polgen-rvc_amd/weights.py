@@ -32,6 +32,23 @@ def synth_cfg_struct(cfg: List, input_dim: int = 768) -> _lib.SynthCfg:
     return s
 
 
+def synth_dec_rf(cfg: List) -> int:
+    """Frames of z an output sample of the NSF decoder can depend on, each side, + 2 -- the host-side twin of
+    SynthModel::dec_rf_frames (csrc/synth.hip): conv_pre k = 7; per stage the ConvTranspose1d's (k - 1) // stride + 1 input
+    samples and the widest ResBlock1's sum_d (k - 1) // 2 * (d + 1) samples at that stage's rate; conv_post k = 7
+    (rvc/lib/algorithm/nsf.py:100-144, residuals.py:15-62).  The decoder window of the pipeline (SynthIO::dec_skip) leaves
+    this many frames around the samples VC.pipeline keeps."""
+    import math
+    rks, rds, ups, upks = cfg[10], cfg[11], cfg[12], cfg[14]
+    rf, rate = 3.0, 1.0
+    for u, k in zip(ups, upks):
+        rf += ((k - 1) // u + 1) / rate
+        rate *= u
+        rf += max(sum((rk - 1) // 2 * (d + 1) for d in ds) for rk, ds in zip(rks, rds)) / rate
+    rf += 3.0 / rate
+    return int(math.ceil(rf)) + 2
+
+
 def rmvpe_cfg_struct(cfg: Dict) -> _lib.RmvpeCfg:
     s = _lib.RmvpeCfg()
     s.n_blocks, s.en_de_layers = cfg["n_blocks"], cfg["en_de_layers"]

@@ -121,3 +121,10 @@ def test_branch_stream_modes_pass_the_reference_goldens(mode):
     three streams (rounds 2 - 5), 0 = all on the main stream.  The running mean over the branches is ordered by events, so the
     PCM must not change: the multi-chunk tiny golden, the CI-argument golden, C2 at full size, the float waveform vs the oracle."""
     _run_mode({"RVCX_RESBLOCK_STREAMS": mode})
+
+
+def test_full_decoder_evaluation_passes_the_reference_goldens_too():
+    """RVCX_DEC_WINDOW=0 (round 6): the NSF decoder over every frame of every call, as before the decoder window -- the
+    reference goldens (tiny multi-chunk, CI arguments, C2 full size, float waveform) and the full-size batch == single tests."""
+    _run_mode({"RVCX_DEC_WINDOW": "0"})
+    _run_mode({"RVCX_DEC_WINDOW": "0"}, "test_gpu_fullsize_batch.py", "c3_batch_of_8 or ragged_full_size", "2 passed")

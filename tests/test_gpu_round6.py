@@ -390,3 +390,67 @@ def test_bigru_publish_probe_holds_on_this_device(ctx):
     rng = np.random.default_rng(5)
     f0 = ctx.rmvpe_f0(rng.standard_normal(16000).astype(np.float32) * 0.1)
     assert np.all(np.isfinite(f0)) and ctx.gru_fallbacks() == fb0
+
+
+def _window_inputs(cfg, E, B, T, seed):
+    g = np.random.default_rng(seed)
+    inter, upp = cfg[2], int(np.prod(cfg[12]))
+    phone = (g.standard_normal((B, T, E)) * 0.3).astype(np.float32)
+    pitchf = (160.0 + 60.0 * np.sin(np.arange(T)[None] / 9.0 + g.uniform(0, 3, (B, 1)))).astype(np.float32)
+    pitchf[:, T // 3:T // 3 + 20] = 0.0                          # an unvoiced stretch
+    pitch = np.clip(np.rint(1 + 254 * (pitchf - 50) / 1050), 1, 255).astype(np.int32)
+    zn = g.standard_normal((B, inter, T)).astype(np.float32)
+    sn = g.standard_normal((B, T * upp)).astype(np.float32)
+    return phone, pitch, pitchf, zn, sn, upp
+
+
+@pytest.mark.parametrize("name,T", [("48k", 264), ("40k", 250), ("tiny", 300)])
+def test_decoder_window_gives_the_samples_of_the_full_evaluation(ctx, name, T):
+    """SynthIO::dec_skip (round 6): the NSF decoder evaluated on frames [skip, T - skip) only must return, inside what
+    VC.pipeline keeps (audio1[t_pad_tgt:-t_pad_tgt], t_pad = 100 frames), the samples of the full evaluation -- up to fp32
+    rounding where a launch's tile / split choice follows the shorter length (measured: 0 or ~1e-7) -- and silence outside
+    its window.  Negative control: a window that starts only 4 frames in front of the kept samples (inside the receptive
+    field, tests/test_decoder_window.py) must NOT reproduce their first frames."""
+    from polgen_rvc_amd import synthetic as S, weights as W
+    cfg = {"48k": S.SYNTH_CFG_48K, "40k": S.SYNTH_CFG_40K, "tiny": S.SYNTH_CFG_TINY}[name]
+    E = 768 if name != "tiny" else S.HUBERT_CFG_TINY["embed_dim"]
+    mid = ctx.load_synth(W.synth_cfg_struct(cfg, E), S.synth_state(cfg, 11, input_dim=E))
+    try:
+        rf = ctx.synth_dec_rf(mid)
+        assert rf == W.synth_dec_rf(cfg)
+        pad = 100
+        skip = (pad - rf) & ~3
+        phone, pitch, pitchf, zn, sn, upp = _window_inputs(cfg, E, 1, T, 3)
+        full = ctx.synth_infer(mid, phone, pitch, pitchf, z_noise=zn, src_noise=sn)[0]
+        win = ctx.synth_infer(mid, phone, pitch, pitchf, z_noise=zn, src_noise=sn, dec_skip=skip)[0]
+        keep = slice(pad * upp, (T - pad) * upp)
+        d = np.abs(win[keep] - full[keep]).max()
+        print(f"{name}: rf {rf}, skip {skip} of {T} frames; kept region max |diff| {d:.2e} (signal rms {rms(full[keep]):.3f})")
+        assert d <= 2e-6
+        assert not win[:skip * upp].any() and not win[(T - skip) * upp:].any()
+        assert np.abs(full[:skip * upp]).max() > 1e-3                    # (what was skipped was not silence)
+        bad = ctx.synth_infer(mid, phone, pitch, pitchf, z_noise=zn, src_noise=sn, dec_skip=pad - 4)[0]
+        first = slice(pad * upp, (pad + 2) * upp)
+        assert np.abs(bad[first] - full[first]).max() > 1e-4, "the control window is inside the receptive field"
+    finally:
+        ctx.unload_synth(mid)
+
+
+def test_decoder_window_in_a_ragged_group(ctx):
+    """members of different lengths: each is windowed at its own length ([skip, len - skip)), results inside each member's
+    kept region equal its full evaluation"""
+    from polgen_rvc_amd import synthetic as S, weights as W
+    cfg, E = S.SYNTH_CFG_TINY, S.HUBERT_CFG_TINY["embed_dim"]
+    mid = ctx.load_synth(W.synth_cfg_struct(cfg, E), S.synth_state(cfg, 12, input_dim=E))
+    try:
+        T, lens, pad = 320, [320, 276, 301], 100
+        skip = (pad - ctx.synth_dec_rf(mid)) & ~3
+        phone, pitch, pitchf, zn, sn, upp = _window_inputs(cfg, E, 3, T, 4)
+        full = ctx.synth_infer(mid, phone, pitch, pitchf, lens=lens, z_noise=zn, src_noise=sn)
+        win = ctx.synth_infer(mid, phone, pitch, pitchf, lens=lens, z_noise=zn, src_noise=sn, dec_skip=skip)
+        for b, L in enumerate(lens):
+            keep = slice(pad * upp, (L - pad) * upp)
+            assert np.abs(win[b, keep] - full[b, keep]).max() <= 2e-6, b
+            assert not win[b, :skip * upp].any() and not win[b, (L - skip) * upp:].any()
+    finally:
+        ctx.unload_synth(mid)
