@@ -89,6 +89,7 @@ static int api_call(rvcx_ctx* ctxp, bool repeat, F&& body) {
       Fp32Scope fp32_scope(attempt > 0 && attempt == last);
       GruScope gru_scope(gru_plain);
       C->launch_seq = 0;
+      C->err_snapshot = false;
       try {
         body(C);
       } catch (const GruTimeout&) {
@@ -201,6 +202,8 @@ int rvcx_create(int device, rvcx_ctx** out) {
     h->c.serial = h->c.serial_env;
     RVCX_HIP(hipMalloc(&h->c.dev_err, sizeof(int)));
     RVCX_HIP(hipMemset(h->c.dev_err, 0, sizeof(int)));
+    RVCX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->c.err_host), sizeof(int), hipHostMallocDefault));
+    *h->c.err_host = 0;
     h->c.arena.reserve((size_t)256 << 20);
     {
       // One-time work a serving process should not pay inside its first request (round 2: 88 ms in the first call's

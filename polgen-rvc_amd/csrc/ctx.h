@@ -207,6 +207,12 @@ struct Ctx {
   bool serial = false;            // profiling: keep every launch on the main stream (true per-kernel times)
   bool serial_env = false;        // RVCX_SERIAL=1: serial for the whole life of the context
   int* dev_err = nullptr;         // device error word (conv.h: kErrGruTimeout, kErrH3Overflow), read after each API call
+  // Round 6: a call that ends in its own stream synchronisation copies the word into pinned host memory just in front of
+  // it (snapshot_dev_err); check_dev_err / take_overflow then read that copy instead of issuing two synchronous 4-byte
+  // hipMemcpy's of their own (~40 us each of a single clip's wall time).  Valid for the one call that took it.
+  int* err_host = nullptr;
+  bool err_snapshot = false;
+  void snapshot_dev_err(hipStream_t s);   // enqueue the copy on s; the caller synchronises s before check_dev_err
   void check_dev_err();           // throws on a GRU timeout; an fp16-split overflow is left for take_overflow()
   bool take_overflow();           // true (and the bit cleared) when a split kernel met an activation beyond fp16
   long fp32_reruns = 0;           // calls repeated because of that (each repeat pins one layer to fp32, or, last resort, all)

@@ -56,10 +56,17 @@ std::vector<float> TensorTable::f32(const std::string& name) const {
 
 Ctx::Ctx() {}
 
+void Ctx::snapshot_dev_err(hipStream_t s) {
+  if (!dev_err || !err_host) return;
+  RVCX_HIP(hipMemcpyAsync(err_host, dev_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  err_snapshot = true;
+}
+
 void Ctx::check_dev_err() {
   if (!dev_err) return;
   int v = 0;
-  RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (err_snapshot) v = *err_host;
+  else RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
   if (inject_gru_timeout) {       // test hook (rvcx_debug_inject): behave as if the cluster kernel had timed out
     inject_gru_timeout = false;
     v |= kErrGruTimeout;
@@ -67,6 +74,7 @@ void Ctx::check_dev_err() {
   if (v & kErrGruTimeout) {
     v &= ~kErrGruTimeout;
     RVCX_HIP(hipMemcpy(dev_err, &v, sizeof(int), hipMemcpyHostToDevice));
+    if (err_snapshot) *err_host = v;
     throw GruTimeout("device-side timeout: a GRU cluster workgroup lost its partner");
   }
 }
@@ -74,7 +82,9 @@ void Ctx::check_dev_err() {
 bool Ctx::take_overflow() {
   if (!dev_err) return false;
   int v = 0;
-  RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (err_snapshot) v = *err_host;
+  else RVCX_HIP(hipMemcpy(&v, dev_err, sizeof(int), hipMemcpyDeviceToHost));
+  err_snapshot = false;            // the copy was this call's: the next reader asks the device
   if (!(v & kErrH3Overflow)) return false;
   v &= ~kErrH3Overflow;
   RVCX_HIP(hipMemcpy(dev_err, &v, sizeof(int), hipMemcpyHostToDevice));
@@ -90,6 +100,7 @@ Ctx::~Ctx() {
   if (timer.made)
     for (auto& e : timer.ev) (void)hipEventDestroy(e);
   if (dev_err) (void)hipFree(dev_err);
+  if (err_host) (void)hipHostFree(err_host);
   for (auto* p : splitk_buf)
     if (p) (void)hipFree(p);
   if (ev_fork) (void)hipEventDestroy(ev_fork);

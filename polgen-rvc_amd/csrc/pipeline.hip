@@ -284,11 +284,16 @@ __global__ void envelope_kernel(float* audio, const float* rms1, int n1, const f
   }
 }
 
-__global__ void absmax_kernel(const float* x, long n, unsigned int* out) {
+// (round 6: one atomic per workgroup instead of one per wave -- 4096 atomics on one word were 45 of the kernel's 49 us)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, unsigned int* out) {
+  __shared__ float part[4];
   float m = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order as uints
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));   // non-negative floats order as uints
 }
 
 // audio_max = max|x| / 0.99; scale = 32768 (/ audio_max if > 1); int16 truncation  (pipeline.py:457-461)
@@ -1196,7 +1201,7 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
       }
       unsigned int* amax = A.alloc<unsigned int>(1);
       RVCX_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned int), s));
-      hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 1024)), dim3(256), 0, s, u.outf,
+      hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 512)), dim3(256), 0, s, u.outf,
                          u.out_n, amax);
       hipLaunchKernelGGL(to_int16_kernel, dim3((unsigned)std::min<long>(cdiv64(u.out_n, 256), 65535)), dim3(256), 0, s,
                          u.outf, u.pcm, u.out_n, amax);
@@ -1228,6 +1233,10 @@ void convert_batch(Ctx& c, int model_id, std::vector<UttIO>& ios, const rvcx_par
     }
   }
   const int e_end = clk.mark(s);
+  // the device error word travels with the call's own synchronisation (Ctx::snapshot_dev_err): every kernel that can set it
+  // has been joined into the main stream by now (F0 and HuBERT streams through ev_join / ev_hubdone, the branch streams
+  // at each stage's end)
+  c.snapshot_dev_err(s);
   RVCX_HIP(hipStreamSynchronize(s));
   if (sf != s) RVCX_HIP(hipStreamSynchronize(sf));
   if (sio != s) RVCX_HIP(hipStreamSynchronize(sio));
