@@ -27,6 +27,10 @@ SYNTH_CFG_48K = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11],
 SYNTH_CFG_40K = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11],
                  [[1, 3, 5], [1, 3, 5], [1, 3, 5]], [10, 10, 2, 2], 512,
                  [16, 16, 4, 4], 109, 256, 40000]
+# the 32 k geometry of RVC v2 (upstream configs/v2/32000.json): rates 10 x 8 x 2 x 2, kernels 20 / 16 / 4 / 4
+SYNTH_CFG_32K = [513, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11],
+                 [[1, 3, 5], [1, 3, 5], [1, 3, 5]], [10, 8, 2, 2], 512,
+                 [20, 16, 4, 4], 109, 256, 32000]
 # reduced config for fast unit tests: channel counts that are NOT multiples of the
 # 32-wide MFMA tile on purpose (exercises the padding / guard paths)
 SYNTH_CFG_TINY = [1025, 32, 48, 48, 96, 2, 2, 3, 0, "1", [3, 7, 11],

@@ -232,10 +232,11 @@ def test_index_with_duplicated_rows_is_searched_exhaustively_and_exactly(ctx):
     ctx.load_index(None)
 
 
-@pytest.mark.parametrize("tag", ["c1_5s_40k", "c2_30s_48k"])
+@pytest.mark.parametrize("tag", ["c1_5s_40k", "c2_30s_48k", "v2_4s_32k"])
 def test_full_size_pipeline_vs_reference_golden(ctx, tag):
-    """BASELINE configs C1 (5 s, 40 k) and C2 (30 s, 48 k) at full model size against the reference's own
-    VC.pipeline output, stored as every 997-th sample + per-4096-block RMS (tools/gen_golden.py --full).
+    """BASELINE configs C1 (5 s, 40 k) and C2 (30 s, 48 k) -- and, round 6, the third geometry RVC v2 ships, a 32 k voice
+    model (rates 10 x 8 x 2 x 2: a stride-8 ConvTranspose1d, a 64-tap noise conv, upp = 320) -- at full model size against
+    the reference's own VC.pipeline output, stored as every 997-th sample + per-4096-block RMS (tools/gen_golden.py --full).
     The two Gaussian draws are regenerated from the recorded seed of the private torch.Generator the
     harness fed the reference with, in the reference's draw order (z, then the source noise)."""
     from polgen_rvc_amd import synthetic as S

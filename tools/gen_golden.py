@@ -663,6 +663,11 @@ def main():
         # an RVC v1 voice model at full size: HuBERT-base layer 9 (not 12) + final_proj 768 -> 256, 40 k synthesizer on 256 features
         steps["pipe_v1_full"] = lambda: gold_pipeline("v1_5s_40k", full40, (1, 6, 38, 41), 5.0, 4, 0, 0, 1.0, 0.33,
                                                       50, 1100, full_store=False, version="v1")
+        # round 6: the third geometry RVC v2 ships (32 k: upsample rates 10 x 8 x 2 x 2, kernels 20 / 16 / 4 / 4 -- a stride-8
+        # ConvTranspose1d, noise convs of 64 / 8 / 4 / 1 taps, upp = 320)
+        full32 = (S.HUBERT_CFG_BASE, S.RMVPE_CFG_FULL, S.SYNTH_CFG_32K)
+        steps["pipe_32k"] = lambda: gold_pipeline("v2_4s_32k", full32, (1, 6, 38, 41), 4.0, 5, 0, 0, 1.0, 0.33,
+                                                  50, 1100, full_store=False)
         steps["pipe_c3"] = gold_pipeline_c3
         steps["pipe_c5"] = gold_pipeline_c5
     for k, fn in steps.items():
