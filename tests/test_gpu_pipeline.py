@@ -69,7 +69,7 @@ def test_highpass_matches_scipy(ctx):
     assert np.abs(got - ref).max() < 1e-6
 
 
-@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short"])
+@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short", "tiny_sid3_noprotect"])
 def test_pipeline_vs_reference_golden(ctx, tag):
     from polgen_rvc_amd import synthetic as S
     from polgen_rvc_amd.infer import infer as I
@@ -80,7 +80,8 @@ def test_pipeline_vs_reference_golden(ctx, tag):
     cfg.x_pad, cfg.x_query, cfg.x_center, cfg.x_max = [int(v) for v in d["geo"]]
     cpt, version, net_g, tgt_sr, vc = I.get_vc("cuda:0", False, cfg, None, cpt=cpt)
     audio = S.make_clip(int(d["clip"]), float(d["seconds"]))
-    pcm, f32 = vc.pipeline(hub, net_g, 0, audio.astype(np.float64), "x.wav", float(d["pitch"]), "rmvpe+", None, 0,
+    sid = int(d["sid"]) if "sid" in d.files else 0      # tiny_sid3_noprotect (round 6): speaker row 3, protect 0.5 = off
+    pcm, f32 = vc.pipeline(hub, net_g, sid, audio.astype(np.float64), "x.wav", float(d["pitch"]), "rmvpe+", None, 0,
                            1, 3, tgt_sr, 0, float(d["volume_envelope"]), "v2", float(d["protect"]), 128, None,
                            float(d["f0_min"]), float(d["f0_max"]), noise=_pack_noise(d), return_f32=True)
     ref = d["pcm"]

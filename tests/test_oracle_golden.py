@@ -61,7 +61,7 @@ def test_hubert_oracle_vs_hf_twin(tag):
     assert rms(out - d["out"]) / rms(d["out"]) < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short", "tiny_v1"])
+@pytest.mark.parametrize("tag", ["tiny_single", "tiny_ciargs", "tiny_chunked", "tiny_short", "tiny_v1", "tiny_sid3_noprotect"])
 def test_pipeline_oracle_vs_reference(tag):
     from oracle import pipeline as OP
     S = _S()
@@ -75,8 +75,9 @@ def test_pipeline_oracle_vs_reference(tag):
     noises = [(torch.from_numpy(d[f"z_noise_{i}"]), torch.from_numpy(d[f"src_noise_{i}"]))
               for i in range(int(d["n_chunks"]))]
     audio = S.make_clip(int(d["clip"]), float(d["seconds"]))
+    sid = int(d["sid"]) if "sid" in d.files else 0
     pcm, parts = OP.pipeline(models, OP.Geometry(scfg[-1], *[int(v) for v in d["geo"]]), audio, float(d["pitch"]),
-                             0, None, 0.0, float(d["volume_envelope"]), float(d["protect"]), float(d["f0_min"]),
+                             sid, None, 0.0, float(d["volume_envelope"]), float(d["protect"]), float(d["f0_min"]),
                              float(d["f0_max"]), noises=noises, return_parts=True)
     assert len(parts["plan"]) == int(d["n_chunks"])
     assert pcm.shape == d["pcm"].shape

@@ -305,7 +305,7 @@ def gold_hubert(tag, cfg, seconds, seed, outliers=False):
 
 
 def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0_min, f0_max, seed,
-                     tgt_sr, file_index=None, index_rate=0, prebuilt=None, f0_method="rmvpe+", version="v2"):
+                     tgt_sr, file_index=None, index_rate=0, prebuilt=None, f0_method="rmvpe+", version="v2", sid=0):
     (hcfg, hsd), (rcfg, rsd), (scfg, ssd) = models_cfg
     vc = P.VC(tgt_sr, Cfg(geo))
     if prebuilt is None:
@@ -334,7 +334,7 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
     torch.randn_like = cap
     torch.manual_seed(seed)
     try:
-        pcm = vc.pipeline(hub, net, 0, audio.astype(np.float64), "x.wav", pitch, f0_method, file_index, index_rate,
+        pcm = vc.pipeline(hub, net, sid, audio.astype(np.float64), "x.wav", pitch, f0_method, file_index, index_rate,
                           1, 3, tgt_sr, 0, volume_envelope, version, protect, 128, None, f0_min, f0_max)
     finally:
         torch.randn_like = orig
@@ -343,7 +343,7 @@ def run_ref_pipeline(models_cfg, geo, audio, pitch, volume_envelope, protect, f0
 
 
 def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, protect, f0_min, f0_max,
-                  full_store=True, fixed_seed=None, version="v2"):
+                  full_store=True, fixed_seed=None, version="v2", sid=0):
     """version "v1": the voice model takes final_proj(HuBERT layer 9) -- emb_phone's input width is the HuBERT's final_dim
     (pipeline.py:228-236, infer.py:91-97)"""
     hcfg, rcfg, scfg = cfgs
@@ -360,11 +360,11 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
     audio = S.make_clip(clip, seconds)
     t0 = time.time()
     pcm, raw, noises = run_ref_pipeline(((hcfg, hsd), (rcfg, rsd), (scfg, ssd)), geo, audio, pitch,
-                                        volume_envelope, protect, f0_min, f0_max, seed, tgt_sr, version=version)
+                                        volume_envelope, protect, f0_min, f0_max, seed, tgt_sr, version=version, sid=sid)
     t_ref = time.time() - t0
     models = O_pipe.Models(hsd, hcfg, rsd, rcfg, ssd, scfg, version=version)
     t0 = time.time()
-    opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(tgt_sr, *geo), audio, pitch, 0, None, 0.0,
+    opcm, parts = O_pipe.pipeline(models, O_pipe.Geometry(tgt_sr, *geo), audio, pitch, sid, None, 0.0,
                                   volume_envelope, protect, f0_min, f0_max, noises=noises, return_parts=True)
     t_or = time.time() - t0
     print(f"  chunks={len(raw)}  ref {t_ref:.1f}s  oracle {t_or:.1f}s  out={pcm.shape}")
@@ -375,7 +375,7 @@ def gold_pipeline(tag, cfgs, geo, seconds, clip, seed, pitch, volume_envelope, p
     print(f"  pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
     assert e < 1e-4 and d.max() <= 8, (e, d.max())
     rawcat = np.concatenate(raw)
-    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, version=version,
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, version=version, sid=sid,
                  volume_envelope=volume_envelope, protect=protect, f0_min=f0_min, f0_max=f0_max,
                  cfgs=json.dumps([hcfg, rcfg, scfg]), n_chunks=len(raw),
                  chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
@@ -482,7 +482,7 @@ def gold_pipeline_fcpe(tag, cfgs, fcfg, geo, seconds, clip, seed, pitch, volume_
     print(f"  chunks={len(raw)} pcm: max |diff| = {d.max()} LSB, frac>1LSB = {(d > 1).mean():.2e}")
     assert e < 1e-4 and d.max() <= 8, (e, d.max())
     rawcat = np.concatenate(raw)
-    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, version=version, volume_envelope=volume_envelope,
+    store = dict(seed=seed, clip=clip, seconds=seconds, geo=np.array(geo), pitch=pitch, version=version, sid=sid, volume_envelope=volume_envelope,
                  protect=protect, f0_min=50, f0_max=1100, cfgs=json.dumps([hcfg, fcfg, scfg]), n_chunks=len(raw),
                  chunk_lens=np.array([len(r) for r in raw]), f0=parts["f0"].astype(np.float32),
                  coarse=parts["coarse"].astype(np.int16), sha256=hashlib.sha256(pcm.tobytes()).hexdigest(),
@@ -640,6 +640,8 @@ def main():
         "pipe_fcpe_tiny": lambda: gold_pipeline_fcpe("tiny_fcpe", tiny, S.FCPE_CFG_TINY, (1, 6, 38, 41), 2.0, 14, 1, 1.0, 1.0, 0.33),
         "pipe_tiny_chunks": lambda: gold_pipeline("tiny_chunked", tiny, (1, 1, 2, 3), 7.3, 13, 1, 2, 1.0, 0.33, 50, 1100),
         # round 6: an RVC v1 voice model (HuBERT output layer 9 + final_proj, emb_phone on final_dim features)
+        # round 6: a speaker id other than 0 (row 3 of emb_g) and the protect mix switched off (protect >= 0.5, pipeline.py:252-262)
+        "pipe_tiny_sid": lambda: gold_pipeline("tiny_sid3_noprotect", tiny, (1, 6, 38, 41), 2.1, 17, 1, 1.5, 0.6, 0.5, 50, 1100, sid=3),
         "pipe_tiny_v1": lambda: gold_pipeline("tiny_v1", tiny, (1, 6, 38, 41), 2.2, 16, 1, 0, 1.0, 0.33, 50, 1100, version="v1"),
     }
     if a.full:
