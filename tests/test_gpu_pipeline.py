@@ -279,22 +279,25 @@ def test_full_size_pipeline_vs_reference_golden(ctx, tag):
     assert np.mean(coarse != d["coarse"]) < 1e-3
 
 
-@pytest.mark.parametrize("seconds,clip", [(1.37, 71), (2.003, 72), (3.71, 73)])
-def test_odd_lengths_vs_oracle(ctx, seconds, clip):
+@pytest.mark.parametrize("seconds,clip,geo", [(1.37, 71, (1, 1, 2, 3)), (2.003, 72, (1, 1, 2, 3)), (3.71, 73, (1, 1, 2, 3)),
+                                              (4.3, 74, (3, 10, 60, 65)), (9.1, 75, (2, 1, 3, 4))])
+def test_odd_lengths_vs_oracle(ctx, seconds, clip, geo):
     """Odd clip lengths (frame counts that are not multiples of any tile size, single- and multi-chunk) against the
-    CPU oracle: float waveform within 2e-5 RMS (budget 1e-3), PCM within 4 LSB."""
+    CPU oracle: float waveform within 2e-5 RMS (budget 1e-3), PCM within 4 LSB.  Round 6: also the reference's CPU
+    geometry (3,10,60,65) (infer.py:45-63; t_pad = 3 s: the decoder window then drops 284 of 300 padding frames per side)
+    and x_pad = 2 with cuts."""
     from oracle import pipeline as OP
     from polgen_rvc_amd import synthetic as S
     from polgen_rvc_amd.infer import infer as I
     cfgs = (S.HUBERT_CFG_TINY, S.RMVPE_CFG_TINY, S.SYNTH_CFG_TINY)
     hub, cpt = _setup(ctx, cfgs, 4)
     cfg = I.Config()
-    cfg.x_pad, cfg.x_query, cfg.x_center, cfg.x_max = 1, 1, 2, 3
+    cfg.x_pad, cfg.x_query, cfg.x_center, cfg.x_max = geo
     cpt, version, net_g, tgt_sr, vc = I.get_vc("cuda:0", False, cfg, None, cpt=cpt)
     audio = S.make_clip(clip, seconds)
     models = OP.Models(S.to_torch(S.hubert_state(cfgs[0], 4)), cfgs[0], S.to_torch(S.rmvpe_state(cfgs[1], 4)),
                        cfgs[1], S.to_torch(cpt["weight"]), cfgs[2])
-    opcm, parts = OP.pipeline(models, OP.Geometry(tgt_sr, 1, 1, 2, 3), audio, 0.0, 0, None, 0.0, 1.0, 0.33, 50,
+    opcm, parts = OP.pipeline(models, OP.Geometry(tgt_sr, *geo), audio, 0.0, 0, None, 0.0, 1.0, 0.33, 50,
                               1100, seed=3, return_parts=True)
     noise = np.concatenate([np.concatenate([z.numpy().ravel(), s.numpy().ravel()]) for z, s in parts["noises"]])
     pcm, f32 = vc.pipeline(hub, net_g, 0, audio, "x.wav", 0.0, "rmvpe+", None, 0, 1, 3, tgt_sr, 0, 1.0, "v2", 0.33,
