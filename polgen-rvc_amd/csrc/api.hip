@@ -178,7 +178,21 @@ int rvcx_create(int device, rvcx_ctx** out) {
       const bool prio = !getenv("RVCX_F0_PRIORITY") || atoi(getenv("RVCX_F0_PRIORITY")) != 0;
       RVCX_HIP(hipStreamCreateWithPriority(&h->c.stream2, hipStreamNonBlocking, prio ? hi : lo));
     }
-    for (auto& s : h->c.aux) RVCX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    RVCX_HIP(hipStreamCreateWithFlags(&h->c.aux[0], hipStreamNonBlocking));
+    {
+      // RVCX_HUBERT_CUS = N (round 6 probe, with RVCX_HUBERT_ON=aux1 RVCX_HUBERT_GATE=0): aux[1] -- unused by the default two
+      // branch streams, created fourth like before so that it shares its hardware queue with the main stream, which idles
+      // during a single clip's front end -- is confined to the first N CUs (bit i = XCD i mod 8, CU i / 8:
+      // tools/cu_mask_probe.hip), for a HuBERT that runs beside the whole F0 model on its own part of the chip
+      const int cus = getenv("RVCX_HUBERT_CUS") ? atoi(getenv("RVCX_HUBERT_CUS")) : 0;
+      if (cus > 0 && cus < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+        RVCX_HIP(hipExtStreamCreateWithCUMask(&h->c.aux[1], 8, mask));
+      } else {
+        RVCX_HIP(hipStreamCreateWithFlags(&h->c.aux[1], hipStreamNonBlocking));
+      }
+    }
     for (auto& e : h->c.ev_aux) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RVCX_HIP(hipEventCreateWithFlags(&h->c.ev_fork, hipEventDisableTiming));
     for (auto& e : h->c.ev_src) RVCX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
