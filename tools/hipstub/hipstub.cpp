@@ -72,6 +72,8 @@ hipError_t hipMalloc(void** p, size_t n) {
   *p = malloc(n);
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p);
 hipError_t hipFree(void* p) {
   if (!p) return hipSuccess;
   {
@@ -105,12 +107,14 @@ hipError_t hipMemset(void* d, int v, size_t n) {
 }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
 
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
   *s = reinterpret_cast<hipStream_t>(new Obj{1});
   ++g_live_streams;
   return hipSuccess;
 }
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { return hipStreamCreateWithFlags(s, 0); }
 hipError_t hipStreamDestroy(hipStream_t s) {
   delete reinterpret_cast<Obj*>(s);
   --g_live_streams;
