@@ -746,17 +746,33 @@ void launch_gru_input(const float* x, float* y, int B, int Cc, int T, int Wp, hi
 
 // to_local_average_cents + decode + range gate.  numpy semantics reproduced: first-max argmax,
 // float32 salience x float64 cents mapping, float32 weight sum in numpy's 8-lane pairwise order.
-__global__ void decode_f0_kernel(const float* sal, float* f0, int T, int ld, float thred, float f0_min,
-                                 float f0_max, long total) {
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+// Round 6: one WAVE per frame (a thread per frame read its 360 bins with a stride of `ld` floats between neighbouring
+// lanes: 32 us for 3201 frames, on the single clip's critical path and once per utterance in a batch).  Lane l scans bins
+// l, l + 64, ... (its first maximum), the wave reduces (value, index) with ties to the lower index -- the same first-max
+// argmax -- and lane 0 forms the nine-bin average exactly as before: same bits.
+__global__ __launch_bounds__(256) void decode_f0_kernel(const float* sal, float* f0, int T, int ld, float thred, float f0_min,
+                                                        float f0_max, long total) {
+  const int lane = threadIdx.x & 63;
+  for (long idx = blockIdx.x * 4L + (threadIdx.x >> 6); idx < total; idx += (long)gridDim.x * 4) {
     const float* s = sal + idx * ld;
-    int center = 0;
-    float mx = s[0];
-    for (int i = 1; i < 360; ++i)
-      if (s[i] > mx) {
-        mx = s[i];
+    int center = lane;
+    float mx = lane < 360 ? s[lane] : -INFINITY;
+    for (int i = lane + 64; i < 360; i += 64) {
+      const float v = s[i];
+      if (v > mx) {
+        mx = v;
         center = i;
       }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(mx, o);
+      const int c2 = __shfl_xor(center, o);
+      if (v2 > mx || (v2 == mx && c2 < center)) {
+        mx = v2;
+        center = c2;
+      }
+    }
+    if (lane != 0) continue;
     float w[9];
     double pw[9];
     for (int k = 0; k < 9; ++k) {
@@ -779,7 +795,8 @@ __global__ void decode_f0_kernel(const float* sal, float* f0, int T, int ld, flo
 void launch_decode_f0(const float* sal, float* f0, int B, int T, int ld, float thred, float f0_min, float f0_max,
                       hipStream_t s) {
   long tot = (long)B * T;
-  hipLaunchKernelGGL(decode_f0_kernel, EW_GRID(tot), 0, s, sal, f0, T, ld, thred, f0_min, f0_max, tot);
+  hipLaunchKernelGGL(decode_f0_kernel, dim3((unsigned)std::min<long>((tot + 3) / 4, 65535)), dim3(256), 0, s, sal, f0, T, ld, thred,
+                     f0_min, f0_max, tot);
 }
 
 __global__ void f0_coarse_kernel(const float* f0_in, float* f0_out, int* coarse, int n, double shift, double mel_min,
