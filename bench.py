@@ -662,6 +662,12 @@ def main():
         cfgd["c5_value"] = _val(c5_obj, "value")
         cfgd["long_clip_value"] = _val(long_obj, "value")
         cfgd["full_decoder_value"] = _val(full_dec_obj, "value")
+        # `value` is PCIe-inclusive (host PCM in, host int16 out: SURVEY 8d).  The same step from its first kernel to its last
+        # on the device (HIP events of the last timed step: input already in HBM, output left there), for a reader who wants
+        # the device-resident rate beside it -- never the headline
+        if stage and stage.get("total") and world == 1 and not (c3 or c5) and B == 1:
+            cfgd["device_resident_value"] = clip_seconds / (stage["total"] * 1e-3)
+            cfgd["device_resident_note"] = "audio seconds / the device-side span of one step (first kernel -> last kernel, H2D / D2H outside)"
         cfgd["roofline_traffic_ratio"] = (None if roofline is None or not roofline.get("traffic") else
                                           roofline["traffic"] / dom_algo_bytes_per_launch())
         cfgd["roofline_traffic_ratio_note"] = ("PMC bytes per launch of the dominant kernel / its algorithmic bytes "
