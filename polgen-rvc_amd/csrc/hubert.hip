@@ -90,7 +90,8 @@ size_t hubert_arena_bytes(const HubertModel& m, int B, int64_t n) {
   const size_t v1_extra = m.has_final_proj ? (size_t)B * m.cfg.embed_dim * T * sizeof(float) + 256 : 0;   // layer-9 map of the v1 path
   size_t conv = 2 * (size_t)m.cfg.conv_dim * t0;
   size_t enc = (size_t)T * (size_t)(11 * m.cfg.embed_dim + m.cfg.ffn_dim + 64 + (8 * 98 + 2 * 96 + 8) * m.cfg.heads);
-  return (size_t)B * (conv + enc) * sizeof(float) + v1_extra + ((size_t)64 << 20);
+  const size_t gn0 = hubert_conv0_part_doubles(B, m.cfg.conv_dim, (int)t0) * sizeof(double) + 256;   // fused conv0 + GroupNorm partial sums
+  return (size_t)B * (conv + enc) * sizeof(float) + v1_extra + gn0 + ((size_t)64 << 20);
 }
 
 void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64_t n, int output_layer,
@@ -168,6 +169,30 @@ void hubert_forward(Ctx& c, const HubertModel& m, int B, const float* wav, int64
     if (i > 0 && split_after(i)) {
       a.y_split = y;
       a.y = nullptr;
+    }
+    // Round 6: layer 0 (a Cin = 1 FIR) is recomputed inside its GroupNorm's two passes instead of being stored (ops.hip:
+    // hubert_conv0_*): the (B, 512, T0) fp32 map -- 210 MB per 32 s clip, written once and read twice -- never exists.
+    // RVCX_HUBERT_FUSE0=0: the three separate passes.
+    static const bool fuse0_on = !getenv("RVCX_HUBERT_FUSE0") || atoi(getenv("RVCX_HUBERT_FUSE0")) != 0;
+    // For micro-batches only (B >= 8: 256 blocks of 16 channels): the recomputed statistics pass is VALU-bound and as long as
+    // the read it replaces (368 vs 363 us at B = 8); at B = 1 its 32 - 128 blocks are latency-bound (170 us against 45) and
+    // the fusion loses 0.1 ms.  Both forms produce the same bits (same FIR, same order of the sums), so a batch member
+    // still equals its single run.
+    const bool fuse0 = i == 0 && fuse0_on && split_after(0) && m.convs[0].cin == 1 && m.convs[0].groups == 1 && !m.convs[0].bias &&
+                       m.convs[0].w && cf.conv_kernels[0] <= 16 && (long)B * (C / 16) >= 256;
+    if (fuse0) {
+      float* z = (y == bufa) ? bufb : bufa;
+      double* part = A.alloc<double>(hubert_conv0_part_doubles(B, C, (int)Tout));
+      launch_hubert_conv0_gn_gelu_split(wav, wav_bs > 0 ? wav_bs : (long)n, m.convs[0].w, cf.conv_kernels[0], cf.conv_strides[0],
+                                        m.convs[0].cin_gp * m.convs[0].cout_gp, m.gn_g, m.gn_b, part, gn_stats, z, B, C, (int)Tout, 1e-5f, s, d_t0,
+                                        c.dev_err, m.convs[1].ovf_word, ++c.launch_seq);
+      c.flops += 2.0 * cf.conv_kernels[0] * C * (double)Tout * B * 2;      // the FIR, evaluated twice
+      RVCX_HIP(hipGetLastError());
+      y = z;
+      x = y;
+      y = (y == bufa) ? bufb : bufa;
+      Tin = Tout;
+      continue;
     }
     c.conv_on(a, s);
     if (i == 0) {

@@ -49,6 +49,13 @@ void launch_cf_to_tm(const float* x, long x_bs, float* y, long ld_y, void* ys, l
 void launch_groupnorm_gelu(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                            float eps, hipStream_t s, const int* lens = nullptr);
 // the same with the output already split for a conv_h3 tile that reads ConvArgs::x_split (stats: B*C*2 floats of scratch)
+// HuBERT's first extractor layer (Cin = 1 FIR) + GroupNorm + GELU + split store without the fp32 map in between (ops.hip);
+// Cp: floats between two taps of the packed fp32 weights (cin_gp * cout_gp); part: hubert_conv0_part_doubles(B, C, T)
+// doubles of scratch, stats: B * C * 2 floats
+size_t hubert_conv0_part_doubles(int B, int C, int T);
+void launch_hubert_conv0_gn_gelu_split(const float* wav, long wav_bs, const float* w, int K, int stride, int Cp, const float* gamma,
+                                       const float* beta, double* part, float* stats, void* y_split, int B, int C, int T,
+                                       float eps, hipStream_t s, const int* lens, int* ovf, int* ovf_layer, int seq);
 void launch_groupnorm_gelu_split(const float* x, const float* gamma, const float* beta, float* stats, void* y_split, int B,
                                  int C, int T, float eps, hipStream_t s, const int* lens, int* ovf, int* ovf_layer, int seq);
 // (B,R,Cc) -> (B,Cc,R)

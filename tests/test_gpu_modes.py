@@ -128,3 +128,10 @@ def test_full_decoder_evaluation_passes_the_reference_goldens_too():
     reference goldens (tiny multi-chunk, CI arguments, C2 full size, float waveform) and the full-size batch == single tests."""
     _run_mode({"RVCX_DEC_WINDOW": "0"})
     _run_mode({"RVCX_DEC_WINDOW": "0"}, "test_gpu_fullsize_batch.py", "c3_batch_of_8 or ragged_full_size", "2 passed")
+
+
+def test_unfused_hubert_first_layer_passes_the_hubert_goldens():
+    """RVCX_HUBERT_FUSE0=0 (round 6): the extractor's first layer as conv -> GroupNorm statistics -> normalise + GELU + split
+    over a stored fp32 map, instead of the FIR recomputed inside the two GroupNorm passes (ops.hip: hubert_conv0_*)."""
+    _run_mode({"RVCX_HUBERT_FUSE0": "0"}, "test_gpu_rmvpe_hubert.py", "hubert", "passed")
+    _run_mode({"RVCX_HUBERT_FUSE0": "0"}, "test_gpu_ragged.py", "ragged", "passed")
